@@ -1,0 +1,336 @@
+"""Generate the golden vectors under tests/golden/ from the reference checkout.
+
+Runs ONLY in the build container (needs /root/reference, CPU torch).  Nothing on the GPU box reads the
+reference: the .npz / .json files this script writes are committed and are the only thing that travels.
+
+What it captures, always with the reference's seed (5000) and the reference's own model / loss files
+imported by path (BasicGANs/models.py, BasicGANs/loss_functions.py):
+
+  ops_*.npz            known-answer vectors per convolution geometry class, produced with the call forms
+                       the reference uses (torch.nn.Conv2d / ConvTranspose2d / F.conv2d / F.conv_transpose2d)
+  dcgan_trace.npz      one DCGAN G+D step (get_minimax_loss, step order of BasicGANs/DCGAN.py:165-181) on a
+                       reduced model (hidden_dim 8, batch 2): every conv layer's input, weight, output,
+                       grad-output, dgrad and the parameter gradients
+  wgangp_trace.npz     one WGAN-GP critic iteration + one generator iteration (get_wasserstein_loss,
+                       BasicGANs/train.py:95-119) incl. the gradient-penalty double backward, reduced model
+  dcgan_losses.json    loss scalars of 3 full-size DCGAN-64 steps (hidden 64, batch 128) with Adam
+  wgangp_losses.json   loss scalars of 1 full cycle (5 critic + 1 generator) WGAN-GP-64 at batch 64 with Adam
+
+Usage:  python tests/golden/make_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import hashlib
+import importlib.util
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.dont_write_bytecode = True  # the reference tree is read-only
+SEED = 5000
+
+
+def load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def seed_all(seed=SEED):
+    random.seed(seed)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+
+
+def weights_init(m):
+    # BasicGANs/utils.py:31-36 (that file imports cv2, which is not installed, so it is restated here)
+    if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+        torch.nn.init.normal_(m.weight, 0.0, 0.02)
+    if isinstance(m, torch.nn.BatchNorm2d):
+        torch.nn.init.normal_(m.weight, 0.0, 0.02)
+        torch.nn.init.constant_(m.bias, 0)
+
+
+def checksum(t):
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------------- ops
+OP_CASES = [
+    # name, kind, N, Cin, H, W, Cout, k, stride, pad, bias, output_padding
+    ("conv_k4s2p1_c3", "conv", 2, 3, 16, 16, 16, 4, 2, 1, False, 0),       # BasicGANs D first layer
+    ("conv_k4s2p1_c32", "conv", 2, 32, 16, 16, 64, 4, 2, 1, True, 0),      # BasicGANs / Pix2Pix / PatchGAN
+    ("conv_k4s1p0_c64", "conv", 3, 64, 4, 4, 1, 4, 1, 0, False, 0),        # BasicGANs D last layer (4x4 -> 1x1)
+    ("conv_k4s1p1_c16", "conv", 2, 16, 9, 9, 24, 4, 1, 1, True, 0),        # PatchGAN conv_4/5 (odd output size)
+    ("conv_k3s1p1_c24", "conv", 2, 24, 10, 12, 40, 3, 1, 1, True, 0),      # StyleGAN / BigGAN 3x3
+    ("conv_k1s1p0_c40", "conv", 2, 40, 7, 5, 3, 1, 1, 0, True, 0),         # toRGB / fromRGB / BigGAN skip 1x1
+    ("conv_k3s1p1_c513", "conv", 1, 513, 4, 4, 8, 3, 1, 1, True, 0),       # StyleGAN D minibatch-std layer
+    ("convt_k4s1p0_c100", "convt", 3, 100, 1, 1, 32, 4, 1, 0, False, 0),   # BasicGANs G first layer (1x1 -> 4x4)
+    ("convt_k4s2p1_c32", "convt", 2, 32, 8, 8, 16, 4, 2, 1, True, 0),      # BasicGANs G / Pix2Pix decoder / FusedUpsample
+    ("convt_k4s2p1_c16_o3", "convt", 2, 16, 8, 8, 3, 4, 2, 1, False, 0),   # BasicGANs G last layer (Cout 3)
+    ("convt_k3s2p1_op1", "convt", 2, 8, 5, 5, 8, 3, 2, 1, True, 1),        # Pix2PixHD upsampling (output_padding)
+]
+
+
+def make_ops(out):
+    seed_all()
+    blob = {}
+    for (name, kind, N, Cin, H, W, Cout, k, s, p, bias, op) in OP_CASES:
+        if kind == "conv":
+            m = torch.nn.Conv2d(Cin, Cout, k, s, p, bias=bias)
+        else:
+            m = torch.nn.ConvTranspose2d(Cin, Cout, k, s, p, output_padding=op, bias=bias)
+        torch.nn.init.normal_(m.weight, 0.0, 0.5)
+        x = torch.randn(N, Cin, H, W, requires_grad=True)
+        y = m(x)
+        gy = torch.randn_like(y)
+        grads = torch.autograd.grad(y, [x, m.weight] + ([m.bias] if bias else []), gy)
+        blob[name + ".x"] = x.detach().numpy()
+        blob[name + ".w"] = m.weight.detach().numpy()
+        if bias:
+            blob[name + ".b"] = m.bias.detach().numpy()
+            blob[name + ".gb"] = grads[2].numpy()
+        blob[name + ".y"] = y.detach().numpy()
+        blob[name + ".gy"] = gy.numpy()
+        blob[name + ".gx"] = grads[0].numpy()
+        blob[name + ".gw"] = grads[1].numpy()
+        blob[name + ".meta"] = np.array([N, Cin, H, W, Cout, k, s, p, int(bias), op, int(kind == "convt")], np.int64)
+    # depthwise blur as the reference calls it (StyleGAN/model.py:95: F.conv2d(x, kernel, padding=1, groups=C))
+    C = 6
+    kern = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.0
+    kern = kern.view(1, 1, 3, 3).repeat(C, 1, 1, 1)
+    x = torch.randn(2, C, 9, 7)
+    blob["blur.x"] = x.numpy()
+    blob["blur.y"] = F.conv2d(x, kern, padding=1, groups=C).numpy()
+    np.savez_compressed(os.path.join(out, "ops.npz"), **blob)
+    print("ops.npz:", len(OP_CASES), "cases")
+
+
+# --------------------------------------------------------------------------------------------- traces
+class ConvTap:
+    """Records (x, y, gy, gx) of every Conv2d / ConvTranspose2d call, in call order."""
+
+    def __init__(self, net, tag):
+        self.records = []
+        self.tag = tag
+        for name, mod in net.named_modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                mod.register_forward_hook(self._hook(name))
+
+    def _hook(self, name):
+        def fn(mod, inp, out):
+            rec = {"name": name, "x": inp[0].detach().clone(), "y": out.detach().clone()}
+            self.records.append(rec)
+            if out.requires_grad:
+                out.register_hook(lambda g, rec=rec: rec.__setitem__("gy", g.detach().clone()))
+            if inp[0].requires_grad:
+                inp[0].register_hook(lambda g, rec=rec: rec.__setitem__("gx", g.detach().clone()))
+        return fn
+
+    def dump(self, blob, prefix):
+        for i, rec in enumerate(self.records):
+            for key in ("x", "y", "gy", "gx"):
+                if key in rec:
+                    blob[f"{prefix}.{self.tag}.call{i:02d}.{rec['name']}.{key}"] = rec[key].numpy()
+
+
+def make_dcgan_trace(ref, out):
+    models = load_by_path("ref_basic_models", os.path.join(ref, "BasicGANs/models.py"))
+    losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
+    seed_all()
+    B, hd, nz, res = 2, 8, 100, 64
+    net_G = models.Generator(nz, hd, 3, resolution=res); net_G.apply(weights_init)
+    net_D = models.Discriminator(3, hd, resolution=res); net_D.apply(weights_init)
+    blob = {}
+    for k, v in net_G.state_dict().items():
+        blob["init.G." + k] = v.clone().numpy()
+    for k, v in net_D.state_dict().items():
+        blob["init.D." + k] = v.clone().numpy()
+    real = torch.rand(B, 3, res, res) * 2 - 1
+    z = torch.randn(B, nz, 1, 1)
+    blob["real"] = real.numpy(); blob["z"] = z.numpy()
+    tapG, tapD = ConvTap(net_G, "G"), ConvTap(net_D, "D")
+    criterion = torch.nn.BCELoss()
+    # step order: BasicGANs/DCGAN.py:165-181
+    net_D.zero_grad()
+    label = torch.full((B,), 1.0)
+    D_error, D_G_z1, D_x, fake = losses.get_minimax_loss(net_G, net_D, criterion, label, real, z, 0.0)
+    for k, p in net_D.named_parameters():
+        blob["dphase.gradD." + k] = p.grad.clone().numpy()
+    blob["dphase.scalars"] = np.array([D_error.item(), D_G_z1, D_x], np.float64)
+    net_G.zero_grad()
+    label.fill_(1.0)
+    G_error, D_G_z2 = losses.get_minimax_loss(net_G, net_D, criterion, label, fake, discriminator=False)
+    for k, p in net_G.named_parameters():
+        blob["gphase.gradG." + k] = p.grad.clone().numpy()
+    blob["gphase.scalars"] = np.array([G_error.item(), D_G_z2], np.float64)
+    blob["fake"] = fake.detach().numpy()
+    tapG.dump(blob, "trace"); tapD.dump(blob, "trace")
+    for k, v in net_G.state_dict().items():   # BatchNorm running statistics after the step
+        if "running" in k:
+            blob["after.G." + k] = v.clone().numpy()
+    for k, v in net_D.state_dict().items():
+        if "running" in k:
+            blob["after.D." + k] = v.clone().numpy()
+    np.savez_compressed(os.path.join(out, "dcgan_trace.npz"), **blob)
+    print("dcgan_trace.npz:", len(blob), "arrays; scalars", blob["dphase.scalars"], blob["gphase.scalars"])
+
+
+def make_wgangp_trace(ref, out):
+    models = load_by_path("ref_basic_models", os.path.join(ref, "BasicGANs/models.py"))
+    losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
+    seed_all()
+    B, hd, nz, res = 4, 8, 100, 64
+    net_G = models.Generator(nz, hd, 3, resolution=res); net_G.apply(weights_init)
+    net_D = models.Discriminator(3, hd, resolution=res, is_wgan=True); net_D.apply(weights_init)
+    blob = {}
+    for k, v in net_G.state_dict().items():
+        blob["init.G." + k] = v.clone().numpy()
+    for k, v in net_D.state_dict().items():
+        blob["init.D." + k] = v.clone().numpy()
+    real = torch.rand(B, 3, res, res) * 2 - 1
+    z = torch.randn(B, nz, 1, 1)
+    z1 = torch.randn(B, nz, 1, 1)
+    blob["real"] = real.numpy(); blob["z"] = z.numpy(); blob["z1"] = z1.numpy()
+    # capture the epsilon the loss function draws internally (loss_functions.py:18)
+    drawn = []
+    orig_rand = torch.rand
+
+    def rand_spy(*a, **kw):
+        t = orig_rand(*a, **kw)
+        drawn.append(t.detach().clone())
+        return t
+    torch.rand = rand_spy
+    try:
+        for p in net_D.parameters():
+            p.grad = None
+        D_x, D_G_z1, gp = losses.get_wasserstein_loss(net_G, net_D, real, z)
+    finally:
+        torch.rand = orig_rand
+    blob["epsilon"] = drawn[0].numpy()
+    blob["critic.scalars"] = np.array([D_x.item(), D_G_z1, gp.item()], np.float64)
+    for k, p in net_D.named_parameters():
+        blob["critic.gradD." + k] = p.grad.clone().numpy()
+    # the first-order gradient w.r.t. the mixed images, recomputed the way the loss does (loss_functions.py:19-25)
+    eps = drawn[0].clone().requires_grad_(True)
+    with torch.no_grad():
+        fake = net_G(z)
+    mixed = real * eps + fake * (1 - eps)
+    g = torch.autograd.grad(outputs=net_D(mixed).sum(), inputs=mixed, create_graph=False)[0]
+    blob["critic.mixed_grad"] = g.numpy()
+    blob["fake"] = fake.numpy()
+    for p in net_G.parameters():
+        p.grad = None
+    for p in net_D.parameters():
+        p.grad = None
+    G_error, D_G_z2 = losses.get_wasserstein_loss(net_G, net_D, noise_vector=z1, discriminator=False)
+    blob["gen.scalars"] = np.array([G_error.item(), D_G_z2], np.float64)
+    for k, p in net_G.named_parameters():
+        blob["gen.gradG." + k] = p.grad.clone().numpy()
+    np.savez_compressed(os.path.join(out, "wgangp_trace.npz"), **blob)
+    print("wgangp_trace.npz:", len(blob), "arrays; scalars", blob["critic.scalars"], blob["gen.scalars"])
+
+
+# --------------------------------------------------------------------------------------- loss curves
+def synth_inputs(gen, B, nz, res, n_z):
+    """Synthetic inputs drawn from a dedicated CPU generator so that the same numbers can be regenerated
+    on any machine with the same torch version (checksums are stored to detect drift)."""
+    real = torch.rand(B, 3, res, res, generator=gen) * 2 - 1
+    zs = [torch.randn(B, nz, 1, 1, generator=gen) for _ in range(n_z)]
+    return real, zs
+
+
+def make_dcgan_losses(ref, out, steps=3):
+    models = load_by_path("ref_basic_models", os.path.join(ref, "BasicGANs/models.py"))
+    losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
+    seed_all()
+    B, hd, nz, res = 128, 64, 100, 64
+    net_G = models.Generator(nz, hd, 3, resolution=res); net_G.apply(weights_init)
+    net_D = models.Discriminator(3, hd, resolution=res); net_D.apply(weights_init)
+    rec = {"config": {"B": B, "hidden_dim": hd, "nz": nz, "res": res, "seed": SEED, "lr": 2e-4, "betas": [0.5, 0.999],
+                      "data_seed": SEED + 1},
+           "param_count": {"G": sum(p.numel() for p in net_G.parameters()), "D": sum(p.numel() for p in net_D.parameters())},
+           "init_checksum": {"G": checksum(torch.cat([p.flatten() for p in net_G.parameters()])),
+                             "D": checksum(torch.cat([p.flatten() for p in net_D.parameters()]))},
+           "steps": []}
+    opt_D = torch.optim.Adam(net_D.parameters(), lr=2e-4, betas=(0.5, 0.999))   # BasicGANs/DCGAN.py:156-157
+    opt_G = torch.optim.Adam(net_G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    criterion = torch.nn.BCELoss()
+    gen = torch.Generator().manual_seed(SEED + 1)
+    for it in range(steps):
+        real, (z,) = synth_inputs(gen, B, nz, res, 1)
+        if it == 0:
+            rec["input_checksum"] = {"real": checksum(real), "z": checksum(z)}
+        net_D.zero_grad()
+        label = torch.full((B,), 1.0)
+        D_error, D_G_z1, D_x, fake = losses.get_minimax_loss(net_G, net_D, criterion, label, real, z, 0.0)
+        opt_D.step()
+        net_G.zero_grad()
+        label.fill_(1.0)
+        G_error, D_G_z2 = losses.get_minimax_loss(net_G, net_D, criterion, label, fake, discriminator=False)
+        opt_G.step()
+        rec["steps"].append({"D_error": D_error.item(), "D_G_z1": D_G_z1, "D_x": D_x, "G_error": G_error.item(), "D_G_z2": D_G_z2})
+        print("dcgan step", it, rec["steps"][-1])
+    json.dump(rec, open(os.path.join(out, "dcgan_losses.json"), "w"), indent=1)
+
+
+def make_wgangp_losses(ref, out, cycles=1):
+    models = load_by_path("ref_basic_models", os.path.join(ref, "BasicGANs/models.py"))
+    losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
+    seed_all()
+    B, hd, nz, res = 64, 64, 100, 64
+    net_G = models.Generator(nz, hd, 3, resolution=res); net_G.apply(weights_init)
+    net_D = models.Discriminator(3, hd, resolution=res, is_wgan=True); net_D.apply(weights_init)
+    rec = {"config": {"B": B, "hidden_dim": hd, "nz": nz, "res": res, "seed": SEED, "lr": 1e-4, "betas": [0.0, 0.9],
+                      "c_lambda": 10, "disc_repeats": 5, "data_seed": SEED + 1},
+           "param_count": {"G": sum(p.numel() for p in net_G.parameters()), "D": sum(p.numel() for p in net_D.parameters())},
+           "init_checksum": {"G": checksum(torch.cat([p.flatten() for p in net_G.parameters()])),
+                             "D": checksum(torch.cat([p.flatten() for p in net_D.parameters()]))},
+           "cycles": []}
+    opt_D = torch.optim.Adam(net_D.parameters(), lr=1e-4, betas=(0.0, 0.9))     # BasicGANs/train.py:79-80
+    opt_G = torch.optim.Adam(net_G.parameters(), lr=1e-4, betas=(0.0, 0.9))
+    gen = torch.Generator().manual_seed(SEED + 1)
+    orig_rand = torch.rand
+    for c in range(cycles):
+        real, zs = synth_inputs(gen, B, nz, res, 6)
+        eps_all = orig_rand(5, B, 1, 1, 1, generator=gen)
+        if c == 0:
+            rec["input_checksum"] = {"real": checksum(real), "z0": checksum(zs[0]), "eps": checksum(eps_all)}
+        crit = []
+        for it in range(5):                                                      # BasicGANs/train.py:95-107
+            opt_D.zero_grad()
+            # the loss draws epsilon with torch.rand(..., requires_grad=True); substitute the pre-drawn value
+            torch.rand = lambda *a, **kw: eps_all[it].clone().requires_grad_(kw.get("requires_grad", False))
+            try:
+                D_x, D_G_z1, gp = losses.get_wasserstein_loss(net_G, net_D, real, zs[it])
+            finally:
+                torch.rand = orig_rand
+            opt_D.step()
+            crit.append({"D_x": D_x.item(), "D_G_z1": D_G_z1, "gp": gp.item()})
+            print("wgangp critic", c, it, crit[-1])
+        opt_G.zero_grad()
+        G_error, D_G_z2 = losses.get_wasserstein_loss(net_G, net_D, noise_vector=zs[5], discriminator=False, c_lambda=10)
+        opt_G.step()
+        rec["cycles"].append({"critic": crit, "G_error": G_error.item(), "D_G_z2": D_G_z2})
+        print("wgangp gen", c, rec["cycles"][-1]["G_error"])
+    json.dump(rec, open(os.path.join(out, "wgangp_losses.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.dirname(os.path.abspath(__file__)))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses"]
+    if "ops" in todo: make_ops(a.out)
+    if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
+    if "wgangp_trace" in todo: make_wgangp_trace(a.ref, a.out)
+    if "dcgan_losses" in todo: make_dcgan_losses(a.ref, a.out)
+    if "wgangp_losses" in todo: make_wgangp_losses(a.ref, a.out)

@@ -1,0 +1,150 @@
+"""Pins the CPU oracle (oracle/conv_oracle.c, oracle/ref_models.py) against the golden vectors captured from
+the reference's own files (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ref_models as R
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+def op_names(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    return sorted({k.rsplit(".", 1)[0] for k in z.files if k.endswith(".meta")})
+
+
+@pytest.mark.parametrize("name", op_names())
+def test_c_oracle_matches_reference_ops(ops, name):
+    N, Cin, H, W, Cout, k, s, p, has_b, op, is_t = [int(v) for v in ops[name + ".meta"]]
+    x, w, y, gy, gx, gw = (ops[f"{name}.{t}"] for t in ("x", "w", "y", "gy", "gx", "gw"))
+    b = ops[name + ".b"] if has_b else None
+    tol = 2e-6  # oneDNN fp32 accumulation vs double accumulation in the oracle
+    if not is_t:
+        assert rel_err(oracle.conv2d_fprop(x, w, b, s, p), y) < tol
+        assert rel_err(oracle.conv2d_dgrad(gy, w, x.shape, s, p), gx) < tol
+        got_gw, got_gb = oracle.conv2d_wgrad(x, gy, w.shape, s, p, with_bias=True)
+        assert rel_err(got_gw, gw) < tol
+        if has_b:
+            assert rel_err(got_gb, ops[name + ".gb"]) < tol
+    else:
+        assert rel_err(oracle.conv_transpose2d_fprop(x, w, b, s, p, op), y) < tol
+        # a transposed conv is the dgrad of the conv whose OIHW weight is this IOHW weight, so its own
+        # backward passes are that conv's fprop (dx) and wgrad with the roles of x and gy swapped (dw)
+        assert rel_err(oracle.conv2d_dgrad(x, w, y.shape, s, p) + (0 if b is None else b[None, :, None, None]), y) < tol
+        assert rel_err(oracle.conv2d_fprop(gy, w, None, s, p), gx) < tol
+        got_gw, got_gb = oracle.conv2d_wgrad(gy, x, w.shape, s, p, with_bias=False), gy.sum((0, 2, 3))
+        assert rel_err(got_gw, gw) < tol
+        if has_b:
+            assert rel_err(got_gb, ops[name + ".gb"]) < 1e-5
+
+
+def test_c_oracle_blur(ops):
+    assert rel_err(oracle.dwblur3x3(ops["blur.x"]), ops["blur.y"]) < 1e-6
+
+
+def test_round_bf16_matches_torch():
+    x = torch.randn(10000) * 3
+    x[0] = float("nan"); x[1] = float("inf"); x[2] = 0.0; x[3] = 1e-40
+    got = oracle.round_bf16(x.numpy())
+    exp = x.bfloat16().float().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    m = ~np.isnan(exp)
+    assert np.array_equal(got[m], exp[m])
+
+
+def _load_state(net, blob, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(blob[k]) for k in blob.files if k.startswith(prefix)}
+    net.load_state_dict(sd)
+
+
+def test_restated_dcgan_step_matches_reference_trace(golden_dir):
+    z = np.load(os.path.join(golden_dir, "dcgan_trace.npz"))
+    B, hd = z["real"].shape[0], z["init.D.main.0.0.weight"].shape[0]
+    G = R.Generator(100, hd, 3, resolution=64); D = R.Discriminator(3, hd, resolution=64)
+    _load_state(G, z, "init.G."); _load_state(D, z, "init.D.")
+    real, noise = torch.from_numpy(z["real"]), torch.from_numpy(z["z"])
+    crit = torch.nn.BCELoss()
+    D.zero_grad()
+    label = torch.full((B,), 1.0)
+    d_err, d_g_z1, d_x, fake = R.minimax_step(G, D, crit, label, real, noise, 0.0)
+    np.testing.assert_allclose([d_err.item(), d_g_z1, d_x], z["dphase.scalars"], rtol=1e-6)
+    for k, p in D.named_parameters():
+        assert rel_err(p.grad.numpy(), z["dphase.gradD." + k]) < 1e-6, k
+    G.zero_grad(); label.fill_(1.0)
+    g_err, d_g_z2 = R.minimax_step(G, D, crit, label, fake, discriminator=False)
+    np.testing.assert_allclose([g_err.item(), d_g_z2], z["gphase.scalars"], rtol=1e-6)
+    for k, p in G.named_parameters():
+        assert rel_err(p.grad.numpy(), z["gphase.gradG." + k]) < 1e-6, k
+    for k, v in G.state_dict().items():
+        if "running" in k:
+            assert rel_err(v.numpy(), z["after.G." + k]) < 1e-6, k
+
+
+def test_c_oracle_on_reference_layer_traces(golden_dir):
+    """Every conv layer call recorded inside the reference's DCGAN step: C oracle reproduces y and gx."""
+    z = np.load(os.path.join(golden_dir, "dcgan_trace.npz"))
+    calls = sorted({k.rsplit(".", 1)[0] for k in z.files if k.startswith("trace.")})
+    assert len(calls) >= 20
+    for c in calls:
+        net, layer = c.split(".")[1], ".".join(c.split(".")[3:])
+        w = z[f"init.{net}.{layer}.weight"]
+        x, y = z[c + ".x"], z[c + ".y"]
+        first, last = layer == "main.0.0", layer == "main.4.0"
+        if net == "D":
+            s, p = (1, 0) if last else (2, 1)
+            assert rel_err(oracle.conv2d_fprop(x, w, None, s, p), y) < 2e-6, c
+            if c + ".gx" in z.files:
+                assert rel_err(oracle.conv2d_dgrad(z[c + ".gy"], w, x.shape, s, p), z[c + ".gx"]) < 2e-6, c
+        else:
+            s, p = (1, 0) if first else (2, 1)
+            assert rel_err(oracle.conv_transpose2d_fprop(x, w, None, s, p), y) < 2e-6, c
+            if c + ".gx" in z.files:
+                assert rel_err(oracle.conv2d_fprop(z[c + ".gy"], w, None, s, p), z[c + ".gx"]) < 2e-6, c
+
+
+def test_restated_wgangp_matches_reference_trace(golden_dir):
+    z = np.load(os.path.join(golden_dir, "wgangp_trace.npz"))
+    hd = z["init.D.main.0.0.weight"].shape[0]
+    G = R.Generator(100, hd, 3, resolution=64); D = R.Discriminator(3, hd, resolution=64, is_wgan=True)
+    _load_state(G, z, "init.G."); _load_state(D, z, "init.D.")
+    real, noise, noise1 = (torch.from_numpy(z[k]) for k in ("real", "z", "z1"))
+    d_x, d_g_z1, gp = R.wasserstein_step(G, D, real, noise, epsilon=torch.from_numpy(z["epsilon"]))
+    np.testing.assert_allclose([d_x.item(), d_g_z1, gp.item()], z["critic.scalars"], rtol=2e-5)
+    for k, p in D.named_parameters():
+        assert rel_err(p.grad.numpy(), z["critic.gradD." + k]) < 2e-5, k
+    G.zero_grad(); D.zero_grad()
+    g_err, d_g_z2 = R.wasserstein_step(G, D, noise_vector=noise1, discriminator=False)
+    np.testing.assert_allclose([g_err.item(), d_g_z2], z["gen.scalars"], rtol=2e-5)
+    for k, p in G.named_parameters():
+        assert rel_err(p.grad.numpy(), z["gen.gradG." + k]) < 2e-5, k
+
+
+def test_restated_dcgan_full_size_losses(golden_dir):
+    """Full-size DCGAN-64 (hidden 64, batch 128): first step's losses with regenerated inputs and weights."""
+    rec = json.load(open(os.path.join(golden_dir, "dcgan_losses.json")))
+    cfg = rec["config"]
+    torch.manual_seed(cfg["seed"])
+    G = R.Generator(cfg["nz"], cfg["hidden_dim"], 3, resolution=cfg["res"]); G.apply(R.weights_init)
+    D = R.Discriminator(3, cfg["hidden_dim"], resolution=cfg["res"]); D.apply(R.weights_init)
+    assert sum(p.numel() for p in G.parameters()) == rec["param_count"]["G"] == 3576704
+    assert sum(p.numel() for p in D.parameters()) == rec["param_count"]["D"] == 2765568
+    opt_D = torch.optim.Adam(D.parameters(), lr=cfg["lr"], betas=tuple(cfg["betas"]))
+    opt_G = torch.optim.Adam(G.parameters(), lr=cfg["lr"], betas=tuple(cfg["betas"]))
+    gen = torch.Generator().manual_seed(cfg["data_seed"])
+    real, (noise,) = R.synth_inputs(gen, cfg["B"], cfg["nz"], cfg["res"], 1)
+    out = R.dcgan_train_step(G, D, opt_G, opt_D, real, noise)
+    for k, v in rec["steps"][0].items():
+        assert abs(out[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, out[k], v)
