@@ -1,0 +1,93 @@
+"""ctypes binding of libganconv.so (the C ABI declared in include/ganconv.h).
+
+The library is built in-tree by gan_amd/csrc/Makefile (see __graft_entry__.build).  There is no fallback: if
+the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads PyTorch's HIP runtime first so that the library binds to the same runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libganconv.so")
+
+GC_F32, GC_BF16 = 0, 1
+GC_PREC_BF16, GC_PREC_F32X3 = 0, 1
+GC_ACT_NONE, GC_ACT_RELU, GC_ACT_LRELU, GC_ACT_TANH, GC_ACT_SIGMOID = 0, 1, 2, 3, 4
+GC_PASS_FPROP, GC_PASS_DGRAD, GC_PASS_WGRAD = 0, 1, 2
+
+EXPORTS = (
+    "gc_version", "gc_last_error", "gc_packed_weight_bytes", "gc_pack_weight", "gc_conv2d_fprop", "gc_conv2d_dgrad",
+    "gc_wgrad_workspace_bytes", "gc_conv2d_wgrad", "gc_dwblur3x3", "gc_profile_enable", "gc_profile_collect",
+)
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "kh", "kw", "stride_h", "stride_w", "pad_h", "pad_w",
+        "x_dtype", "y_dtype", "precision", "x_cstride", "x_coff", "y_cstride", "y_coff")] + [("reserved", ctypes.c_int32 * 4)]
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("bias", ctypes.c_void_p), ("ch_sum", ctypes.c_void_p),
+                ("ch_sumsq", ctypes.c_void_p), ("reserved", ctypes.c_int32 * 4)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C gan_amd/csrc` (or __graft_entry__.build()); "
+            "gan_amd has no fallback convolution path")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64p = ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)
+    L.gc_version.restype = ctypes.c_int
+    L.gc_last_error.restype = ctypes.c_char_p
+    L.gc_packed_weight_bytes.restype = ctypes.c_size_t
+    L.gc_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int]
+    L.gc_pack_weight.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, vp, i64p, ctypes.c_float, vp, vp]
+    L.gc_conv2d_fprop.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, ctypes.POINTER(Epilogue), vp]
+    L.gc_conv2d_dgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, ctypes.POINTER(Epilogue), vp]
+    L.gc_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    L.gc_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    L.gc_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, i64p, ctypes.c_float, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]
+    L.gc_dwblur3x3.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.gc_profile_enable.argtypes = [ctypes.c_int]
+    L.gc_profile_collect.argtypes = [ctypes.c_int, vp, vp, vp, vp]
+    for fn in ("gc_pack_weight", "gc_conv2d_fprop", "gc_conv2d_dgrad", "gc_conv2d_wgrad", "gc_dwblur3x3", "gc_profile_enable",
+               "gc_profile_collect"):
+        getattr(L, fn).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gc_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"ganconv: {what} failed (status {rc}): {msg}")
+
+
+def strides4(t):
+    return (ctypes.c_int64 * 4)(*[int(s) for s in t.stride()])
+
+
+def profile_enable(on):
+    check(lib().gc_profile_enable(1 if on else 0), "gc_profile_enable")
+
+
+def profile_collect(max_entries=32):
+    names = ((ctypes.c_char * 64) * max_entries)()
+    launches = (ctypes.c_int64 * max_entries)()
+    total_ms = (ctypes.c_double * max_entries)()
+    flops = (ctypes.c_double * max_entries)()
+    n = lib().gc_profile_collect(max_entries, ctypes.cast(names, ctypes.c_void_p), ctypes.cast(launches, ctypes.c_void_p),
+                                 ctypes.cast(total_ms, ctypes.c_void_p), ctypes.cast(flops, ctypes.c_void_p))
+    if n < 0:
+        check(n, "gc_profile_collect")
+    return {names[i].value.decode(): {"launches": int(launches[i]), "total_ms": float(total_ms[i]), "flops": float(flops[i])}
+            for i in range(n)}

@@ -1,0 +1,38 @@
+// Weight-gradient kernel: parameter block shared by host and device.
+#pragma once
+#include "common.h"
+
+namespace gc {
+
+struct WgradParams {
+  const void* x;    // [N, H, W, x_cstride]
+  const void* gy;   // [N, Ho, Wo, y_cstride]
+  float* part;      // split-K partial sums [S][T][Cout][Cin] fp32
+  int32_t N, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw;
+  int32_t x_cstride, x_coff, y_cstride, y_coff;
+  int32_t K;             // N*Ho*Wo: length of the reduction
+  int32_t k_per_split;   // multiple of the reduction step
+  int32_t n_co_tiles, n_ci_tiles, splits;
+  FastDiv div_wo, div_ho;
+};
+
+struct WgradLaunch {
+  int to, tc;
+  bool bf16, x3, aligned;
+};
+
+struct WgradReduceParams {
+  const float* part;
+  float* gw;
+  int64_t s_co, s_ci, s_r, s_s;   // element strides of gw
+  int32_t Cout, Cin, kh, kw, splits;
+  float alpha;
+  int32_t accumulate;
+};
+
+void plan_wgrad(WgradParams& p, WgradLaunch& l);
+int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
+int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream);
+int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream);
+
+}  // namespace gc

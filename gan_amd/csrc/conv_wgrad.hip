@@ -1,0 +1,294 @@
+// Weight gradient on the bf16 matrix cores:  gw[tap][co][ci] = sum over pixels k of  gy[k][co] * x[gather(k, tap)][ci]
+//
+// GEMM view: rows = output channels, columns = input channels (of one filter tap), reduction = the N*Ho*Wo
+// output pixels.  Both operands are stored pixel-major in HBM (NHWC), i.e. with the reduction index on the slow
+// axis, so the LDS tiles keep that orientation ([pixel][channel], XOR-swizzled 32-byte segments) and the MFMA
+// fragments are formed with the transposing LDS read (ds_read_b64_tr_b16).  The reduction is split across
+// workgroups (grid.z); every split writes its partial tile with plain stores and a second small kernel sums
+// the splits in a fixed order, scales, and scatters into the caller's [Cout][Cin][kh][kw] layout -- bitwise
+// reproducible, no float atomics.
+#include "conv_wgrad.h"
+
+namespace gc {
+
+constexpr int kWBK = 32;  // pixels per reduction step
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <int ROWB>
+__device__ __forceinline__ int wswz(int k) {
+  return ROWB == 256 ? ((k & 3) | (((k >> 3) & 1) << 2)) : (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+}
+
+template <typename T, int TO, int TC, bool X3, bool ALIGNED>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int PL = X3 ? 2 : 1;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int CPRY = TO / EPC, RPPY = kThreads / CPRY, PY = kWBK / RPPY;
+  constexpr int CPRX = TC / EPC, RPPX = kThreads / CPRX, PX = kWBK / RPPX;
+  constexpr int ROWBY = TO * 2, ROWBX = TC * 2;
+  constexpr int Y_BYTES = kWBK * ROWBY, X_BYTES = kWBK * ROWBX;
+  constexpr int STAGE = PL * (Y_BYTES + X_BYTES);
+  constexpr int FO = TO / 32, FC = TC / 32;
+  static_assert(PY >= 1 && PX >= 1, "tile too narrow for the load mapping");
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wo = wave >> 1, wc = wave & 1;
+  const int tile = blockIdx.x;
+  const int co0 = (tile / p.n_ci_tiles) * TO, ci0 = (tile % p.n_ci_tiles) * TC;
+  const int tap = blockIdx.y, r = tap / p.kw, s = tap % p.kw;
+  const int split = blockIdx.z;
+  const int kb0 = split * p.k_per_split;
+  const int kend = min(p.K, kb0 + p.k_per_split);
+
+  const T* gy = reinterpret_cast<const T*>(p.gy);
+  const T* x = reinterpret_cast<const T*>(p.x);
+  const int cy = t % CPRY, cx = t % CPRX;
+
+  u32x4 yreg[PY], xreg[PX];
+
+  auto load_chunk = [&](const T* src, int c_first, int c_limit, bool ok) -> u32x4 {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ALIGNED) {
+      if (ok && c_first < c_limit) v = *reinterpret_cast<const u32x4*>(src);
+    } else if (ok) {
+      if (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (c_first + e < c_limit) v[e] = reinterpret_cast<const uint32_t*>(src)[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if (c_first + e < c_limit) v[e >> 1] |= (uint32_t)reinterpret_cast<const uint16_t*>(src)[e] << (16 * (e & 1));
+      }
+    }
+    return v;
+  };
+
+  auto load_tile = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < PY; i++) {
+      const int k = kb + t / CPRY + RPPY * i;
+      const int c = co0 + cy * EPC;
+      yreg[i] = load_chunk(gy + ((size_t)k * p.y_cstride + p.y_coff + c), c, p.Cout, k < kend);
+    }
+#pragma unroll
+    for (int i = 0; i < PX; i++) {
+      const int k = kb + t / CPRX + RPPX * i;
+      const uint32_t kk = k < kend ? (uint32_t)k : 0u;
+      const uint32_t q1 = fd_div(kk, p.div_wo);
+      const int wo_ = (int)(kk - q1 * p.div_wo.d);
+      const uint32_t n = fd_div(q1, p.div_ho);
+      const int ho_ = (int)(q1 - n * p.div_ho.d);
+      const int ih = ho_ * p.sh - p.ph + r, iw = wo_ * p.sw - p.pw + s;
+      const bool ok = k < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const int c = ci0 + cx * EPC;
+      xreg[i] = load_chunk(x + (((size_t)n * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff + c, c, p.Cin, ok);
+    }
+  };
+
+  auto store_one = [&](char* base, int plane_bytes, int rowb_sel, int row, int ch, u32x4 v) {
+    // ch: 16-byte chunk index of the source row; rowb_sel: 0 -> gy tile, 1 -> x tile
+    const int rowb = rowb_sel ? ROWBX : ROWBY;
+    const int f = rowb_sel ? wswz<ROWBX>(row) : wswz<ROWBY>(row);
+    if (sizeof(T) == 4) {
+      const f32x4 fv = __builtin_bit_cast(f32x4, v);
+      const u32x2 hi = cvt_bf16x4(fv);
+      const int off = row * rowb + (((ch >> 2) ^ f) << 5) + (ch & 3) * 8;
+      *reinterpret_cast<u32x2*>(base + off) = hi;
+      if (X3) *reinterpret_cast<u32x2*>(base + plane_bytes + off) = cvt_bf16x4(fv - widen_bf16x4(hi));
+    } else {
+      *reinterpret_cast<u32x4*>(base + row * rowb + (((ch >> 1) ^ f) << 5) + (ch & 1) * 16) = v;
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* yb = smem + buf * STAGE;
+    char* xb = yb + PL * Y_BYTES;
+#pragma unroll
+    for (int i = 0; i < PY; i++) store_one(yb, Y_BYTES, 0, t / CPRY + RPPY * i, cy, yreg[i]);
+#pragma unroll
+    for (int i = 0; i < PX; i++) store_one(xb, X_BYTES, 1, t / CPRX + RPPX * i, cx, xreg[i]);
+  };
+
+  f32x4 acc[FO][FC];
+#pragma unroll
+  for (int i = 0; i < FO; i++)
+#pragma unroll
+    for (int j = 0; j < FC; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposing read: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) addresses row 8g+q (+4), columns 4pp..4pp+3
+  // of a 16-channel segment and receives, for channel lane&15, the four rows 8g..8g+3 (+4): exactly k = 8g+j.
+  const int k0 = 8 * (lane >> 4) + ((lane >> 2) & 3);
+  const int sub = (lane & 3) * 8;
+
+  auto read_frag = [&](const char* base, int rowb, int f, int seg) -> bf16x8 {
+    const char* a0 = base + k0 * rowb + ((seg ^ f) << 5) + sub;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 4 * rowb));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  auto compute = [&](int buf) {
+    const char* yb = smem + buf * STAGE;
+    const char* xb = yb + PL * Y_BYTES;
+    const int fy = wswz<ROWBY>(k0), fx = wswz<ROWBX>(k0);
+    bf16x8 a[PL][FO], b[PL][FC];
+#pragma unroll
+    for (int pl = 0; pl < PL; pl++) {
+#pragma unroll
+      for (int i = 0; i < FO; i++) a[pl][i] = read_frag(yb + pl * Y_BYTES, ROWBY, fy, wo * FO + i);
+#pragma unroll
+      for (int j = 0; j < FC; j++) b[pl][j] = read_frag(xb + pl * X_BYTES, ROWBX, fx, wc * FC + j);
+    }
+#pragma unroll
+    for (int i = 0; i < FO; i++)
+#pragma unroll
+      for (int j = 0; j < FC; j++) {
+        if (X3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  const int nsteps = kend > kb0 ? (kend - kb0 + kWBK - 1) / kWBK : 0;
+  if (nsteps > 0) {
+    load_tile(kb0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int it = 0; it < nsteps; it++) {
+    const bool more = it + 1 < nsteps;
+    if (more) load_tile(kb0 + (it + 1) * kWBK);
+    compute(it & 1);
+    if (more) store_tile((it + 1) & 1);
+    __syncthreads();
+  }
+
+  float* part = p.part + ((size_t)split * (p.kh * p.kw) + tap) * p.Cout * p.Cin;
+#pragma unroll
+  for (int i = 0; i < FO; i++)
+#pragma unroll
+    for (int j = 0; j < FC; j++) {
+      const int ci = ci0 + wc * (TC / 2) + j * 16 + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int co = co0 + wo * (TO / 2) + i * 16 + (lane >> 4) * 4 + e;
+        if (co < p.Cout && ci < p.Cin) part[(size_t)co * p.Cin + ci] = acc[i][j][e];
+      }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const WgradReduceParams p) {
+  const size_t per_tap = (size_t)p.Cout * p.Cin;
+  const size_t total = per_tap * p.kh * p.kw;
+  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
+    float sum = 0.f;
+    for (int sp = 0; sp < p.splits; sp++) sum += p.part[(size_t)sp * total + e];
+    const int tap = (int)(e / per_tap);
+    const size_t rem = e - (size_t)tap * per_tap;
+    const int co = (int)(rem / p.Cin), ci = (int)(rem - (size_t)co * p.Cin);
+    float* dst = p.gw + co * p.s_co + ci * p.s_ci + (tap / p.kw) * p.s_r + (tap % p.kw) * p.s_s;
+    const float v = p.alpha * sum;
+    *dst = p.accumulate ? *dst + v : v;
+  }
+}
+
+// gb[c] += sum over pixels of gy[k][c]; gb is zeroed by the launcher.  One block sums a run of pixels.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void colsum_kernel(const T* gy, float* gb, int K, int C, int cstride, int coff, int k_per_block) {
+  const int k0 = blockIdx.x * k_per_block, k1 = min(K, k0 + k_per_block);
+  // threads are laid out [pixel lane][channel]: tc channels wide
+  const int tc = C >= kThreads ? kThreads : C;
+  const int tk = kThreads / tc;
+  const int c_lane = threadIdx.x % tc, k_lane = threadIdx.x / tc;
+  __shared__ float red[kThreads];
+  for (int cb = 0; cb < C; cb += tc) {
+    const int c = cb + c_lane;
+    float s = 0.f;
+    if (k_lane < tk && c < C)
+      for (int k = k0 + k_lane; k < k1; k += tk) {
+        const T v = gy[(size_t)k * cstride + coff + c];
+        s += sizeof(T) == 4 ? __builtin_bit_cast(float, (uint32_t)v) : bf16_bits_to_float((uint16_t)v);
+      }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (k_lane == 0 && c < C) {
+      for (int j = 1; j < tk; j++) s += red[j * tc + c_lane];
+      atomicAdd(gb + c, s);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+void plan_wgrad(WgradParams& p, WgradLaunch& l) {
+  l.to = p.Cout <= 64 ? 64 : 128;
+  l.tc = p.Cin <= 64 ? 64 : 128;
+  p.n_co_tiles = (p.Cout + l.to - 1) / l.to;
+  p.n_ci_tiles = (p.Cin + l.tc - 1) / l.tc;
+  const long tiles = (long)p.n_co_tiles * p.n_ci_tiles * p.kh * p.kw;
+  if (p.K <= 0) { p.k_per_split = kWBK; p.splits = 1; return; }
+  // enough splits for about four workgroups per CU, each split at least 8 reduction steps long
+  long want = (4 * 256 + tiles - 1) / tiles;
+  const long max_splits = (p.K + 8 * kWBK - 1) / (8 * kWBK);
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  long kps = (p.K + want - 1) / want;
+  kps = (kps + kWBK - 1) / kWBK * kWBK;
+  p.k_per_split = (int)kps;
+  p.splits = (int)((p.K + kps - 1) / kps);
+}
+
+template <typename T, int TO, int TC, bool X3, bool ALIGNED>
+static int launch_one(const WgradParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TO, TC, X3, ALIGNED>),
+                     dim3(p.n_co_tiles * p.n_ci_tiles, p.kh * p.kw, p.splits), dim3(kThreads), 0, stream, p);
+  return check_hip(hipGetLastError(), "conv_wgrad launch");
+}
+
+template <typename T, bool X3, bool ALIGNED>
+static int launch_tile(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
+  if (l.to == 128 && l.tc == 128) return launch_one<T, 128, 128, X3, ALIGNED>(p, s);
+  if (l.to == 128 && l.tc == 64) return launch_one<T, 128, 64, X3, ALIGNED>(p, s);
+  if (l.to == 64 && l.tc == 128) return launch_one<T, 64, 128, X3, ALIGNED>(p, s);
+  return launch_one<T, 64, 64, X3, ALIGNED>(p, s);
+}
+
+int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
+  if (p.K <= 0 || p.Cout <= 0 || p.Cin <= 0) return GC_OK;
+  if (l.bf16) return l.aligned ? launch_tile<uint16_t, false, true>(p, l, s) : launch_tile<uint16_t, false, false>(p, l, s);
+  if (l.x3) return l.aligned ? launch_tile<float, true, true>(p, l, s) : launch_tile<float, true, false>(p, l, s);
+  return l.aligned ? launch_tile<float, false, true>(p, l, s) : launch_tile<float, false, false>(p, l, s);
+}
+
+int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
+  const size_t total = (size_t)p.Cout * p.Cin * p.kh * p.kw;
+  if (total == 0) return GC_OK;
+  size_t blocks = (total + kThreads - 1) / kThreads;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+  return check_hip(hipGetLastError(), "wgrad_reduce launch");
+}
+
+int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream) {
+  if (check_hip(hipMemsetAsync(gb, 0, sizeof(float) * C, stream), "hipMemsetAsync")) return GC_HIP_ERROR;
+  if (K <= 0 || C <= 0) return GC_OK;
+  int kpb = (K + 1023) / 1024;
+  if (kpb < 64) kpb = 64;
+  const int blocks = (K + kpb - 1) / kpb;
+  if (bf16)
+    hipLaunchKernelGGL(colsum_kernel<uint16_t>, dim3(blocks), dim3(kThreads), 0, stream, (const uint16_t*)gy, gb, K, C, cstride, coff, kpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<uint32_t>, dim3(blocks), dim3(kThreads), 0, stream, (const uint32_t*)gy, gb, K, C, cstride, coff, kpb);
+  return check_hip(hipGetLastError(), "colsum launch");
+}
+
+}  // namespace gc

@@ -1,0 +1,404 @@
+// C ABI of libganconv.so (see include/ganconv.h): descriptor validation, tap tables, kernel selection, the
+// weight repack and depthwise blur kernels, and the optional per-launch event timing.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "conv_gather.h"
+#include "conv_wgrad.h"
+
+namespace gc {
+
+// ---- errors -------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return GC_HIP_ERROR;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------------
+struct ProfRec {
+  std::string name;
+  double flops;
+  hipEvent_t e0, e1;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+ProfScope::ProfScope(const char* name, double flops, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{name, flops, nullptr, nullptr};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  hipEventRecord(r.e0, s);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEventRecord(g_prof[slot].e1, stream);
+}
+
+// ---- weight repack -------------------------------------------------------------------------------------
+// dst[plane][row][tap][col] (bf16, col padded with zeros to colp) from fp32 w[co][ci][r][s] with strides.
+// transpose == 0: row = co, col = ci (forward image); transpose == 1: row = ci, col = co (data-gradient image).
+__global__ __launch_bounds__(kThreads) void pack_weight_kernel(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_s,
+                                                                uint16_t* dst, int rows, int cols, int colp, int kh, int kw,
+                                                                int transpose, int planes, float alpha) {
+  const size_t total = (size_t)rows * kh * kw * colp;
+  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
+    const int col = (int)(e % colp);
+    size_t q = e / colp;
+    const int tap = (int)(q % (kh * kw));
+    const int row = (int)(q / (kh * kw));
+    float v = 0.f;
+    if (col < cols) {
+      const int co = transpose ? col : row, ci = transpose ? row : col;
+      v = alpha * w[co * s_co + ci * s_ci + (tap / kw) * s_r + (tap % kw) * s_s];
+    }
+    const uint16_t hi = float_to_bf16_bits(v);
+    dst[e] = hi;
+    if (planes == 2) dst[total + e] = float_to_bf16_bits(v - bf16_bits_to_float(hi));
+  }
+}
+
+// ---- depthwise 3x3 binomial blur, NHWC ----------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* x, T* y, int N, int H, int W, int C4) {
+  // one thread per (pixel, group of 4 channels): 16-byte (fp32) or 8-byte (bf16) accesses
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
+    const int c4 = (int)(e % C4);
+    size_t pix = e / C4;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const size_t n = pix / ((size_t)W * H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dr = -1; dr <= 1; dr++) {
+      const int hh = h + dr;
+      if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+      for (int dc = -1; dc <= 1; dc++) {
+        const int ww = w + dc;
+        if ((unsigned)ww >= (unsigned)W) continue;
+        const float k = (float)((2 - (dr != 0)) * (2 - (dc != 0)));
+        const size_t off = (((n * H + hh) * W + ww) * C4 + c4) * 4;
+        f32x4 v;
+        if (sizeof(T) == 4) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + off);
+        else v = widen_bf16x4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(x) + off));
+        acc += k * v;
+      }
+    }
+    acc *= (1.f / 16.f);
+    const size_t off = e * 4;
+    if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + off) = acc;
+    else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(y) + off) = cvt_bf16x4(acc);
+  }
+}
+
+// ---- descriptor handling ------------------------------------------------------------------------------
+static int validate(const gc_conv_desc* d) {
+  if (d == nullptr) { set_error("null descriptor"); return GC_BAD_DESC; }
+  if (d->N < 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) {
+    set_error("non-positive extent in descriptor (N=%d H=%d W=%d Cin=%d Ho=%d Wo=%d Cout=%d)", d->N, d->H, d->W, d->Cin, d->Ho, d->Wo, d->Cout);
+    return GC_BAD_DESC;
+  }
+  if (d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0) {
+    set_error("bad filter geometry (k=%dx%d stride=%dx%d pad=%dx%d)", d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w);
+    return GC_BAD_DESC;
+  }
+  for (int i = 0; i < 4; i++)
+    if (d->reserved[i] != 0) { set_error("reserved descriptor fields must be zero"); return GC_BAD_DESC; }
+  if ((d->x_dtype != GC_F32 && d->x_dtype != GC_BF16) || (d->y_dtype != GC_F32 && d->y_dtype != GC_BF16)) {
+    set_error("unknown dtype"); return GC_BAD_DESC;
+  }
+  if (d->precision != GC_PREC_BF16 && d->precision != GC_PREC_F32X3) { set_error("unknown precision"); return GC_BAD_DESC; }
+  // the conv's own output size may not exceed (Ho, Wo); H may exceed the minimal size (transposed conv output_padding)
+  const int ho_full = (d->H + 2 * d->pad_h - d->kh) / d->stride_h + 1, wo_full = (d->W + 2 * d->pad_w - d->kw) / d->stride_w + 1;
+  if (d->H + 2 * d->pad_h < d->kh || d->W + 2 * d->pad_w < d->kw || ho_full != d->Ho || wo_full != d->Wo) {
+    set_error("Ho/Wo (%d,%d) do not match the convolution of H/W (%d,%d): expected (%d,%d)", d->Ho, d->Wo, d->H, d->W, ho_full, wo_full);
+    return GC_BAD_DESC;
+  }
+  if (d->x_dtype != d->y_dtype) { set_error("mixed activation dtypes are not supported"); return GC_UNSUPPORTED_GEOMETRY; }
+  if (d->precision == GC_PREC_F32X3 && d->x_dtype != GC_F32) { set_error("GC_PREC_F32X3 needs fp32 activations"); return GC_UNSUPPORTED_GEOMETRY; }
+  if (d->kh * d->kw > kMaxTaps) { set_error("filters larger than %d taps are not supported", kMaxTaps); return GC_UNSUPPORTED_GEOMETRY; }
+  if (d->stride_h * d->stride_w > kMaxClasses) { set_error("stride %dx%d is not supported", d->stride_h, d->stride_w); return GC_UNSUPPORTED_GEOMETRY; }
+  if (d->kh > 127 || d->kw > 127 || d->pad_h > 127 || d->pad_w > 127) { set_error("filter or padding too large"); return GC_UNSUPPORTED_GEOMETRY; }
+  if ((long)d->N * d->H * d->W >= (1l << 31) || (long)d->N * d->Ho * d->Wo >= (1l << 31)) { set_error("more than 2^31 pixels"); return GC_UNSUPPORTED_GEOMETRY; }
+  if (d->x_cstride != 0 && d->x_cstride < d->x_coff + d->Cin) { set_error("x channel slice exceeds x_cstride"); return GC_BAD_DESC; }
+  if (d->y_cstride != 0 && d->y_cstride < d->y_coff + d->Cout) { set_error("y channel slice exceeds y_cstride"); return GC_BAD_DESC; }
+  if (d->x_coff < 0 || d->y_coff < 0) { set_error("negative channel offset"); return GC_BAD_DESC; }
+  return GC_OK;
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int x_cs(const gc_conv_desc* d) { return d->x_cstride ? d->x_cstride : d->Cin; }
+static inline int y_cs(const gc_conv_desc* d) { return d->y_cstride ? d->y_cstride : d->Cout; }
+static inline int elems_per_chunk(int dtype) { return dtype == GC_BF16 ? 8 : 4; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static double conv_flops(const gc_conv_desc* d) {
+  return 2.0 * d->N * d->Ho * d->Wo * (double)d->Cout * d->Cin * d->kh * d->kw;
+}
+
+static void fill_epilogue(GatherParams& p, const gc_epilogue* ep) {
+  p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
+  if (ep != nullptr) {
+    p.bias = ep->bias; p.ch_sum = ep->ch_sum; p.ch_sumsq = ep->ch_sumsq; p.act = ep->act; p.slope = ep->slope;
+  }
+}
+
+static int check_epilogue(const gc_epilogue* ep) {
+  if (ep == nullptr) return GC_OK;
+  if (ep->act < GC_ACT_NONE || ep->act > GC_ACT_SIGMOID) { set_error("unknown activation %d", ep->act); return GC_BAD_ARGUMENT; }
+  for (int i = 0; i < 4; i++)
+    if (ep->reserved[i] != 0) { set_error("reserved epilogue fields must be zero"); return GC_BAD_ARGUMENT; }
+  if (ep->ch_sumsq != nullptr && ep->ch_sum == nullptr) { set_error("ch_sumsq needs ch_sum"); return GC_BAD_ARGUMENT; }
+  return GC_OK;
+}
+
+}  // namespace gc
+
+using namespace gc;
+
+extern "C" {
+
+int gc_version(void) { return GANCONV_VERSION; }
+
+const char* gc_last_error(void) { return g_err; }
+
+size_t gc_packed_weight_bytes(const gc_conv_desc* d, int pass) {
+  if (validate(d) != GC_OK) return 0;
+  const int planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
+  const size_t taps = (size_t)d->kh * d->kw;
+  if (pass == GC_PASS_FPROP) return (size_t)planes * d->Cout * taps * round_up(d->Cin, kBK) * 2;
+  if (pass == GC_PASS_DGRAD) return (size_t)planes * d->Cin * taps * round_up(d->Cout, kBK) * 2;
+  set_error("gc_packed_weight_bytes: pass must be GC_PASS_FPROP or GC_PASS_DGRAD");
+  return 0;
+}
+
+int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_t w_strides[4], float alpha, void* packed,
+                   void* stream) {
+  int rc = validate(d);
+  if (rc != GC_OK) return rc;
+  if (w == nullptr || packed == nullptr || w_strides == nullptr) { set_error("gc_pack_weight: null pointer"); return GC_BAD_ARGUMENT; }
+  if (pass != GC_PASS_FPROP && pass != GC_PASS_DGRAD) { set_error("gc_pack_weight: bad pass"); return GC_BAD_ARGUMENT; }
+  if (!aligned16(packed)) { set_error("gc_pack_weight: packed buffer must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
+  const int transpose = pass == GC_PASS_DGRAD;
+  const int rows = transpose ? d->Cin : d->Cout, cols = transpose ? d->Cout : d->Cin;
+  const int colp = round_up(cols, kBK);
+  const int planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
+  const size_t total = (size_t)rows * d->kh * d->kw * colp;
+  size_t blocks = (total + kThreads - 1) / kThreads;
+  if (blocks > 4096) blocks = 4096;
+  ProfScope ps("pack_weight", 0.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, w, w_strides[0], w_strides[1],
+                     w_strides[2], w_strides[3], (uint16_t*)packed, rows, cols, colp, d->kh, d->kw, transpose, planes, alpha);
+  return check_hip(hipGetLastError(), "pack_weight launch");
+}
+
+int gc_conv2d_fprop(const gc_conv_desc* d, const void* x, const void* packed_w, void* y, const gc_epilogue* ep, void* stream) {
+  int rc = validate(d);
+  if (rc != GC_OK) return rc;
+  if ((rc = check_epilogue(ep)) != GC_OK) return rc;
+  if (d->N == 0) return GC_OK;
+  if (x == nullptr || packed_w == nullptr || y == nullptr) { set_error("gc_conv2d_fprop: null pointer"); return GC_BAD_ARGUMENT; }
+  if (!aligned16(packed_w)) { set_error("gc_conv2d_fprop: packed weights must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
+  GatherParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = x; p.wp = (const uint16_t*)packed_w; p.out = y;
+  fill_epilogue(p, ep);
+  p.N = d->N; p.IH = d->H; p.IW = d->W; p.IC = d->Cin; p.ICp = round_up(d->Cin, kBK);
+  p.OH = d->Ho; p.OW = d->Wo; p.OC = d->Cout; p.T = d->kh * d->kw;
+  p.a = d->stride_h; p.b = 1;
+  if (d->stride_h != d->stride_w) { set_error("anisotropic stride is not supported"); return GC_UNSUPPORTED_GEOMETRY; }
+  p.in_cstride = x_cs(d); p.in_coff = d->x_coff; p.out_cstride = y_cs(d); p.out_coff = d->y_coff;
+  p.plane_stride = (int64_t)d->Cout * p.T * p.ICp;
+  p.tt.n_classes = 1;
+  p.tt.cls_tap_start[0] = 0;
+  for (int c = 1; c <= kMaxClasses; c++) p.tt.cls_tap_start[c] = p.T;
+  p.tt.cls_ph[0] = p.tt.cls_pw[0] = 0; p.tt.cls_oh[0] = d->Ho; p.tt.cls_ow[0] = d->Wo;
+  for (int r = 0; r < d->kh; r++)
+    for (int s = 0; s < d->kw; s++) {
+      const int i = r * d->kw + s;
+      p.tt.dh[i] = (int8_t)(r - d->pad_h); p.tt.dw[i] = (int8_t)(s - d->pad_w); p.tt.wtap[i] = (uint8_t)i;
+    }
+  GatherLaunch l;
+  l.in_bf16 = d->x_dtype == GC_BF16; l.x3 = d->precision == GC_PREC_F32X3;
+  const int epc = elems_per_chunk(d->x_dtype);
+  l.aligned = aligned16(x) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
+  p.out_vec = (reinterpret_cast<uintptr_t>(y) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
+  plan_gather(p, l);
+  ProfScope ps("conv_fprop", conv_flops(d), (hipStream_t)stream);
+  return launch_gather(p, l, (hipStream_t)stream);
+}
+
+int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w, void* gx, const gc_epilogue* ep, void* stream) {
+  int rc = validate(d);
+  if (rc != GC_OK) return rc;
+  if ((rc = check_epilogue(ep)) != GC_OK) return rc;
+  if (d->N == 0) return GC_OK;
+  if (gy == nullptr || packed_w == nullptr || gx == nullptr) { set_error("gc_conv2d_dgrad: null pointer"); return GC_BAD_ARGUMENT; }
+  if (!aligned16(packed_w)) { set_error("gc_conv2d_dgrad: packed weights must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
+  if (d->stride_h != d->stride_w) { set_error("anisotropic stride is not supported"); return GC_UNSUPPORTED_GEOMETRY; }
+  const int b = d->stride_h;
+  GatherParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = gy; p.wp = (const uint16_t*)packed_w; p.out = gx;
+  fill_epilogue(p, ep);
+  p.N = d->N; p.IH = d->Ho; p.IW = d->Wo; p.IC = d->Cout; p.ICp = round_up(d->Cout, kBK);
+  p.OH = d->H; p.OW = d->W; p.OC = d->Cin; p.T = d->kh * d->kw;
+  p.a = 1; p.b = b;
+  p.in_cstride = y_cs(d); p.in_coff = d->y_coff; p.out_cstride = x_cs(d); p.out_coff = d->x_coff;
+  p.plane_stride = (int64_t)d->Cin * p.T * p.ICp;
+  // x pixel (h, w) receives gy[(h + pad - r)/b, (w + pad - s)/b] * w[r][s] for every tap with an exact quotient:
+  // class (ph, pw) = (h mod b, w mod b) sees the taps r = (ph + pad) mod b, +b, ... at the fixed offset
+  // dh = (ph + pad - r)/b from the class-local row h' = h / b.
+  p.tt.n_classes = b * b;
+  int e = 0;
+  for (int ph = 0; ph < b; ph++)
+    for (int pw = 0; pw < b; pw++) {
+      const int c = ph * b + pw;
+      p.tt.cls_tap_start[c] = e;
+      p.tt.cls_ph[c] = ph; p.tt.cls_pw[c] = pw;
+      p.tt.cls_oh[c] = (d->H - ph + b - 1) / b; p.tt.cls_ow[c] = (d->W - pw + b - 1) / b;
+      for (int r = (ph + d->pad_h) % b; r < d->kh; r += b)
+        for (int s = (pw + d->pad_w) % b; s < d->kw; s += b) {
+          const int dh = (ph + d->pad_h - r) / b, dw = (pw + d->pad_w - s) / b;  // exact; may be negative
+          p.tt.dh[e] = (int8_t)dh; p.tt.dw[e] = (int8_t)dw; p.tt.wtap[e] = (uint8_t)(r * d->kw + s);
+          e++;
+        }
+    }
+  for (int c = p.tt.n_classes; c <= kMaxClasses; c++) p.tt.cls_tap_start[c] = e;
+  GatherLaunch l;
+  l.in_bf16 = d->y_dtype == GC_BF16; l.x3 = d->precision == GC_PREC_F32X3;
+  const int epc = elems_per_chunk(d->y_dtype);
+  l.aligned = aligned16(gy) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
+  p.out_vec = (reinterpret_cast<uintptr_t>(gx) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
+  plan_gather(p, l);
+  ProfScope ps("conv_dgrad", conv_flops(d), (hipStream_t)stream);
+  return launch_gather(p, l, (hipStream_t)stream);
+}
+
+static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l) {
+  memset(&p, 0, sizeof(p));
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.kh = d->kh; p.kw = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+  p.x_cstride = x_cs(d); p.x_coff = d->x_coff; p.y_cstride = y_cs(d); p.y_coff = d->y_coff;
+  p.K = d->N * d->Ho * d->Wo;
+  p.div_wo = make_fastdiv((uint32_t)d->Wo); p.div_ho = make_fastdiv((uint32_t)d->Ho);
+  l.bf16 = d->x_dtype == GC_BF16; l.x3 = d->precision == GC_PREC_F32X3;
+  plan_wgrad(p, l);
+}
+
+size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
+  if (validate(d) != GC_OK) return 0;
+  WgradParams p; WgradLaunch l;
+  wgrad_setup(d, p, l);
+  return (size_t)p.splits * d->kh * d->kw * d->Cout * d->Cin * sizeof(float);
+}
+
+int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float* gw, const int64_t gw_strides[4], float alpha,
+                    int accumulate, float* gbias, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(d);
+  if (rc != GC_OK) return rc;
+  if (x == nullptr || gy == nullptr || gw == nullptr || gw_strides == nullptr) { set_error("gc_conv2d_wgrad: null pointer"); return GC_BAD_ARGUMENT; }
+  WgradParams p; WgradLaunch l;
+  wgrad_setup(d, p, l);
+  const size_t need = (size_t)p.splits * d->kh * d->kw * d->Cout * d->Cin * sizeof(float);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("gc_conv2d_wgrad: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    return GC_WORKSPACE_TOO_SMALL;
+  }
+  if (!aligned16(workspace)) { set_error("gc_conv2d_wgrad: workspace must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
+  p.x = x; p.gy = gy; p.part = (float*)workspace;
+  const int epc = elems_per_chunk(d->x_dtype);
+  l.aligned = aligned16(x) && aligned16(gy) && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0) &&
+              (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
+  {
+    ProfScope ps("conv_wgrad", conv_flops(d), (hipStream_t)stream);
+    if ((rc = launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
+  }
+  WgradReduceParams r;
+  r.part = p.part; r.gw = gw;
+  r.s_co = gw_strides[0]; r.s_ci = gw_strides[1]; r.s_r = gw_strides[2]; r.s_s = gw_strides[3];
+  r.Cout = d->Cout; r.Cin = d->Cin; r.kh = d->kh; r.kw = d->kw; r.splits = d->N == 0 ? 0 : p.splits;
+  r.alpha = alpha; r.accumulate = accumulate;
+  {
+    ProfScope ps("wgrad_reduce", 0.0, (hipStream_t)stream);
+    if ((rc = launch_wgrad_reduce(r, (hipStream_t)stream)) != GC_OK) return rc;
+  }
+  if (gbias != nullptr) {
+    ProfScope ps("bias_grad", 0.0, (hipStream_t)stream);
+    if ((rc = launch_colsum(gy, gbias, p.K, d->Cout, p.y_cstride, p.y_coff, l.bf16, (hipStream_t)stream)) != GC_OK) return rc;
+  }
+  return GC_OK;
+}
+
+int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || C <= 0) { set_error("gc_dwblur3x3: bad shape"); return GC_BAD_ARGUMENT; }
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("gc_dwblur3x3: unknown dtype"); return GC_BAD_ARGUMENT; }
+  if (N == 0) return GC_OK;
+  if (x == nullptr || y == nullptr) { set_error("gc_dwblur3x3: null pointer"); return GC_BAD_ARGUMENT; }
+  if (C % 4 != 0 || !aligned16(x) || !aligned16(y)) {
+    set_error("gc_dwblur3x3: channels must be a multiple of 4 and buffers 16-byte aligned (C=%d)", C);
+    return GC_UNSUPPORTED_GEOMETRY;
+  }
+  const size_t total = (size_t)N * H * W * (C / 4);
+  size_t blocks = (total + kThreads - 1) / kThreads;
+  if (blocks > 8192) blocks = 8192;
+  ProfScope ps("dwblur3x3", 0.0, (hipStream_t)stream);
+  if (dtype == GC_F32)
+    hipLaunchKernelGGL(dwblur3x3_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C / 4);
+  else
+    hipLaunchKernelGGL(dwblur3x3_kernel<uint16_t>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, N, H, W, C / 4);
+  return check_hip(hipGetLastError(), "dwblur3x3 launch");
+}
+
+int gc_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return GC_OK;
+}
+
+int gc_profile_collect(int max_entries, char names[][64], int64_t* launches, double* total_ms, double* flops) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      int i = 0;
+      for (; i < n; i++)
+        if (strncmp(names[i], r.name.c_str(), 63) == 0) break;
+      if (i == n && n < max_entries) {
+        strncpy(names[n], r.name.c_str(), 63);
+        names[n][63] = 0;
+        launches[n] = 0; total_ms[n] = 0.0; flops[n] = 0.0;
+        n++;
+      }
+      if (i < n) { launches[i]++; total_ms[i] += ms; flops[i] += r.flops; }
+    }
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+"""Drop-in replacements for the two torch.nn.functional calls on the reference's hot path.
+
+    conv2d(x, w, bias, stride, padding, dilation, groups)            BigGAN/model.py:56-58
+    conv_transpose2d(x, w, bias, stride, padding, output_padding)    StyleGAN/model.py:404
+
+Same argument meaning as torch.nn.functional (ints or pairs).  Geometry the MI355X kernels do not implement
+(dilation > 1, groups > 1, anisotropic stride/padding, string padding) raises RuntimeError -- there is no
+fallback to another backend.
+"""
+import torch
+
+from . import ops
+
+
+def _single(v, name):
+    if isinstance(v, (tuple, list)):
+        if len(v) == 1:
+            return int(v[0])
+        if len(v) != 2 or v[0] != v[1]:
+            raise RuntimeError(f"ganconv: {name}={tuple(v)} is not supported (must be the same in both dimensions)")
+        return int(v[0])
+    if isinstance(v, str):
+        raise RuntimeError(f"ganconv: {name}='{v}' is not supported")
+    return int(v)
+
+
+def _check_input(x, w):
+    if x.dim() != 4 or w.dim() != 4:
+        raise RuntimeError(f"ganconv: expected 4-D input and weight, got {tuple(x.shape)} and {tuple(w.shape)}")
+    if w.shape[2] != w.shape[3] and False:
+        raise RuntimeError("unreachable")
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, *, _wkey=0, precision=None):
+    _check_input(input, weight)
+    if _single(dilation, "dilation") != 1:
+        raise RuntimeError("ganconv: dilation > 1 is not supported")
+    if groups != 1:
+        raise RuntimeError("ganconv: groups > 1 is not supported by conv2d (the StyleGAN depthwise blur is ops.blur3x3)")
+    prec = ops.get_precision() if precision is None else precision
+    return ops.conv_fprop(input, weight, bias, _single(stride, "stride"), _single(padding, "padding"), prec, _wkey)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, *, _wkey=0,
+                     precision=None):
+    """weight is [Cin, Cout, kh, kw] as in torch.  Runs as the data-gradient of the mirrored convolution."""
+    _check_input(input, weight)
+    if _single(dilation, "dilation") != 1 or groups != 1:
+        raise RuntimeError("ganconv: dilation > 1 / groups > 1 are not supported")
+    s, p, op = _single(stride, "stride"), _single(padding, "padding"), _single(output_padding, "output_padding")
+    if op >= max(s, 1) and op != 0:
+        raise RuntimeError("ganconv: output_padding must be smaller than stride")
+    if weight.shape[0] != input.shape[1]:
+        raise RuntimeError(f"ganconv: weight expects {weight.shape[0]} input channels, input has {input.shape[1]}")
+    kh, kw = weight.shape[2], weight.shape[3]
+    H = (input.shape[2] - 1) * s - 2 * p + kh + op
+    W = (input.shape[3] - 1) * s - 2 * p + kw + op
+    prec = ops.get_precision() if precision is None else precision
+    return ops.conv_dgrad(input, weight, bias, H, W, s, p, prec, _wkey)
+
+
+def blur3x3(input):
+    return ops.blur3x3(input)

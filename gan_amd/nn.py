@@ -1,0 +1,58 @@
+"""Drop-in torch.nn.Conv2d / torch.nn.ConvTranspose2d whose forward, data-gradient and weight-gradient passes
+run on the hand-written gfx950 kernels.
+
+They SUBCLASS the torch modules: constructor arguments, parameter names/shapes (state_dict compatible with the
+reference's checkpoints), `.weight/.bias/.stride/.padding/...` attributes and isinstance checks
+(BasicGANs/utils.py:32, BigGAN/train.py:110) all behave as in torch.  `self.weight` is read at call time, so
+hooks that replace it with a non-leaf tensor (EqualizedLR, StyleGAN/model.py:40-50) and subclasses that call
+the functional form with a transformed weight (BigGAN/model.py:48-58) keep working.
+
+Reference call sites: BasicGANs/models.py:35,77; Pix2Pix/models.py:17,83,123-124,225-232; StyleGAN/model.py:72.
+"""
+import weakref
+
+import torch
+
+from . import functional as F
+from . import ops
+
+
+class _KeyedWeight:
+    """Gives a module a packed-weight cache key that is valid while `self.weight` is its own Parameter."""
+
+    def _wkey_for(self, weight):
+        if not isinstance(weight, torch.nn.Parameter):
+            return 0
+        key = self.__dict__.get("_ganconv_wkey")
+        if key is None:
+            key = ops.new_weight_key()
+            self.__dict__["_ganconv_wkey"] = key
+            weakref.finalize(self, ops.drop_weight_key, key)
+        return key
+
+
+class Conv2d(_KeyedWeight, torch.nn.Conv2d):
+    def _conv_forward(self, input, weight, bias):
+        if self.padding_mode != "zeros":
+            raise RuntimeError("ganconv: only zero padding is supported")
+        key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
+        return F.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key)
+
+
+class ConvTranspose2d(_KeyedWeight, torch.nn.ConvTranspose2d):
+    def forward(self, input, output_size=None):
+        if self.padding_mode != "zeros":
+            raise RuntimeError("ganconv: only zero padding is supported")
+        if output_size is not None:
+            raise RuntimeError("ganconv: output_size is not supported; use output_padding")
+        weight = self.weight
+        key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
+        return F.conv_transpose2d(input, weight, self.bias, self.stride, self.padding, self.output_padding, self.groups,
+                                  self.dilation, _wkey=key)
+
+
+class BlurLayer(torch.nn.Module):
+    """Depthwise 3x3 binomial blur (reference StyleGAN/model.py:140-150)."""
+
+    def forward(self, input):
+        return F.blur3x3(input)

@@ -1,0 +1,289 @@
+"""torch.library custom ops over libganconv.so: conv forward / data-gradient / weight-gradient.
+
+Three ops, closed under differentiation (every backward formula is written with the same three ops), so the
+WGAN-GP gradient penalty -- torch.autograd.grad(..., create_graph=True) followed by .backward(), reference
+BasicGANs/loss_functions.py:21-28 -- runs through the same kernels:
+
+    y  = conv_fprop(x, w)        dy/dx -> conv_dgrad(gy, w)     dy/dw -> conv_wgrad(x, gy)
+    gx = conv_dgrad(gy, w)       d/dgy -> conv_fprop(u, w)      d/dw  -> conv_wgrad(u, gy)
+    gw = conv_wgrad(x, gy)       d/dx  -> conv_dgrad(gy, v)     d/dgy -> conv_fprop(x, v)
+
+All tensors are logically NCHW (what the reference's modules exchange) and physically channels-last; weights
+are logically [Cout, Cin, kh, kw] with any strides.  These ops replace aten::convolution /
+aten::convolution_backward / _convolution_double_backward at the reference call sites listed in
+include/ganconv.h.  There is no fallback: on a CPU tensor, a missing library or an unsupported geometry they
+raise RuntimeError.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ConvDesc, Epilogue
+
+_PRECISION = {"bf16": _lib.GC_PREC_BF16, "fp32x3": _lib.GC_PREC_F32X3}
+_default_precision = _lib.GC_PREC_BF16
+
+
+def set_precision(name):
+    """'bf16': operands rounded to bf16, fp32 accumulate (fast).  'fp32x3': three-term bf16 split of fp32
+    operands (about 1e-5 relative error, three times the matrix work)."""
+    global _default_precision
+    _default_precision = _PRECISION[name]
+
+
+def get_precision():
+    return _default_precision
+
+
+# ---- packed-weight cache -------------------------------------------------------------------------------------
+# A module that owns a Parameter registers a key; the cache entry remembers which storage/version it was packed
+# from and is refreshed when the parameter has been modified in place (optimizer step, weights_init, load).
+_wcache = {}
+_next_key = [1]
+
+
+def new_weight_key():
+    k = _next_key[0]
+    _next_key[0] += 1
+    return k
+
+
+def drop_weight_key(key):
+    for p in (_lib.GC_PASS_FPROP, _lib.GC_PASS_DGRAD):
+        for prec in (0, 1):
+            _wcache.pop((key, p, prec), None)
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return _lib.GC_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.GC_BF16
+    raise RuntimeError(f"ganconv: unsupported activation dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ganconv: tensors must live on the GPU (this library has no CPU path)")
+
+
+def _nhwc(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, dtype_code, precision):
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
+    d.kh, d.kw, d.stride_h, d.stride_w, d.pad_h, d.pad_w = kh, kw, stride, stride, padding, padding
+    d.x_dtype = d.y_dtype = dtype_code
+    d.precision = precision if dtype_code == _lib.GC_F32 else _lib.GC_PREC_BF16
+    return d
+
+
+def _packed(desc, w, pass_, wkey):
+    """bf16 image of w for `pass_`; cached per registered key and refreshed when the weight's version moved."""
+    L = _lib.lib()
+    ck = (wkey, pass_, int(desc.precision))
+    if wkey:
+        ent = _wcache.get(ck)
+        if ent is not None and ent[0] == w.data_ptr() and ent[1] == w._version and ent[2] == tuple(w.shape):
+            return ent[3]
+    if w.dtype != torch.float32:
+        w = w.float()
+    nbytes = L.gc_packed_weight_bytes(ctypes.byref(desc), pass_)
+    if nbytes == 0:
+        _lib.check(-1, "gc_packed_weight_bytes")
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), 1.0,
+                                ctypes.c_void_p(buf.data_ptr()), _stream()), "gc_pack_weight")
+    if wkey:
+        _wcache[ck] = (w.data_ptr(), w._version, tuple(w.shape), buf)
+    return buf
+
+
+def _epilogue(bias):
+    if bias is None:
+        return None, None
+    b = bias if bias.dtype == torch.float32 and bias.is_contiguous() else bias.float().contiguous()
+    ep = Epilogue()
+    ep.act = _lib.GC_ACT_NONE
+    ep.bias = b.data_ptr()
+    return ep, b
+
+
+# ---- op implementations (run below autograd) -------------------------------------------------------------------
+@torch.library.custom_op("ganconv::conv_fprop", mutates_args=())
+def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, padding: int, precision: int, wkey: int) -> Tensor:
+    _check_cuda(x, w, bias)
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = w.shape
+    if Cin_w != Cin:
+        raise RuntimeError(f"ganconv: weight expects {Cin_w} input channels, input has {Cin}")
+    if H + 2 * padding < kh or W + 2 * padding < kw:
+        raise RuntimeError(f"ganconv: kernel ({kh}x{kw}) larger than padded input ({H + 2 * padding}x{W + 2 * padding})")
+    Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
+    x = _nhwc(x)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
+    wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey)
+    ep, keep = _epilogue(bias)
+    _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
+                                          ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
+               "gc_conv2d_fprop")
+    return y
+
+
+@conv_fprop.register_fake
+def _(x, w, bias, stride, padding, precision, wkey):
+    N, _, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    return x.new_empty((N, Cout, (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1))
+
+
+@torch.library.custom_op("ganconv::conv_dgrad", mutates_args=())
+def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, stride: int, padding: int, precision: int,
+               wkey: int) -> Tensor:
+    """gx [N, Cin, H, W] of the conv x -> y described by (w [Cout,Cin,kh,kw], stride, padding), given gy.
+    `bias` ([Cin]) is added to gx: the bias of a transposed convolution whose forward pass this is."""
+    _check_cuda(gy, w, bias)
+    N, Cout, Ho, Wo = gy.shape
+    Cout_w, Cin, kh, kw = w.shape
+    if Cout_w != Cout:
+        raise RuntimeError(f"ganconv: weight has {Cout_w} output channels, gradient has {Cout}")
+    if (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
+        raise RuntimeError(f"ganconv: input size ({H}x{W}) is inconsistent with the gradient's ({Ho}x{Wo})")
+    gy = _nhwc(gy)
+    gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gy), precision)
+    wp = _packed(d, w, _lib.GC_PASS_DGRAD, wkey)
+    ep, keep = _epilogue(bias)
+    _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
+                                          ctypes.c_void_p(gx.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
+               "gc_conv2d_dgrad")
+    return gx
+
+
+@conv_dgrad.register_fake
+def _(gy, w, bias, H, W, stride, padding, precision, wkey):
+    return gy.new_empty((gy.shape[0], w.shape[1], H, W))
+
+
+@torch.library.custom_op("ganconv::conv_wgrad", mutates_args=())
+def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: int, precision: int) -> Tensor:
+    """gw [Cout, Cin, kh, kw] (fp32) of the conv x -> y, given x and gy."""
+    _check_cuda(x, gy)
+    N, Cin, H, W = x.shape
+    N2, Cout, Ho, Wo = gy.shape
+    if N2 != N or (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
+        raise RuntimeError("ganconv: x and gy shapes are inconsistent with the convolution geometry")
+    if x.dtype != gy.dtype:
+        gy = gy.to(x.dtype)
+    x, gy = _nhwc(x), _nhwc(gy)
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
+    L = _lib.lib()
+    gw = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
+    ws_bytes = L.gc_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(L.gc_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(gy.data_ptr()),
+                                 ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), 1.0, 0, None,
+                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gc_conv2d_wgrad")
+    return gw
+
+
+@conv_wgrad.register_fake
+def _(x, gy, kh, kw, stride, padding, precision):
+    return x.new_empty((gy.shape[1], x.shape[1], kh, kw), dtype=torch.float32)
+
+
+# ---- autograd: each formula uses only the three ops above -------------------------------------------------------
+def _fprop_setup(ctx, inputs, output):
+    x, w, bias, stride, padding, precision, wkey = inputs
+    ctx.save_for_backward(x, w)
+    ctx.cfg = (stride, padding, precision, wkey, bias is not None)
+
+
+def _fprop_backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    stride, padding, precision, wkey, has_bias = ctx.cfg
+    gx = gw = gb = None
+    if ctx.needs_input_grad[0]:
+        gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey)
+    if ctx.needs_input_grad[1]:
+        gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
+    if has_bias and ctx.needs_input_grad[2]:
+        gb = gy.sum((0, 2, 3))
+    return gx, gw, gb, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::conv_fprop", _fprop_backward, setup_context=_fprop_setup)
+
+
+def _dgrad_setup(ctx, inputs, output):
+    gy, w, bias, H, W, stride, padding, precision, wkey = inputs
+    ctx.save_for_backward(gy, w)
+    ctx.cfg = (stride, padding, precision, wkey, bias is not None)
+
+
+def _dgrad_backward(ctx, u):
+    gy, w = ctx.saved_tensors
+    stride, padding, precision, wkey, has_bias = ctx.cfg
+    g_gy = g_w = g_b = None
+    if ctx.needs_input_grad[0]:
+        g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey)
+    if ctx.needs_input_grad[1]:
+        g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
+    if has_bias and ctx.needs_input_grad[2]:
+        g_b = u.sum((0, 2, 3))
+    return g_gy, g_w, g_b, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::conv_dgrad", _dgrad_backward, setup_context=_dgrad_setup)
+
+
+def _wgrad_setup(ctx, inputs, output):
+    x, gy, kh, kw, stride, padding, precision = inputs
+    ctx.save_for_backward(x, gy)
+    ctx.cfg = (stride, padding, precision)
+
+
+def _wgrad_backward(ctx, v):
+    x, gy = ctx.saved_tensors
+    stride, padding, precision = ctx.cfg
+    g_x = g_gy = None
+    if ctx.needs_input_grad[0]:
+        g_x = conv_dgrad(gy, v, None, x.shape[2], x.shape[3], stride, padding, precision, 0)
+    if ctx.needs_input_grad[1]:
+        g_gy = conv_fprop(x, v, None, stride, padding, precision, 0)
+    return g_x, g_gy, None, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::conv_wgrad", _wgrad_backward, setup_context=_wgrad_setup)
+
+
+@torch.library.custom_op("ganconv::blur3x3", mutates_args=())
+def blur3x3(x: Tensor) -> Tensor:
+    """Depthwise [1 2 1]x[1 2 1]/16 blur with zero padding 1 (reference StyleGAN/model.py:82-150)."""
+    _check_cuda(x)
+    N, C, H, W = x.shape
+    x = _nhwc(x)
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_dwblur3x3(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), N, H, W, C, _dtype_code(x), _stream()),
+               "gc_dwblur3x3")
+    return y
+
+
+@blur3x3.register_fake
+def _(x):
+    return torch.empty_like(x)
+
+
+# the kernel is symmetric, so the blur is self-adjoint: its backward (and double backward) is the blur itself
+torch.library.register_autograd("ganconv::blur3x3", lambda ctx, g: blur3x3(g), setup_context=lambda ctx, inputs, output: None)

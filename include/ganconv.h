@@ -1,0 +1,144 @@
+/*
+ * ganconv.h -- C ABI of libganconv.so: convolution forward / data-gradient / weight-gradient passes as
+ * hand-written gfx950 (MI355X) kernels.
+ *
+ * The reference repository has no operator or plugin API of its own; the path this library replaces is
+ * reached through PyTorch's module / functional calls.  Each entry point names the reference call sites it
+ * serves (paths relative to the reference checkout) and the ATen operator that executes there today.
+ *
+ * Conventions
+ *   - Plain C: POD structs, raw device pointers, byte sizes.  No C++ types, no exceptions cross the boundary.
+ *   - Every function returns GC_OK (0) or a negative gc_status; gc_last_error() gives a thread-local message.
+ *   - Functions only ENQUEUE work on the given stream (a hipStream_t passed as void*; NULL = the null stream)
+ *     and return; they never synchronise, never allocate device memory and keep no reference to any buffer.
+ *     The caller owns all buffers including the workspace.
+ *   - Activations are NHWC ("channels last"): element (n,h,w,c) of a tensor with C channels lives at
+ *     ((n*H + h)*W + w) * cstride + coff + c, where cstride/coff default to C/0 and let a caller read from or
+ *     write into a channel slice of a wider buffer (U-Net skip concatenation without a copy).
+ *   - A gc_conv_desc always describes the CONVOLUTION  x[N,H,W,Cin] -> y[N,Ho,Wo,Cout]; a transposed
+ *     convolution is the data-gradient of that convolution, so its forward pass is gc_conv2d_dgrad with
+ *     the transposed conv's input in the role of gy and its output in the role of gx.
+ *   - Weights are always indexed logically as w[co][ci][r][s] (co over Cout, ci over Cin of the desc), with
+ *     arbitrary element strides: torch.nn.Conv2d.weight [Cout,Cin,kh,kw] is that order directly, and
+ *     torch.nn.ConvTranspose2d.weight [Cin_t,Cout_t,kh,kw] is that order too because the transposed conv's
+ *     input channels are the mirrored conv's output channels.
+ *   - Unsupported geometry is an error (GC_UNSUPPORTED_GEOMETRY); there is no fallback to another backend.
+ */
+#ifndef GANCONV_H
+#define GANCONV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANCONV_VERSION 1
+
+typedef enum gc_status {
+  GC_OK = 0,
+  GC_BAD_DESC = -1,
+  GC_UNSUPPORTED_GEOMETRY = -2,
+  GC_WORKSPACE_TOO_SMALL = -3,
+  GC_HIP_ERROR = -4,
+  GC_BAD_ARGUMENT = -5
+} gc_status;
+
+typedef enum gc_dtype { GC_F32 = 0, GC_BF16 = 1 } gc_dtype;
+
+/* Arithmetic of the contraction.  Both accumulate in fp32 on the bf16 matrix cores.
+ *   GC_PREC_BF16  : operands rounded to bf16 (one MFMA per product)
+ *   GC_PREC_F32X3 : each fp32 operand split into bf16 hi + lo parts, products hi*hi + hi*lo + lo*hi
+ *                   (three MFMAs per product; relative error of a product about 2^-16) */
+typedef enum gc_precision { GC_PREC_BF16 = 0, GC_PREC_F32X3 = 1 } gc_precision;
+
+typedef enum gc_act { GC_ACT_NONE = 0, GC_ACT_RELU = 1, GC_ACT_LRELU = 2, GC_ACT_TANH = 3, GC_ACT_SIGMOID = 4 } gc_act;
+
+typedef enum gc_pass { GC_PASS_FPROP = 0, GC_PASS_DGRAD = 1, GC_PASS_WGRAD = 2 } gc_pass;
+
+typedef struct gc_conv_desc {
+  int32_t N, H, W, Cin;   /* x  : [N, H,  W,  Cin ] */
+  int32_t Ho, Wo, Cout;   /* y  : [N, Ho, Wo, Cout]; must satisfy Ho = (H + 2*pad_h - kh)/stride_h + 1 (floor), or,
+                             for a transposed conv with output_padding, H may exceed (Ho-1)*stride_h - 2*pad_h + kh */
+  int32_t kh, kw;
+  int32_t stride_h, stride_w;
+  int32_t pad_h, pad_w;
+  int32_t x_dtype;        /* gc_dtype of the x-side tensors (x in fprop/wgrad, gx in dgrad) */
+  int32_t y_dtype;        /* gc_dtype of the y-side tensors (y in fprop, gy in dgrad/wgrad) */
+  int32_t precision;      /* gc_precision */
+  int32_t x_cstride, x_coff;   /* 0,0 = dense (cstride = Cin) */
+  int32_t y_cstride, y_coff;   /* 0,0 = dense (cstride = Cout) */
+  int32_t reserved[4];    /* must be zero */
+} gc_conv_desc;
+
+/* Fused output stage of gc_conv2d_fprop / gc_conv2d_dgrad, applied in this order:
+ *   v = acc (+ bias[c]) ; v = act(v) ; store ; optional per-channel statistics of the STORED value.
+ * ch_sum / ch_sumsq, when non-NULL, are float[C] accumulators the kernel ADDS into with atomics (the caller
+ * zeroes them): sum and sum of squares over N*H*W per output channel -- the batch statistics BatchNorm2d
+ * needs right after the conv (BasicGANs/models.py:37,79; Pix2Pix/models.py:86,127). */
+typedef struct gc_epilogue {
+  int32_t act;            /* gc_act */
+  float slope;            /* LeakyReLU negative slope */
+  const float* bias;      /* float[C] or NULL */
+  float* ch_sum;          /* float[C] or NULL */
+  float* ch_sumsq;        /* float[C] or NULL */
+  int32_t reserved[4];    /* must be zero */
+} gc_epilogue;
+
+int gc_version(void);
+const char* gc_last_error(void);
+
+/* Size in bytes of the packed weight image consumed by the given pass (GC_PASS_FPROP or GC_PASS_DGRAD). */
+size_t gc_packed_weight_bytes(const gc_conv_desc* desc, int pass);
+
+/* Repack fp32 weights w[co][ci][r][s] (element strides w_strides[4]) into the bf16 (hi[,lo]) image the
+ * kernels of `pass` read, multiplied by alpha.  alpha carries the per-layer scalar prologues of the reference:
+ * EqualizedLR sqrt(2/fan_in) (StyleGAN/model.py:33-37) and SpectralNorm 1/sigma (BigGAN/model.py:20-25). */
+int gc_pack_weight(const gc_conv_desc* desc, int pass, const float* w, const int64_t w_strides[4], float alpha,
+                   void* packed, void* stream);
+
+/* y = conv2d(x, w) [+ bias, activation, statistics].  Replaces aten::convolution (forward) behind
+ *   torch.nn.Conv2d        BasicGANs/models.py:77; Pix2Pix/models.py:17,83,225-232; StyleGAN/model.py:72
+ *   F.conv2d               BigGAN/model.py:56-58
+ * and, as the gradient of a transposed conv w.r.t. its input, aten::convolution_backward of
+ *   torch.nn.ConvTranspose2d  BasicGANs/models.py:35; Pix2Pix/models.py:123-124; StyleGAN/model.py:404.
+ * packed_w comes from gc_pack_weight(desc, GC_PASS_FPROP, ...). */
+int gc_conv2d_fprop(const gc_conv_desc* desc, const void* x, const void* packed_w, void* y, const gc_epilogue* ep,
+                    void* stream);
+
+/* gx = d(conv2d)/dx applied to gy.  Replaces the input-gradient half of aten::convolution_backward for the
+ * Conv2d call sites above, and IS the forward pass of
+ *   torch.nn.ConvTranspose2d  BasicGANs/models.py:35; Pix2Pix/models.py:123-124
+ *   F.conv_transpose2d        StyleGAN/model.py:404
+ * (with the optional epilogue adding the transposed conv's bias / activation / statistics on gx).
+ * packed_w comes from gc_pack_weight(desc, GC_PASS_DGRAD, ...). */
+int gc_conv2d_dgrad(const gc_conv_desc* desc, const void* gy, const void* packed_w, void* gx, const gc_epilogue* ep,
+                    void* stream);
+
+/* Workspace bytes gc_conv2d_wgrad needs for this desc (split-K partial sums). */
+size_t gc_wgrad_workspace_bytes(const gc_conv_desc* desc);
+
+/* gw[co][ci][r][s] (fp32, element strides gw_strides[4]) = alpha * sum_{n,ho,wo} gy * x  (+ existing value if
+ * accumulate != 0); gbias (float[Cout], may be NULL) = sum_{n,ho,wo} gy.  Replaces the weight-gradient half
+ * of aten::convolution_backward for every call site above (for a transposed conv pass its input as gy and
+ * its output gradient as x). */
+int gc_conv2d_wgrad(const gc_conv_desc* desc, const void* x, const void* gy, float* gw, const int64_t gw_strides[4],
+                    float alpha, int accumulate, float* gbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Depthwise 3x3 binomial blur ([1 2 1] x [1 2 1]) / 16, zero padding 1, NHWC, dtype gc_dtype.  The kernel is
+ * symmetric, so the same call serves forward and backward (StyleGAN/model.py:82-150: BlurFunction,
+ * BlurFunctionBackward; F.conv2d(x, kernel, padding=1, groups=C)). */
+int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream around every launch while enabled.
+ * gc_profile_collect synchronises on the recorded events, returns the number of kernel families written to
+ * the caller's arrays (at most max_entries) and resets the records.  flops[] holds the algorithmic FLOPs
+ * (2 * MACs, necessary taps only) of the launches counted in launches[]. */
+int gc_profile_enable(int on);
+int gc_profile_collect(int max_entries, char names[][64], int64_t* launches, double* total_ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANCONV_H */
