@@ -1,0 +1,161 @@
+"""Benchmark of the convolution hot path inside the reference's WGAN-GP-64 training cycle on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one training cycle of BasicGANs/train.py:95-119 on synthetic data: 5 critic iterations (each: real
+pass, fake pass, gradient-penalty double backward, Adam step) + 1 generator iteration, batch 256 per GPU, i.e.
+256 real images consumed per GPU per step.  Prints ONE JSON line (rank 0):
+  value        whole-job images/s = n_gpus * 256 * K / (max over ranks of the time for K steps)
+  roofline     the dominant conv kernel family: algorithmic FLOPs (2*MACs, necessary taps only) of its launches
+               divided by their HIP-event time, measured on the launch stream in a profiled pass of the same
+               cycle right after the timed region; peak = dense bf16 MFMA rate of MI355X (2.5 PFLOP/s)
+  cpu_baseline the same cycle on the host CPU through the oracle's restatement of the reference (stock torch
+               CPU ops), rank 0 and N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH, HIDDEN, NZ, RES, REPS = 256, 64, 100, 64, 5
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def cpu_baseline(threads):
+    """One full WGAN-GP cycle (batch 256) on the host through oracle.ref_models; returns images/s."""
+    from oracle import ref_models as R
+    torch.set_num_threads(threads)
+    torch.manual_seed(5000)
+    G = R.Generator(NZ, HIDDEN, 3, resolution=RES); G.apply(R.weights_init)
+    D = R.Discriminator(3, HIDDEN, resolution=RES, is_wgan=True); D.apply(R.weights_init)
+    opt_D = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.0, 0.9))
+    opt_G = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.0, 0.9))
+    gen = torch.Generator().manual_seed(5001)
+    real, zs = R.synth_inputs(gen, BATCH, NZ, RES, REPS + 1)
+    eps = torch.rand(REPS, BATCH, 1, 1, 1, generator=gen)
+    # warm-up: one critic iteration on a quarter batch
+    R.wasserstein_step(G, D, real[:64], zs[0][:64], epsilon=eps[0][:64]); opt_D.zero_grad()
+    t0 = time.perf_counter()
+    R.wgangp_train_cycle(G, D, opt_G, opt_D, real, zs, eps)
+    dt = time.perf_counter() - t0
+    return {"value": BATCH / dt, "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": "1 full cycle (5 critic + 1 generator iterations) at batch 256, oracle/ref_models.py on torch CPU ops, fp32",
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="run the cycle eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32x3"])
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import gan_amd
+    from gan_amd import _lib
+    from gan_amd.ddp import GradReducer
+    from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
+    gan_amd.set_precision(a.precision)
+
+    use_graph = not a.no_graph and world == 1
+    tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if world > 1 else None),
+                       capturable=use_graph)
+    if world > 1:  # replicas start from identical parameters
+        for p in list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers()):
+            dist.broadcast(p.data, 0)
+    gen = torch.Generator().manual_seed(5001 + rank)
+    real, zs = synth_inputs(gen, BATCH, NZ, RES, REPS + 1)
+    eps = torch.rand(REPS, BATCH, 1, 1, 1, generator=gen)
+    tr.set_inputs(real, zs, eps)
+    if use_graph:
+        tr.capture(warmup=2)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.cycle()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.cycle()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    losses = tr.last.detach().float().cpu().tolist() if tr.graph is None else tr.static_out.detach().float().cpu().tolist()
+    finite = all(x == x and abs(x) != float("inf") for x in losses)
+
+    # ---- per-kernel timing of the same cycle (HIP events on the launch stream), eager, outside the timed region
+    roofline = None
+    if rank == 0:
+        _lib.profile_enable(True)
+        for _ in range(2):
+            tr.cycle_eager()
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        _lib.profile_enable(False)
+        conv = {k: v for k, v in prof.items() if v["flops"] > 0}
+        if conv:
+            name = max(conv, key=lambda k: conv[k]["total_ms"])
+            v = conv[name]
+            achieved = v["flops"] / (v["total_ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "launches": v["launches"],
+                        "avg_launch_us": 1e3 * v["total_ms"] / v["launches"], "avg_launch_gflop": v["flops"] / v["launches"] / 1e9,
+                        "all_kernels": {k: {"launches": q["launches"], "avg_us": 1e3 * q["total_ms"] / max(q["launches"], 1),
+                                            "tflops": (q["flops"] / (q["total_ms"] * 1e-3) / 1e12) if q["total_ms"] > 0 else 0.0}
+                                        for k, q in prof.items()}}
+
+    if rank == 0:
+        out = {
+            "metric": "G+D train img/s", "value": world * BATCH * a.steps / dt, "unit": "img/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == "bf16" else "bf16x3", "data": "synthetic",
+            "config": {"workload": "BasicGANs WGAN-GP 64x64 (hidden 64, nz 100), batch 256 per GPU; step = 5 critic iterations "
+                                   "(incl. gradient-penalty double backward) + 1 generator iteration, Adam; activations fp32 NHWC, "
+                                   "conv operands bf16 on MFMA with fp32 accumulate",
+                       "global_batch": world * BATCH, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "losses_finite": finite},
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+            try:
+                out["cpu_baseline"] = cpu_baseline(threads)
+            except Exception as e:  # the GPU number stands on its own
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

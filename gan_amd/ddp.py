@@ -1,0 +1,116 @@
+"""Data-parallel gradient reduction: one process per GPU, parameters replicated, gradients summed over ranks with
+bucketed all-reduce (RCCL over xGMI when the backend is "nccl") overlapped with the backward pass.
+
+The reference's only multi-GPU mechanism is single-process torch.nn.DataParallel (StyleGAN/train.py:121-125,
+BigGAN/train.py:150-154), which re-broadcasts every parameter on each forward and reduces gradients onto
+device 0.  Here every rank keeps its parameters resident and only gradients cross the links:
+
+  * all gradients of a network live in a few flat buckets (`param.grad` is a view into its bucket), built
+    in reverse registration order because the last layers' gradients are ready first;
+  * zero_grad() is one memset per bucket;
+  * a GAN phase may call .backward() several times (WGAN-GP: real, fake, penalty) -- gradients accumulate
+    locally and `arm()` is called before the LAST backward; from then on a post-accumulate hook counts the
+    parameters of each bucket and launches that bucket's asynchronous all-reduce as soon as it is complete,
+    while the rest of the backward pass is still running;
+  * finish() launches whatever was not triggered (parameters without gradient in this phase), waits for the
+    collectives on the current stream and averages.
+
+Batch-coupled layers: BatchNorm statistics stay per rank (as they do under the reference's DataParallel).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, average=True):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.average = average
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        self.dtype = params[0].dtype
+        for p in params:
+            if p.dtype != self.dtype:
+                raise ValueError("GradReducer expects all parameters of a module to share one dtype")
+        self.params = params
+        self.buckets = []          # flat tensors
+        self.bucket_of = {}        # id(param) -> bucket index
+        self._offset = {}          # id(param) -> element offset inside its bucket
+        self._members = []         # number of params per bucket
+        cur, cur_bytes = [], 0
+        groups = []
+        for p in reversed(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for bi, group in enumerate(groups):
+            n = sum(p.numel() for p in group)
+            flat = torch.zeros(n, dtype=self.dtype, device=group[0].device)
+            off = 0
+            for p in group:
+                self.bucket_of[id(p)] = bi
+                self._offset[id(p)] = off
+                off += p.numel()
+            self.buckets.append(flat)
+            self._members.append(len(group))
+            for p in group:
+                self._reattach(p)
+        self._armed = False
+        self._pending = [0] * len(self.buckets)
+        self._works = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    # -- public ---------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        for flat in self.buckets:
+            flat.zero_()
+        for p in self.params:      # re-attach views in case something replaced .grad (e.g. zero_grad(set_to_none=True))
+            if p.grad is None or p.grad.data_ptr() != self.buckets[self.bucket_of[id(p)]].data_ptr() + p.element_size() * self._offset[id(p)]:
+                self._reattach(p)
+
+    def arm(self):
+        """Call right before the last backward pass of the phase."""
+        self._armed = True
+        self._pending = list(self._members)
+        self._works = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+
+    def finish(self):
+        """Reduce what is left, wait (stream-ordered) and average.  After this the gradients are the mean over
+        ranks of the locally accumulated gradients."""
+        self._armed = False
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        for w in self._works:
+            if w is not None:
+                w.wait()
+        if self.average and self.world > 1:
+            for flat in self.buckets:
+                flat.div_(self.world)
+
+    # -- internals -------------------------------------------------------------------------------------------
+    def _reattach(self, p):
+        off = self._offset[id(p)]
+        p.grad = self.buckets[self.bucket_of[id(p)]][off:off + p.numel()].view(p.shape)
+
+    def _launch(self, bi):
+        self._launched[bi] = True
+        if self.world > 1:
+            self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _hook(self, p):
+        if not self._armed:
+            return
+        bi = self.bucket_of[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and not self._launched[bi]:
+            self._launch(bi)

@@ -1,0 +1,222 @@
+"""DCGAN / WGAN-GP generator, discriminator and training phases of the reference's BasicGANs family on the
+gan_amd convolution modules.
+
+Graphs and parameter names follow BasicGANs/models.py:6-86 (`main.{i}.0.weight` ...), the phases follow
+BasicGANs/loss_functions.py:4-76 and the step order BasicGANs/DCGAN.py:165-181 / BasicGANs/train.py:95-119.
+Differences that do not change results: no host synchronisation inside a phase (losses are returned as
+tensors, never .item()), and the WGAN-GP interpolation factor epsilon is an argument instead of a draw inside
+the loss, so that a step can be replayed exactly (tests) and captured into a HIP graph (bench).
+"""
+import math
+
+import torch
+
+from .. import nn as gnn
+
+
+def _seq(*m):
+    return torch.nn.Sequential(*m)
+
+
+class Generator(torch.nn.Module):
+    def __init__(self, z_dim, hidden_dim, image_dim=3, resolution=128):
+        super().__init__()
+        n_layers = int(math.log2(resolution)) - 1
+        width = 8 * hidden_dim
+        layers = []
+        for i in range(n_layers):
+            first, last = i == 0, i == n_layers - 1
+            cin = z_dim if first else int(width / 2 ** (i - 1))
+            cout = image_dim if last else int(width / 2 ** i)
+            conv = gnn.ConvTranspose2d(cin, cout, 4, 1 if first else 2, 0 if first else 1, bias=False)
+            layers.append(_seq(conv, torch.nn.Tanh()) if last else _seq(conv, torch.nn.BatchNorm2d(cout), torch.nn.ReLU(True)))
+        self.main = _seq(*layers)
+
+    def forward(self, noise_vector):
+        return self.main(noise_vector)
+
+
+class Discriminator(torch.nn.Module):
+    def __init__(self, image_dim, hidden_dim, resolution=128, is_wgan=False):
+        super().__init__()
+        n_layers = int(math.log2(resolution)) - 1
+        layers = []
+        for i in range(n_layers):
+            first, last = i == 0, i == n_layers - 1
+            cin = image_dim if first else int(hidden_dim * 2 ** (i - 1))
+            cout = 1 if last else int(hidden_dim * 2 ** i)
+            ops = [gnn.Conv2d(cin, cout, 4, 1 if last else 2, 0 if last else 1, bias=False)]
+            if first:
+                ops.append(torch.nn.LeakyReLU(0.2, inplace=True))
+            elif not last:
+                ops += [(torch.nn.InstanceNorm2d if is_wgan else torch.nn.BatchNorm2d)(cout), torch.nn.LeakyReLU(0.2, inplace=True)]
+            elif not is_wgan:
+                ops.append(torch.nn.Sigmoid())
+            layers.append(_seq(*ops))
+        self.main = _seq(*layers)
+
+    def forward(self, x):
+        return self.main(x)
+
+
+def weights_init(m):
+    """BasicGANs/utils.py:31-36."""
+    if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+        torch.nn.init.normal_(m.weight, 0.0, 0.02)
+    if isinstance(m, torch.nn.BatchNorm2d):
+        torch.nn.init.normal_(m.weight, 0.0, 0.02)
+        torch.nn.init.constant_(m.bias, 0)
+
+
+# ---- WGAN-GP phases (BasicGANs/loss_functions.py:4-38) --------------------------------------------------------
+def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_backward=None):
+    """Three backward passes accumulate into net_D's gradients: real batch (with the 0.001 drift term), fake
+    batch, gradient penalty (double backward).  `on_last_backward` is called right before the last one (a
+    data-parallel gradient reducer arms its hooks there).  Returns (D_x, D_G_z1, penalty) as tensors."""
+    d_real = net_D(real).view(-1)
+    d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
+    (-d_real).backward()
+
+    fake = net_G(z)
+    d_fake = net_D(fake.detach()).view(-1).mean()
+    d_fake.backward()
+
+    eps = epsilon.detach().clone().requires_grad_(True)
+    mixed = real.detach() * eps + fake.detach() * (1 - eps)
+    scores = net_D(mixed)
+    gradient = torch.autograd.grad(inputs=mixed, outputs=scores.sum(), create_graph=True)[0]
+    penalty = c_lambda * ((gradient.reshape(gradient.shape[0], -1).norm(2, dim=1) - 1) ** 2).mean()
+    if on_last_backward is not None:
+        on_last_backward()
+    penalty.backward()
+    return d_real.detach(), d_fake.detach(), penalty.detach()
+
+
+def wgan_generator_phase(net_G, net_D, z, on_last_backward=None):
+    fake = net_G(z)
+    d_fake = net_D(fake).view(-1)
+    g_error = -d_fake.mean()
+    if on_last_backward is not None:
+        on_last_backward()
+    g_error.backward()
+    return g_error.detach()
+
+
+# ---- DCGAN phases (BasicGANs/loss_functions.py:41-76, step order BasicGANs/DCGAN.py:165-181) ---------------------
+def dcgan_discriminator_phase(net_G, net_D, real, z, on_last_backward=None):
+    bce = torch.nn.functional.binary_cross_entropy
+    out_real = net_D(real).view(-1)
+    err_real = bce(out_real, torch.ones_like(out_real))
+    err_real.backward()
+    fake = net_G(z)
+    out_fake = net_D(fake.detach()).view(-1)
+    err_fake = bce(out_fake, torch.zeros_like(out_fake))
+    if on_last_backward is not None:
+        on_last_backward()
+    err_fake.backward()
+    return (err_real + err_fake).detach(), out_fake.mean().detach(), out_real.mean().detach(), fake
+
+
+def dcgan_generator_phase(net_D, fake, on_last_backward=None):
+    """`fake` still carries the generator graph built in the discriminator phase (the reference re-uses it)."""
+    bce = torch.nn.functional.binary_cross_entropy
+    out = net_D(fake).view(-1)
+    g_error = bce(out, torch.ones_like(out))
+    if on_last_backward is not None:
+        on_last_backward()
+    g_error.backward()
+    return g_error.detach(), out.mean().detach()
+
+
+def synth_inputs(gen, B, nz, res, n_z):
+    """Synthetic real batch U(-1,1) (stands in for Normalize(0.5, 0.5) images) and n_z latent batches N(0,1)
+    drawn on the CPU from `gen`, so the same numbers exist on every machine."""
+    real = torch.rand(B, 3, res, res, generator=gen) * 2 - 1
+    zs = [torch.randn(B, nz, 1, 1, generator=gen) for _ in range(n_z)]
+    return real, zs
+
+
+class WganGpTrainer:
+    """WGAN-GP 64x64 training cycle of BasicGANs/train.py: `disc_repeats` critic iterations, one generator
+    iteration, Adam(lr 1e-4, betas (0, 0.9)) for both nets.  Inputs live in static device buffers so that the
+    cycle can be captured into one HIP graph (no host work, no allocation, no synchronisation per cycle)."""
+
+    def __init__(self, batch, hidden_dim=64, z_dim=100, resolution=64, device="cuda", lr=1e-4, betas=(0.0, 0.9),
+                 c_lambda=10.0, disc_repeats=5, seed=5000, reducer_factory=None, capturable=True):
+        torch.manual_seed(seed)
+        self.B, self.nz, self.res, self.reps, self.c_lambda = batch, z_dim, resolution, disc_repeats, c_lambda
+        self.device = torch.device(device)
+        self.net_G = Generator(z_dim, hidden_dim, 3, resolution)
+        self.net_D = Discriminator(3, hidden_dim, resolution, is_wgan=True)
+        self.net_G.apply(weights_init)
+        self.net_D.apply(weights_init)
+        self.net_G.to(self.device)
+        self.net_D.to(self.device)
+        cap = capturable and self.device.type == "cuda"
+        self.opt_D = torch.optim.Adam(self.net_D.parameters(), lr=lr, betas=betas, capturable=cap, foreach=True)
+        self.opt_G = torch.optim.Adam(self.net_G.parameters(), lr=lr, betas=betas, capturable=cap, foreach=True)
+        cl = torch.channels_last
+        self.real = torch.zeros(batch, 3, resolution, resolution, device=self.device).contiguous(memory_format=cl)
+        self.z = torch.zeros(disc_repeats + 1, batch, z_dim, 1, 1, device=self.device)
+        self.eps = torch.zeros(disc_repeats, batch, 1, 1, 1, device=self.device)
+        self.red_D = reducer_factory(self.net_D) if reducer_factory else None
+        self.red_G = reducer_factory(self.net_G) if reducer_factory else None
+        self.graph = None
+        self.last = None
+
+    def set_inputs(self, real, zs, eps):
+        self.real.copy_(real)
+        self.z.copy_(torch.stack(list(zs)))
+        self.eps.copy_(eps)
+
+    def _zero(self, net, red):
+        if red is not None:
+            red.zero_grad()
+        else:
+            for p in net.parameters():
+                p.grad = None
+
+    def cycle_eager(self):
+        out = []
+        for it in range(self.reps):
+            self._zero(self.net_D, self.red_D)
+            arm = self.red_D.arm if self.red_D is not None else None
+            d_x, d_g_z1, gp = wgan_critic_phase(self.net_G, self.net_D, self.real, self.z[it], self.eps[it], self.c_lambda, arm)
+            if self.red_D is not None:
+                self.red_D.finish()
+            self.opt_D.step()
+            out += [d_x, d_g_z1, gp]
+        self._zero(self.net_G, self.red_G)
+        # the critic's gradients of the generator phase are never used (cleared by the next zero_grad)
+        for p in self.net_D.parameters():
+            p.requires_grad_(False)
+        arm = self.red_G.arm if self.red_G is not None else None
+        g_err = wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], arm)
+        for p in self.net_D.parameters():
+            p.requires_grad_(True)
+        if self.red_G is not None:
+            self.red_G.finish()
+        self.opt_G.step()
+        out.append(g_err)
+        self.last = torch.stack([o.reshape(()) for o in out])
+        return self.last
+
+    def capture(self, warmup=3):
+        """Warm up on a side stream, then record one cycle into a HIP graph."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.cycle_eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = self.cycle_eager()
+        return self.graph
+
+    def cycle(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_out
+        return self.cycle_eager()

@@ -1,0 +1,79 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol the header declares, validates
+descriptors and reports errors through the status / gc_last_error convention.  No kernel is launched."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from gan_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ganconv.h")).read()
+    declared = set(re.findall(r"\b(gc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"gc_pack_weight(desc"}  # nothing: keeps the set literal explicit
+    assert set(_lib.EXPORTS) == declared, (sorted(declared), sorted(_lib.EXPORTS))
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.gc_version() == 1
+
+
+def _desc(**kw):
+    d = _lib.ConvDesc()
+    base = dict(N=2, H=16, W=16, Cin=8, Ho=8, Wo=8, Cout=16, kh=4, kw=4, stride_h=2, stride_w=2, pad_h=1, pad_w=1,
+                x_dtype=_lib.GC_F32, y_dtype=_lib.GC_F32, precision=_lib.GC_PREC_BF16)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_sizes_and_descriptor_validation():
+    L = _lib.lib()
+    d = _desc()
+    # forward image: [Cout][16 taps][Cin padded to 64] bf16
+    assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == 16 * 16 * 64 * 2
+    assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_DGRAD) == 8 * 16 * 64 * 2
+    d.precision = _lib.GC_PREC_F32X3
+    assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == 2 * 16 * 16 * 64 * 2
+    assert L.gc_wgrad_workspace_bytes(ctypes.byref(d)) % (16 * 16 * 8 * 4) == 0 and L.gc_wgrad_workspace_bytes(ctypes.byref(d)) > 0
+    bad = _desc(Ho=9)
+    assert L.gc_packed_weight_bytes(ctypes.byref(bad), _lib.GC_PASS_FPROP) == 0
+    assert b"do not match" in L.gc_last_error()
+    assert L.gc_conv2d_fprop(ctypes.byref(bad), None, None, None, None, None) == -1          # GC_BAD_DESC
+    assert L.gc_conv2d_fprop(ctypes.byref(_desc(stride_h=3, stride_w=3, Ho=5, Wo=5)), None, None, None, None, None) == -2
+    assert L.gc_conv2d_fprop(ctypes.byref(_desc()), None, None, None, None, None) == -5       # null pointers
+    assert L.gc_conv2d_fprop(ctypes.byref(_desc(N=0)), None, None, None, None, None) == 0     # empty batch is a no-op
+    assert L.gc_conv2d_wgrad(ctypes.byref(_desc()), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
+                             (ctypes.c_int64 * 4)(1, 1, 1, 1), 1.0, 0, None, None, 0, None) == -3  # workspace too small
+    assert L.gc_dwblur3x3(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 4, 4, 6, _lib.GC_F32, None) == -2
+
+
+def test_python_layer_fails_loudly_without_gpu():
+    import gan_amd
+    conv = gan_amd.nn.Conv2d(3, 8, 4, 2, 1)
+    assert isinstance(conv, torch.nn.Conv2d) and conv.weight.shape == (8, 3, 4, 4)
+    with pytest.raises(RuntimeError, match="GPU"):
+        conv(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="dilation"):
+        gan_amd.functional.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(8, 3, 3, 3), dilation=2)
+    with pytest.raises(RuntimeError, match="groups"):
+        gan_amd.functional.conv2d(torch.zeros(1, 4, 8, 8), torch.zeros(4, 1, 3, 3), groups=4)
+    convt = gan_amd.nn.ConvTranspose2d(8, 3, 4, 2, 1, bias=False)
+    assert isinstance(convt, torch.nn.ConvTranspose2d) and convt.weight.shape == (8, 3, 4, 4)
+
+
+def test_state_dict_names_match_reference_checkpoints():
+    from gan_amd.harness.basic_gans import Discriminator, Generator
+    from oracle import ref_models as R
+    G, D = Generator(100, 8, 3, 64), Discriminator(3, 8, 64, is_wgan=True)
+    Gr, Dr = R.Generator(100, 8, 3, 64), R.Discriminator(3, 8, 64, is_wgan=True)
+    assert list(G.state_dict().keys()) == list(Gr.state_dict().keys())
+    assert list(D.state_dict().keys()) == list(Dr.state_dict().keys())
+    assert [tuple(v.shape) for v in G.state_dict().values()] == [tuple(v.shape) for v in Gr.state_dict().values()]
+    G.load_state_dict(Gr.state_dict()); D.load_state_dict(Dr.state_dict())
