@@ -38,6 +38,7 @@ struct GatherParams {
 struct GatherLaunch {
   int to, tp;          // tile: output channels x pixels
   bool in_bf16, x3, aligned;
+  double flops;        // algorithmic FLOPs of this launch (for the optional event timing)
 };
 
 // Chooses the tile for a problem; fills n_pix_tiles / n_oc_tiles and the class tile prefix in p.tt.

@@ -10,6 +10,8 @@
 // Block = 256 threads = 4 waves, tile TO channels x TP pixels, reduction depth 64 per step, operands staged
 // global -> registers -> LDS (bf16, XOR-swizzled 128-byte rows, conflict-free ds_read_b128) with two LDS
 // buffers: the loads of step k+1 are in flight while step k runs on the matrix cores.
+#include <stdio.h>
+
 #include "conv_gather.h"
 
 namespace gc {
@@ -296,7 +298,7 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
 }
 
 template <typename TIn, int TO, int TP, bool X3, bool ALIGNED>
-static int launch_one(const GatherParams& p, hipStream_t stream) {
+static int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int PL = X3 ? 2 : 1;
   constexpr int smem = 2 * PL * (TO + TP) * 128;
   auto kern = conv_gather_kernel<TIn, TO, TP, X3, ALIGNED>;
@@ -308,15 +310,19 @@ static int launch_one(const GatherParams& p, hipStream_t stream) {
     attr_set = true;
   }
   const unsigned nblocks = (unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles;
+  char name[64];  // the demangled kernel name as a profiler prints it
+  snprintf(name, sizeof(name), "gc::conv_gather_kernel<%s, %d, %d, %s, %s>", sizeof(TIn) == 4 ? "float" : "unsigned short", TO, TP,
+           X3 ? "true" : "false", ALIGNED ? "true" : "false");
+  ProfScope ps(name, flops, stream);
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kThreads), smem, stream, p);
   return check_hip(hipGetLastError(), "conv_gather launch");
 }
 
 template <typename TIn, bool X3, bool ALIGNED>
 static int launch_tile(const GatherParams& p, const GatherLaunch& l, hipStream_t s) {
-  if (l.to == 128) return launch_one<TIn, 128, 128, X3, ALIGNED>(p, s);
-  if (l.to == 64) return launch_one<TIn, 64, 128, X3, ALIGNED>(p, s);
-  return launch_one<TIn, 16, 256, X3, ALIGNED>(p, s);
+  if (l.to == 128) return launch_one<TIn, 128, 128, X3, ALIGNED>(p, l.flops, s);
+  if (l.to == 64) return launch_one<TIn, 64, 128, X3, ALIGNED>(p, l.flops, s);
+  return launch_one<TIn, 16, 256, X3, ALIGNED>(p, l.flops, s);
 }
 
 int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t s) {

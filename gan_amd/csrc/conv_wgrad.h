@@ -19,6 +19,7 @@ struct WgradParams {
 struct WgradLaunch {
   int to, tc;
   bool bf16, x3, aligned;
+  double flops;
 };
 
 struct WgradReduceParams {

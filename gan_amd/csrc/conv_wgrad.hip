@@ -7,6 +7,8 @@
 // workgroups (grid.z); every split writes its partial tile with plain stores and a second small kernel sums
 // the splits in a fixed order, scales, and scatters into the caller's [Cout][Cin][kh][kw] layout -- bitwise
 // reproducible, no float atomics.
+#include <stdio.h>
+
 #include "conv_wgrad.h"
 
 namespace gc {
@@ -248,7 +250,11 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l) {
 }
 
 template <typename T, int TO, int TC, bool X3, bool ALIGNED>
-static int launch_one(const WgradParams& p, hipStream_t stream) {
+static int launch_one(const WgradParams& p, double flops, hipStream_t stream) {
+  char name[64];
+  snprintf(name, sizeof(name), "gc::conv_wgrad_kernel<%s, %d, %d, %s, %s>", sizeof(T) == 4 ? "float" : "unsigned short", TO, TC,
+           X3 ? "true" : "false", ALIGNED ? "true" : "false");
+  ProfScope ps(name, flops, stream);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, TO, TC, X3, ALIGNED>),
                      dim3(p.n_co_tiles * p.n_ci_tiles, p.kh * p.kw, p.splits), dim3(kThreads), 0, stream, p);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
@@ -256,10 +262,10 @@ static int launch_one(const WgradParams& p, hipStream_t stream) {
 
 template <typename T, bool X3, bool ALIGNED>
 static int launch_tile(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
-  if (l.to == 128 && l.tc == 128) return launch_one<T, 128, 128, X3, ALIGNED>(p, s);
-  if (l.to == 128 && l.tc == 64) return launch_one<T, 128, 64, X3, ALIGNED>(p, s);
-  if (l.to == 64 && l.tc == 128) return launch_one<T, 64, 128, X3, ALIGNED>(p, s);
-  return launch_one<T, 64, 64, X3, ALIGNED>(p, s);
+  if (l.to == 128 && l.tc == 128) return launch_one<T, 128, 128, X3, ALIGNED>(p, l.flops, s);
+  if (l.to == 128 && l.tc == 64) return launch_one<T, 128, 64, X3, ALIGNED>(p, l.flops, s);
+  if (l.to == 64 && l.tc == 128) return launch_one<T, 64, 128, X3, ALIGNED>(p, l.flops, s);
+  return launch_one<T, 64, 64, X3, ALIGNED>(p, l.flops, s);
 }
 
 int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {

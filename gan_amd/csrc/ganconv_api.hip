@@ -44,14 +44,14 @@ ProfScope::ProfScope(const char* name, double flops, hipStream_t s) : slot(-1), 
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r{name, flops, nullptr, nullptr};
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-  hipEventRecord(r.e0, s);
+  (void)hipEventRecord(r.e0, s);
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;
 }
 ProfScope::~ProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  hipEventRecord(g_prof[slot].e1, stream);
+  (void)hipEventRecord(g_prof[slot].e1, stream);
 }
 
 // ---- weight repack -------------------------------------------------------------------------------------
@@ -207,7 +207,7 @@ int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_
   const size_t total = (size_t)rows * d->kh * d->kw * colp;
   size_t blocks = (total + kThreads - 1) / kThreads;
   if (blocks > 4096) blocks = 4096;
-  ProfScope ps("pack_weight", 0.0, (hipStream_t)stream);
+  ProfScope ps("gc::pack_weight_kernel", 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, w, w_strides[0], w_strides[1],
                      w_strides[2], w_strides[3], (uint16_t*)packed, rows, cols, colp, d->kh, d->kw, transpose, planes, alpha);
   return check_hip(hipGetLastError(), "pack_weight launch");
@@ -245,7 +245,7 @@ int gc_conv2d_fprop(const gc_conv_desc* d, const void* x, const void* packed_w, 
   l.aligned = aligned16(x) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
   p.out_vec = (reinterpret_cast<uintptr_t>(y) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
   plan_gather(p, l);
-  ProfScope ps("conv_fprop", conv_flops(d), (hipStream_t)stream);
+  l.flops = conv_flops(d);
   return launch_gather(p, l, (hipStream_t)stream);
 }
 
@@ -292,7 +292,7 @@ int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w,
   l.aligned = aligned16(gy) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
   p.out_vec = (reinterpret_cast<uintptr_t>(gx) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
   plan_gather(p, l);
-  ProfScope ps("conv_dgrad", conv_flops(d), (hipStream_t)stream);
+  l.flops = conv_flops(d);
   return launch_gather(p, l, (hipStream_t)stream);
 }
 
@@ -331,21 +331,19 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   const int epc = elems_per_chunk(d->x_dtype);
   l.aligned = aligned16(x) && aligned16(gy) && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0) &&
               (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
-  {
-    ProfScope ps("conv_wgrad", conv_flops(d), (hipStream_t)stream);
-    if ((rc = launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
-  }
+  l.flops = conv_flops(d);
+  if ((rc = launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
   WgradReduceParams r;
   r.part = p.part; r.gw = gw;
   r.s_co = gw_strides[0]; r.s_ci = gw_strides[1]; r.s_r = gw_strides[2]; r.s_s = gw_strides[3];
   r.Cout = d->Cout; r.Cin = d->Cin; r.kh = d->kh; r.kw = d->kw; r.splits = d->N == 0 ? 0 : p.splits;
   r.alpha = alpha; r.accumulate = accumulate;
   {
-    ProfScope ps("wgrad_reduce", 0.0, (hipStream_t)stream);
+    ProfScope ps("gc::wgrad_reduce_kernel", 0.0, (hipStream_t)stream);
     if ((rc = launch_wgrad_reduce(r, (hipStream_t)stream)) != GC_OK) return rc;
   }
   if (gbias != nullptr) {
-    ProfScope ps("bias_grad", 0.0, (hipStream_t)stream);
+    ProfScope ps("gc::colsum_kernel", 0.0, (hipStream_t)stream);
     if ((rc = launch_colsum(gy, gbias, p.K, d->Cout, p.y_cstride, p.y_coff, l.bf16, (hipStream_t)stream)) != GC_OK) return rc;
   }
   return GC_OK;
@@ -363,7 +361,7 @@ int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_
   const size_t total = (size_t)N * H * W * (C / 4);
   size_t blocks = (total + kThreads - 1) / kThreads;
   if (blocks > 8192) blocks = 8192;
-  ProfScope ps("dwblur3x3", 0.0, (hipStream_t)stream);
+  ProfScope ps("gc::dwblur3x3_kernel", 0.0, (hipStream_t)stream);
   if (dtype == GC_F32)
     hipLaunchKernelGGL(dwblur3x3_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C / 4);
   else
@@ -394,8 +392,8 @@ int gc_profile_collect(int max_entries, char names[][64], int64_t* launches, dou
       }
       if (i < n) { launches[i]++; total_ms[i] += ms; flops[i] += r.flops; }
     }
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
   return n;
