@@ -1,0 +1,177 @@
+// InstanceNorm2d (affine = false, biased variance) fused with LeakyReLU, NHWC fp32: forward, backward and the
+// backward of the backward (needed by the WGAN-GP gradient penalty, which differentiates the critic twice).
+//
+//   forward       z  = lrelu(xh),  xh = (x - mu) * r,  mu / r = per-(n,c) mean and rsqrt(var + eps) over H*W
+//   backward      gx = r * P(gy),  gy = gz * m,  m = (xh > 0 ? 1 : slope),  P(v) = v - mean(v) - xh * mean(v * xh)
+//   2nd backward  given u (the gradient arriving at gx):
+//                   g_gz = m * r * P(u)
+//                   g_x  = -(r^2 / n) * [ (a - b*c/n) * xh + c * P(u) + b * P(gy) ]
+//                 with n = H*W, a = sum(u*gy) - n*mean(u)*mean(gy), b = sum(u*xh), c = sum(gy*xh)
+//                 (P is self-adjoint and LeakyReLU is piecewise linear, so no further terms appear).
+//
+// One workgroup owns one sample and a run of 64 channels: 16 lanes across channel quads (16-byte accesses,
+// coalesced along the NHWC channel axis) x 16 lanes across pixels.  Statistics are recomputed from x in every
+// kernel (mean first, then centred sums: no E[x^2]-E[x]^2 cancellation); the per-workgroup slab (H*W x 64
+// channels) is re-read from L2.
+#include "common.h"
+
+namespace gc {
+
+struct InstNormParams {
+  const float* x;
+  const float* gz;
+  const float* u;
+  float* out0;   // z | gx | g_x
+  float* out1;   // - | -  | g_gz
+  int32_t N, HW, C;
+  int32_t qb_log2;   // log2 of channel quads per workgroup (<= 4)
+  float eps, slope;
+  int32_t act;       // GC_ACT_NONE or GC_ACT_LRELU
+};
+
+__device__ __forceinline__ f32x4 block_sum(f32x4 v, f32x4* red, int tq, int tl, int QB, int PL) {
+  red[tl * QB + tq] = v;
+  __syncthreads();
+  if (tl == 0) {
+    f32x4 s = v;
+    for (int j = 1; j < PL; j++) s += red[j * QB + tq];
+    red[tq] = s;
+  }
+  __syncthreads();
+  const f32x4 r = red[tq];
+  __syncthreads();
+  return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams p) {
+  __shared__ f32x4 red[kThreads];
+  const int QB = 1 << p.qb_log2, PL = kThreads >> p.qb_log2;
+  const int t = threadIdx.x, tq = t & (QB - 1), tl = t >> p.qb_log2;
+  const int chunks = (p.C / 4 + QB - 1) / QB;
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int c = (chunk * QB + tq) * 4;
+  const bool cok = c < p.C;
+  const size_t base = (size_t)n * p.HW * p.C + (cok ? c : 0);
+  const float inv_n = 1.f / (float)p.HW;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto ld = [&](const float* ptr, int pix) -> f32x4 { return *reinterpret_cast<const f32x4*>(ptr + base + (size_t)pix * p.C); };
+  auto mask = [&](f32x4 d) -> f32x4 {
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; e++) m[e] = (p.act == GC_ACT_LRELU && !(d[e] > 0.f)) ? p.slope : 1.f;
+    return m;
+  };
+
+  f32x4 s = zero;
+  if (cok)
+    for (int pix = tl; pix < p.HW; pix += PL) s += ld(p.x, pix);
+  const f32x4 mu = block_sum(s, red, tq, tl, QB, PL) * inv_n;
+
+  f32x4 s2 = zero, sg = zero, sgd = zero, su = zero, sud = zero, sug = zero;
+  if (cok)
+    for (int pix = tl; pix < p.HW; pix += PL) {
+      const f32x4 d = ld(p.x, pix) - mu;
+      s2 += d * d;
+      if (MODE >= 1) {
+        const f32x4 gy = ld(p.gz, pix) * mask(d);
+        sg += gy;
+        sgd += gy * d;
+        if (MODE == 2) {
+          const f32x4 uu = ld(p.u, pix);
+          su += uu;
+          sud += uu * d;
+          sug += uu * gy;
+        }
+      }
+    }
+  s2 = block_sum(s2, red, tq, tl, QB, PL);
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; e++) r[e] = rsqrtf(s2[e] * inv_n + p.eps);
+  if (MODE >= 1) {
+    sg = block_sum(sg, red, tq, tl, QB, PL);
+    sgd = block_sum(sgd, red, tq, tl, QB, PL);
+  }
+  if (MODE == 2) {
+    su = block_sum(su, red, tq, tl, QB, PL);
+    sud = block_sum(sud, red, tq, tl, QB, PL);
+    sug = block_sum(sug, red, tq, tl, QB, PL);
+  }
+  if (!cok) return;
+
+  if (MODE == 0) {
+    for (int pix = tl; pix < p.HW; pix += PL) {
+      const f32x4 d = ld(p.x, pix) - mu;
+      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = d * r * mask(d);
+    }
+  } else if (MODE == 1) {
+    const f32x4 gbar = sg * inv_n, cbar = sgd * r * inv_n;   // mean(gy), mean(gy * xh)
+    for (int pix = tl; pix < p.HW; pix += PL) {
+      const f32x4 d = ld(p.x, pix) - mu;
+      const f32x4 gy = ld(p.gz, pix) * mask(d);
+      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = r * (gy - gbar - d * r * cbar);
+    }
+  } else {
+    const float nn = (float)p.HW;
+    const f32x4 gbar = sg * inv_n, ubar = su * inv_n;
+    const f32x4 c_ = sgd * r, b_ = sud * r;                  // sum(gy * xh), sum(u * xh)
+    const f32x4 a_ = sug - nn * ubar * gbar;
+    const f32x4 k0 = a_ - b_ * c_ * inv_n;
+    const f32x4 scale = -(r * r) * inv_n;
+    for (int pix = tl; pix < p.HW; pix += PL) {
+      const f32x4 d = ld(p.x, pix) - mu;
+      const f32x4 m = mask(d);
+      const f32x4 xh = d * r;
+      const f32x4 gy = ld(p.gz, pix) * m;
+      const f32x4 uu = ld(p.u, pix);
+      const f32x4 pu = uu - ubar - xh * (b_ * inv_n);
+      const f32x4 pg = gy - gbar - xh * (c_ * inv_n);
+      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = scale * (k0 * xh + c_ * pu + b_ * pg);
+      *reinterpret_cast<f32x4*>(p.out1 + base + (size_t)pix * p.C) = m * r * pu;
+    }
+  }
+}
+
+static int launch_instnorm(int mode, const float* x, const float* gz, const float* u, float* out0, float* out1, int N, int HW, int C,
+                           float eps, float slope, int act, hipStream_t stream) {
+  if (N < 0 || HW <= 0 || C <= 0) { set_error("instnorm: bad shape"); return GC_BAD_ARGUMENT; }
+  if (act != GC_ACT_NONE && act != GC_ACT_LRELU) { set_error("instnorm: activation must be none or LeakyReLU"); return GC_BAD_ARGUMENT; }
+  if (act == GC_ACT_LRELU && !(slope > 0.f)) { set_error("instnorm: LeakyReLU slope must be positive"); return GC_UNSUPPORTED_GEOMETRY; }
+  if (C % 4 != 0) { set_error("instnorm: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
+  if (N == 0) return GC_OK;
+  const void* ptrs[5] = {x, mode >= 1 ? gz : x, mode == 2 ? u : x, out0, mode == 2 ? out1 : out0};
+  for (auto q : ptrs)
+    if (q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u)) { set_error("instnorm: null or misaligned pointer"); return GC_BAD_ARGUMENT; }
+  InstNormParams p{x, gz, u, out0, out1, N, HW, C, 0, eps, slope, act};
+  while ((1 << p.qb_log2) < C / 4 && p.qb_log2 < 4) p.qb_log2++;
+  const int QB = 1 << p.qb_log2;
+  const int chunks = (C / 4 + QB - 1) / QB;
+  const dim3 grid((unsigned)N * chunks), block(kThreads);
+  static const char* names[3] = {"gc::instnorm_kernel<0>", "gc::instnorm_kernel<1>", "gc::instnorm_kernel<2>"};
+  ProfScope ps(names[mode], 0.0, stream);
+  if (mode == 0) hipLaunchKernelGGL(instnorm_kernel<0>, grid, block, 0, stream, p);
+  else if (mode == 1) hipLaunchKernelGGL(instnorm_kernel<1>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(instnorm_kernel<2>, grid, block, 0, stream, p);
+  return check_hip(hipGetLastError(), "instnorm launch");
+}
+
+}  // namespace gc
+
+extern "C" {
+
+int gc_instnorm_act_fwd(const float* x, float* z, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream) {
+  return gc::launch_instnorm(0, x, nullptr, nullptr, z, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
+}
+
+int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope,
+                        void* stream) {
+  return gc::launch_instnorm(1, x, gz, nullptr, gx, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
+}
+
+int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, int32_t N, int32_t HW, int32_t C,
+                            float eps, int32_t act, float slope, void* stream) {
+  return gc::launch_instnorm(2, x, gz, u, g_x, g_gz, N, HW, C, eps, slope, act, (hipStream_t)stream);
+}
+
+}  // extern "C"

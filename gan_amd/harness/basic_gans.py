@@ -48,8 +48,10 @@ class Discriminator(torch.nn.Module):
             ops = [gnn.Conv2d(cin, cout, 4, 1 if last else 2, 0 if last else 1, bias=False)]
             if first:
                 ops.append(torch.nn.LeakyReLU(0.2, inplace=True))
+            elif not last and is_wgan:   # InstanceNorm2d + LeakyReLU(0.2) of the reference as one fused op (no parameters)
+                ops.append(gnn.InstanceNormAct2d(cout, negative_slope=0.2))
             elif not last:
-                ops += [(torch.nn.InstanceNorm2d if is_wgan else torch.nn.BatchNorm2d)(cout), torch.nn.LeakyReLU(0.2, inplace=True)]
+                ops += [torch.nn.BatchNorm2d(cout), torch.nn.LeakyReLU(0.2, inplace=True)]
             elif not is_wgan:
                 ops.append(torch.nn.Sigmoid())
             layers.append(_seq(*ops))

@@ -56,3 +56,24 @@ class BlurLayer(torch.nn.Module):
 
     def forward(self, input):
         return F.blur3x3(input)
+
+
+class InstanceNormAct2d(torch.nn.Module):
+    """InstanceNorm2d(affine=False, track_running_stats=False) followed by LeakyReLU(negative_slope), or by nothing
+    when negative_slope is None, as ONE kernel with hand-written backward and double-backward kernels.  Holds no
+    parameters or buffers, so replacing the reference's norm + activation pair (BasicGANs/models.py:79-80) with it
+    leaves state_dicts unchanged."""
+
+    def __init__(self, num_features, eps=1e-5, negative_slope=0.2):
+        super().__init__()
+        self.num_features, self.eps, self.negative_slope = num_features, eps, negative_slope
+
+    def forward(self, input):
+        if input.shape[1] != self.num_features:
+            raise RuntimeError(f"expected {self.num_features} channels, got {input.shape[1]}")
+        if self.negative_slope is None:
+            return ops.instnorm_act(input, self.eps, 0, 0.0)
+        return ops.instnorm_act(input, self.eps, 2, float(self.negative_slope))
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, negative_slope={self.negative_slope}"

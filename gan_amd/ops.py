@@ -287,3 +287,92 @@ def _(x):
 
 # the kernel is symmetric, so the blur is self-adjoint: its backward (and double backward) is the blur itself
 torch.library.register_autograd("ganconv::blur3x3", lambda ctx, g: blur3x3(g), setup_context=lambda ctx, inputs, output: None)
+
+
+# ---- InstanceNorm (+ LeakyReLU), with explicit first- and second-order backward kernels --------------------------
+def _in_args(x):
+    if x.dtype != torch.float32:
+        raise RuntimeError("ganconv: instance norm kernels take float32 tensors")
+    N, C, H, W = x.shape
+    return N, H * W, C
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+@torch.library.custom_op("ganconv::instnorm_act", mutates_args=())
+def instnorm_act(x: Tensor, eps: float, act: int, slope: float) -> Tensor:
+    """act((x - mean) * rsqrt(var + eps)) per (sample, channel); act = GC_ACT_NONE or GC_ACT_LRELU."""
+    _check_cuda(x)
+    x = _nhwc(x)
+    N, HW, C = _in_args(x)
+    z = torch.empty_like(x, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_instnorm_act_fwd(_ptr(x), _ptr(z), N, HW, C, eps, act, slope, _stream()), "gc_instnorm_act_fwd")
+    return z
+
+
+@instnorm_act.register_fake
+def _(x, eps, act, slope):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("ganconv::instnorm_act_bwd", mutates_args=())
+def instnorm_act_bwd(x: Tensor, gz: Tensor, eps: float, act: int, slope: float) -> Tensor:
+    _check_cuda(x, gz)
+    x, gz = _nhwc(x), _nhwc(gz)
+    N, HW, C = _in_args(x)
+    gx = torch.empty_like(x, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_instnorm_act_bwd(_ptr(x), _ptr(gz), _ptr(gx), N, HW, C, eps, act, slope, _stream()), "gc_instnorm_act_bwd")
+    return gx
+
+
+@instnorm_act_bwd.register_fake
+def _(x, gz, eps, act, slope):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("ganconv::instnorm_act_bwd_bwd", mutates_args=())
+def instnorm_act_bwd_bwd(x: Tensor, gz: Tensor, u: Tensor, eps: float, act: int, slope: float) -> tuple[Tensor, Tensor]:
+    _check_cuda(x, gz, u)
+    x, gz, u = _nhwc(x), _nhwc(gz), _nhwc(u)
+    N, HW, C = _in_args(x)
+    g_x = torch.empty_like(x, memory_format=torch.channels_last)
+    g_gz = torch.empty_like(x, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_instnorm_act_bwd_bwd(_ptr(x), _ptr(gz), _ptr(u), _ptr(g_x), _ptr(g_gz), N, HW, C, eps, act, slope, _stream()),
+               "gc_instnorm_act_bwd_bwd")
+    return g_x, g_gz
+
+
+@instnorm_act_bwd_bwd.register_fake
+def _(x, gz, u, eps, act, slope):
+    return torch.empty_like(x), torch.empty_like(x)
+
+
+def _in_setup(ctx, inputs, output):
+    x, eps, act, slope = inputs
+    ctx.save_for_backward(x)
+    ctx.cfg = (eps, act, slope)
+
+
+def _in_backward(ctx, gz):
+    (x,) = ctx.saved_tensors
+    return instnorm_act_bwd(x, gz, *ctx.cfg), None, None, None
+
+
+torch.library.register_autograd("ganconv::instnorm_act", _in_backward, setup_context=_in_setup)
+
+
+def _in_bwd_setup(ctx, inputs, output):
+    x, gz, eps, act, slope = inputs
+    ctx.save_for_backward(x, gz)
+    ctx.cfg = (eps, act, slope)
+
+
+def _in_bwd_backward(ctx, u):
+    x, gz = ctx.saved_tensors
+    g_x, g_gz = instnorm_act_bwd_bwd(x, gz, u, *ctx.cfg)
+    return g_x, g_gz, None, None, None
+
+
+torch.library.register_autograd("ganconv::instnorm_act_bwd", _in_bwd_backward, setup_context=_in_bwd_setup)

@@ -131,6 +131,21 @@ int gc_conv2d_wgrad(const gc_conv_desc* desc, const void* x, const void* gy, flo
  * BlurFunctionBackward; F.conv2d(x, kernel, padding=1, groups=C)). */
 int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 
+/* InstanceNorm2d (affine = false, no running statistics, biased variance, eps inside the square root) fused with
+ * an optional LeakyReLU, NHWC fp32, C a multiple of 4; HW = H*W.  Replaces aten::instance_norm + aten::leaky_relu
+ * and their first- and second-order backward at
+ *   torch.nn.InstanceNorm2d(out_dim), torch.nn.LeakyReLU(0.2)   BasicGANs/models.py:79-80 (the WGAN-GP critic)
+ *   torch.nn.InstanceNorm2d(channels) inside AdaIN               StyleGAN/model.py:195 (act = GC_ACT_NONE)
+ * fwd:      z = act((x - mean) * rsqrt(var + eps))
+ * bwd:      gx = d(loss)/dx given gz = d(loss)/dz              (statistics are recomputed from x)
+ * bwd_bwd:  given u = d(loss2)/d(gx):  g_x = d(loss2)/dx through gx,  g_gz = d(loss2)/d(gz)
+ * The second-order kernel is what the gradient penalty's .backward() needs (BasicGANs/loss_functions.py:21-28). */
+int gc_instnorm_act_fwd(const float* x, float* z, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream);
+int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, int32_t N, int32_t HW, int32_t C, float eps, int32_t act,
+                        float slope, void* stream);
+int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, int32_t N, int32_t HW,
+                            int32_t C, float eps, int32_t act, float slope, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around every launch while enabled.
  * gc_profile_collect synchronises on the recorded events, returns the number of kernel families written to
  * the caller's arrays (at most max_entries) and resets the records.  flops[] holds the algorithmic FLOPs

@@ -184,6 +184,32 @@ def test_blur(gan, ops_golden):
     assert rel(xx.grad, oracle.dwblur3x3(g.cpu().numpy())) < 1e-6   # self-adjoint
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 128, 16, 16), (2, 512, 4, 4), (1, 8, 5, 7)])
+@pytest.mark.parametrize("slope", [0.2, None])
+def test_instnorm_act_first_and_second_order(gan, shape, slope):
+    """Fused InstanceNorm (+LeakyReLU) forward, backward and double backward against stock torch CPU autograd
+    (float64 reference of torch.nn.InstanceNorm2d + LeakyReLU, the reference's BasicGANs/models.py:79-80 pair)."""
+    torch.manual_seed(2)
+    x = torch.randn(*shape); gz = torch.randn(*shape); u = torch.randn(*shape)
+
+    def run(f, x, gz, u):
+        x = x.clone().requires_grad_(True); gz = gz.clone().requires_grad_(True)
+        z = f(x)
+        (gx,) = torch.autograd.grad(z, x, gz, create_graph=True)
+        g_x, g_gz = torch.autograd.grad((gx * u).sum(), [x, gz])
+        return z.detach(), gx.detach(), g_x, g_gz
+
+    def ref(x):
+        y = torch.nn.functional.instance_norm(x, eps=1e-5)
+        return torch.nn.functional.leaky_relu(y, slope) if slope is not None else y
+
+    mod = gan.nn.InstanceNormAct2d(shape[1], negative_slope=slope)
+    want = run(ref, x.double(), gz.double(), u.double())
+    got = run(mod, x.cuda(), gz.cuda(), u.cuda())
+    for name, a, b in zip(("z", "gx", "g_x", "g_gz"), got, want):
+        assert rel(a, b) < 2e-5, name
+
+
 def _load_state(net, blob, prefix):
     sd = {k[len(prefix):]: torch.from_numpy(blob[k]) for k in blob.files if k.startswith(prefix)}
     net.load_state_dict(sd)
