@@ -18,7 +18,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;   // 4 wavefronts of 64
 constexpr int kBK = 64;         // reduction-tile depth (channels) of the gather kernels, in elements
 constexpr int kMaxTaps = 64;
-constexpr int kMaxClasses = 4;
+constexpr int kMaxClasses = 16;
 
 // fp32 x4 -> bf16 x4 (round to nearest even; v_cvt_pk_bf16_f32), returned as two packed dwords
 __device__ __forceinline__ u32x2 cvt_bf16x4(f32x4 v) {

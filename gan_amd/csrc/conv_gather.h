@@ -11,37 +11,49 @@ struct TapTable {
   int32_t n_classes;
   int32_t cls_tile_start[kMaxClasses + 1];  // first pixel-tile index of each class (prefix sums)
   int32_t cls_tap_start[kMaxClasses + 1];   // first entry of each class in dh/dw/wtap
-  int32_t cls_ph[kMaxClasses], cls_pw[kMaxClasses];  // output pixel of class-local (oh', ow') is (oh'*b + ph, ow'*b + pw)
-  int32_t cls_oh[kMaxClasses], cls_ow[kMaxClasses];  // class extent
+  int8_t cls_ph[kMaxClasses], cls_pw[kMaxClasses];    // output pixel of class-local (oh', ow') is (oh'*b + ph, ow'*b + pw)
+  int16_t cls_oh[kMaxClasses], cls_ow[kMaxClasses];   // class extent
   int8_t dh[kMaxTaps], dw[kMaxTaps];        // input row / column of a tap: oh'*a + dh, ow'*a + dw
   uint8_t wtap[kMaxTaps];                   // index r*kw + s into the packed weight
 };
 
 struct GatherParams {
   const void* in;      // [N, IH, IW, in_cstride]
-  const uint16_t* wp;  // packed bf16 [planes][OC][T][ICp]
+  const uint16_t* wp;  // packed bf16 [planes][OC][row_pitch]; a row is [tap][ICp] (+ zero tail up to row_pitch)
   void* out;           // [N, OH, OW, out_cstride]
   const float* bias;   // [OC] or null
   float* ch_sum;       // [OC] or null
   float* ch_sumsq;     // [OC] or null
   int32_t N, IH, IW, IC, ICp, OH, OW, OC, T;
+  int32_t row_pitch;   // elements per packed weight row
   int32_t a, b;        // input-coordinate multiplier, output class stride
   int32_t in_cstride, in_coff, out_cstride, out_coff;
   int32_t act;
   float slope;
   int32_t out_vec;     // 1: 16-byte (fp32) / 8-byte (bf16) stores of 4 channels are aligned
+  int32_t icp_log2;    // log2(ICp) in the thin-input mode (reduction over (tap, channel) jointly, 64 per step)
+  int32_t ksplit;      // > 1: the reduction is split over ksplit workgroups that add into a zeroed fp32 output
   int32_t n_pix_tiles, n_oc_tiles;
   int64_t plane_stride;  // elements between the hi and lo planes of wp
   TapTable tt;
 };
 
+enum GatherMode { kVecLoads = 0, kElemLoads = 1, kThinInput = 2 };
+
 struct GatherLaunch {
   int to, tp;          // tile: output channels x pixels
-  bool in_bf16, x3, aligned;
+  bool in_bf16, x3;
+  int mode;            // GatherMode
   double flops;        // algorithmic FLOPs of this launch (for the optional event timing)
 };
 
-// Chooses the tile for a problem; fills n_pix_tiles / n_oc_tiles and the class tile prefix in p.tt.
+// Packed-weight geometry for `ic` channels on the reduction side and `taps` filter taps.
+struct PackGeom {
+  int icp, row_pitch, thin;
+};
+PackGeom pack_geom(int ic, int taps, bool allow_thin);
+
+// Chooses the tile for a problem; fills n_pix_tiles / n_oc_tiles / ksplit and the class tile prefix in p.tt.
 void plan_gather(GatherParams& p, GatherLaunch& l);
 int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t stream);
 

@@ -10,6 +10,12 @@
 // Block = 256 threads = 4 waves, tile TO channels x TP pixels, reduction depth 64 per step, operands staged
 // global -> registers -> LDS (bf16, XOR-swizzled 128-byte rows, conflict-free ds_read_b128) with two LDS
 // buffers: the loads of step k+1 are in flight while step k runs on the matrix cores.
+//
+// Load modes: 16-byte vector loads (channel counts / strides that are multiples of a chunk), element loads, and a
+// thin-input mode for up to 32 input channels (RGB images, 6-channel image pairs, scores) in which the reduction
+// runs over (tap, channel) jointly -- 64 per step -- instead of padding every tap to 64 channels.
+// Small problems (few tiles, long reduction: 4x4 -> 1x1 "full window" layers) split the reduction over several
+// workgroups that add their partial tiles into a zeroed fp32 output.
 #include <stdio.h>
 
 #include "conv_gather.h"
@@ -26,8 +32,10 @@ struct TileCfg {
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <typename TIn, int TO, int TP, bool X3, bool ALIGNED>
+template <typename TIn, int TO, int TP, bool X3, int MODE>
 __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParams p) {
+  constexpr bool ALIGNED = MODE == kVecLoads;
+  constexpr bool THIN = MODE == kThinInput;
   using C = TileCfg<TO, TP>;
   constexpr int PL = X3 ? 2 : 1;
   constexpr int EPC = 16 / (int)sizeof(TIn);   // elements per 16-byte chunk of the activation
@@ -39,14 +47,17 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
   constexpr int STAGE = PL * (W_BYTES + A_BYTES);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* tap_lds = reinterpret_cast<int*>(smem + 2 * STAGE);   // thin-input mode: (dh, dw) per tap
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wo = wave / C::WP, wp_ = wave % C::WP;
 
   // ---- which tile ------------------------------------------------------------------------------------
-  const uint32_t nblocks = (uint32_t)p.n_pix_tiles * (uint32_t)p.n_oc_tiles;
-  const uint32_t lid = xcd_remap(blockIdx.x, nblocks);
+  const uint32_t nblocks = (uint32_t)p.n_pix_tiles * (uint32_t)p.n_oc_tiles * (uint32_t)p.ksplit;
+  uint32_t lid = xcd_remap(blockIdx.x, nblocks);
+  const int split = lid % p.ksplit;
+  lid /= p.ksplit;
   const int pix_tile = lid / p.n_oc_tiles;
   const int oc0 = (lid % p.n_oc_tiles) * TO;
   int cls = 0;
@@ -73,11 +84,58 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
     row_iw[i] = ow * p.a;
   }
   const TIn* in = reinterpret_cast<const TIn*>(p.in);
+  if (THIN) {
+    if (t < kMaxTaps) tap_lds[t] = ((int)p.tt.dh[t] & 0xffff) | ((int)p.tt.dw[t] << 16);
+    __syncthreads();
+  }
 
   u32x4 areg[AR][AC];
   u32x4 wreg[PL][WR];
 
+  // thin-input mode: `tap` is the reduction step; chunk ch of a row holds elements step*64 + ch*EPC .. of the
+  // joint (tap, channel) index, each aligned group of 4 belonging to one tap
+  auto load_tile_thin = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+#pragma unroll
+      for (int j = 0; j < AC; j++) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int sub = 0; sub < EPC / 4; sub++) {
+          const int kk = step * kBK + ((t & 3) + 4 * j) * EPC + sub * 4;
+          const int tapi = kk >> p.icp_log2, c = kk & (p.ICp - 1);
+          if (tapi < p.T && row_ok[i]) {
+            const int e = tap_lds[tapi];
+            const int ih = row_ih[i] + (int)(int16_t)(e & 0xffff), iw = row_iw[i] + (e >> 16);
+            if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+              const TIn* src = in + ((size_t)(row_base[i] + ih * p.IW + iw) * p.in_cstride + p.in_coff + c);
+#pragma unroll
+              for (int q = 0; q < 4; q++)
+                if (c + q < p.IC) {
+                  if (sizeof(TIn) == 4) v[q] = reinterpret_cast<const uint32_t*>(src)[q];
+                  else v[sub * 2 + (q >> 1)] |= (uint32_t)reinterpret_cast<const uint16_t*>(src)[q] << (16 * (q & 1));
+                }
+            }
+          }
+        }
+        areg[i][j] = v;
+      }
+    }
+    if (TO >= 32 || t < TO * 8) {
+#pragma unroll
+      for (int pl = 0; pl < PL; pl++)
+#pragma unroll
+        for (int i = 0; i < WR; i++) {
+          const int oc = oc0 + (t >> 3) + 32 * i;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (oc < p.OC) v = *reinterpret_cast<const u32x4*>(p.wp + pl * p.plane_stride + (size_t)oc * p.row_pitch + step * kBK + (t & 7) * 8);
+          wreg[pl][i] = v;
+        }
+    }
+  };
+
   auto load_tile = [&](int tap, int c0) {
+    if (THIN) { load_tile_thin(tap); return; }
     const int dh = p.tt.dh[tap], dw = p.tt.dw[tap], wt = p.tt.wtap[tap];
 #pragma unroll
     for (int i = 0; i < AR; i++) {
@@ -114,7 +172,7 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
           const int oc = oc0 + (t >> 3) + 32 * i;
           u32x4 v = {0u, 0u, 0u, 0u};
           if (oc < p.OC)
-            v = *reinterpret_cast<const u32x4*>(p.wp + pl * p.plane_stride + ((size_t)oc * p.T + wt) * p.ICp + c0 + (t & 7) * 8);
+            v = *reinterpret_cast<const u32x4*>(p.wp + pl * p.plane_stride + (size_t)oc * p.row_pitch + wt * p.ICp + c0 + (t & 7) * 8);
           wreg[pl][i] = v;
         }
     }
@@ -192,11 +250,14 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
   };
 
   // ---- main loop ---------------------------------------------------------------------------------------
-  const int csteps = p.ICp / kBK;
-  const int nsteps = (tap_end - tap_begin) * csteps;
-  int tap = tap_begin, cs = 0;
+  const int csteps = THIN ? 1 : p.ICp / kBK;
+  const int total_steps = THIN ? (p.T * p.ICp + kBK - 1) / kBK : (tap_end - tap_begin) * csteps;
+  const int per_split = (total_steps + p.ksplit - 1) / p.ksplit;
+  const int step0 = split * per_split;
+  const int nsteps = max(0, min(total_steps, step0 + per_split) - step0);
+  int tap = THIN ? step0 : tap_begin + step0 / csteps, cs = THIN ? 0 : step0 % csteps;
   if (nsteps > 0) {
-    load_tile(tap, 0);
+    load_tile(tap, cs * kBK);
     store_tile(0);
   }
   __syncthreads();
@@ -236,13 +297,19 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         float x = acc[i][j][r];
-        if (p.bias != nullptr && oc + r < p.OC) x += p.bias[oc + r];
+        if (p.bias != nullptr && oc + r < p.OC && split == 0) x += p.bias[oc + r];
         x = apply_act(x, p.act, p.slope);
         if (sizeof(TIn) == 2) x = bf16_bits_to_float(float_to_bf16_bits(x));
         v[r] = x;
         if (stats && mok && oc + r < p.OC) { ssum[i][r] += x; ssq[i][r] += x * x; }
       }
       if (!mok) continue;
+      if (p.ksplit > 1) {   // partial tile of a split reduction: fp32 adds into the zeroed output
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (oc + r < p.OC) atomicAdd(reinterpret_cast<float*>(dst) + oc + r, v[r]);
+        continue;
+      }
       if (vec_ok && oc + 3 < p.OC) {
         if (sizeof(TIn) == 4) {
           *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
@@ -281,27 +348,55 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
 }
 
 // ---------------------------------------------------------------------------------------------------------
+PackGeom pack_geom(int ic, int taps, bool allow_thin) {
+  PackGeom g;
+  if (allow_thin && ic <= 32) {
+    g.icp = 4;
+    while (g.icp < ic) g.icp *= 2;
+    g.row_pitch = (taps * g.icp + kBK - 1) / kBK * kBK;
+    g.thin = 1;
+  } else {
+    g.icp = (ic + kBK - 1) / kBK * kBK;
+    g.row_pitch = taps * g.icp;
+    g.thin = 0;
+  }
+  return g;
+}
+
 void plan_gather(GatherParams& p, GatherLaunch& l) {
   // Channel tile: the smallest of {16, 64, 128} covering OC (128 when OC > 64); pixel tile 128, or 256 for the
   // 16-channel tile (thin outputs such as RGB images or critic scores).
   l.to = p.OC <= 16 ? 16 : (p.OC <= 64 ? 64 : 128);
   l.tp = l.to == 16 ? 256 : 128;
   p.n_oc_tiles = (p.OC + l.to - 1) / l.to;
-  int tiles = 0;
+  int tiles = 0, min_steps = 1 << 30;
   for (int c = 0; c < p.tt.n_classes; c++) {
     p.tt.cls_tile_start[c] = tiles;
     const long mc = (long)p.N * p.tt.cls_oh[c] * p.tt.cls_ow[c];
     tiles += (int)((mc + l.tp - 1) / l.tp);
+    const int steps = l.mode == kThinInput ? (p.T * p.ICp + kBK - 1) / kBK
+                                           : (p.tt.cls_tap_start[c + 1] - p.tt.cls_tap_start[c]) * (p.ICp / kBK);
+    if (steps < min_steps) min_steps = steps;
   }
   for (int c = p.tt.n_classes; c <= kMaxClasses; c++) p.tt.cls_tile_start[c] = tiles;
   p.n_pix_tiles = tiles;
+  // Split the reduction when the grid cannot fill the chip and the output can take fp32 adds.
+  p.ksplit = 1;
+  const long blocks = (long)tiles * p.n_oc_tiles;
+  const bool can_split = !l.in_bf16 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
+  if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16) {
+    long want = (256 + blocks - 1) / blocks;
+    if (want > min_steps / 8) want = min_steps / 8;
+    if (want > 32) want = 32;
+    if (want > 1) p.ksplit = (int)want;
+  }
 }
 
-template <typename TIn, int TO, int TP, bool X3, bool ALIGNED>
+template <typename TIn, int TO, int TP, bool X3, int MODE>
 static int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int PL = X3 ? 2 : 1;
-  constexpr int smem = 2 * PL * (TO + TP) * 128;
-  auto kern = conv_gather_kernel<TIn, TO, TP, X3, ALIGNED>;
+  constexpr int smem = 2 * PL * (TO + TP) * 128 + kMaxTaps * 4;
+  auto kern = conv_gather_kernel<TIn, TO, TP, X3, MODE>;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
     if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
@@ -309,29 +404,37 @@ static int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
       return GC_HIP_ERROR;
     attr_set = true;
   }
-  const unsigned nblocks = (unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles;
+  if (p.ksplit > 1) {
+    const size_t bytes = (size_t)p.N * p.OH * p.OW * p.OC * sizeof(float);
+    if (check_hip(hipMemsetAsync(p.out, 0, bytes, stream), "hipMemsetAsync")) return GC_HIP_ERROR;
+  }
+  const unsigned nblocks = (unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles * (unsigned)p.ksplit;
   char name[64];  // the demangled kernel name as a profiler prints it
-  snprintf(name, sizeof(name), "gc::conv_gather_kernel<%s, %d, %d, %s, %s>", sizeof(TIn) == 4 ? "float" : "unsigned short", TO, TP,
-           X3 ? "true" : "false", ALIGNED ? "true" : "false");
+  snprintf(name, sizeof(name), "gc::conv_gather_kernel<%s, %d, %d, %s, %d>", sizeof(TIn) == 4 ? "float" : "unsigned short", TO, TP,
+           X3 ? "true" : "false", MODE);
   ProfScope ps(name, flops, stream);
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kThreads), smem, stream, p);
   return check_hip(hipGetLastError(), "conv_gather launch");
 }
 
-template <typename TIn, bool X3, bool ALIGNED>
+template <typename TIn, bool X3, int MODE>
 static int launch_tile(const GatherParams& p, const GatherLaunch& l, hipStream_t s) {
-  if (l.to == 128) return launch_one<TIn, 128, 128, X3, ALIGNED>(p, l.flops, s);
-  if (l.to == 64) return launch_one<TIn, 64, 128, X3, ALIGNED>(p, l.flops, s);
-  return launch_one<TIn, 16, 256, X3, ALIGNED>(p, l.flops, s);
+  if (l.to == 128) return launch_one<TIn, 128, 128, X3, MODE>(p, l.flops, s);
+  if (l.to == 64) return launch_one<TIn, 64, 128, X3, MODE>(p, l.flops, s);
+  return launch_one<TIn, 16, 256, X3, MODE>(p, l.flops, s);
+}
+
+template <typename TIn, bool X3>
+static int launch_mode(const GatherParams& p, const GatherLaunch& l, hipStream_t s) {
+  if (l.mode == kVecLoads) return launch_tile<TIn, X3, kVecLoads>(p, l, s);
+  if (l.mode == kElemLoads) return launch_tile<TIn, X3, kElemLoads>(p, l, s);
+  return launch_tile<TIn, X3, kThinInput>(p, l, s);
 }
 
 int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t s) {
   if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
-  if (l.in_bf16) {
-    return l.aligned ? launch_tile<uint16_t, false, true>(p, l, s) : launch_tile<uint16_t, false, false>(p, l, s);
-  }
-  if (l.x3) return l.aligned ? launch_tile<float, true, true>(p, l, s) : launch_tile<float, true, false>(p, l, s);
-  return l.aligned ? launch_tile<float, false, true>(p, l, s) : launch_tile<float, false, false>(p, l, s);
+  if (l.in_bf16) return launch_mode<uint16_t, false>(p, l, s);
+  return l.x3 ? launch_mode<float, true>(p, l, s) : launch_mode<float, false>(p, l, s);
 }
 
 }  // namespace gc

@@ -13,6 +13,8 @@ struct WgradParams {
   int32_t K;             // N*Ho*Wo: length of the reduction
   int32_t k_per_split;   // multiple of the reduction step
   int32_t n_co_tiles, n_ci_tiles, splits;
+  int32_t thin;          // 1: Cin <= 32; the tile's columns run over (tap, channel) jointly, channel padded to ICp
+  int32_t ICp, icp_log2, ncols;   // thin mode: padded channels per tap, its log2, T * ICp
   FastDiv div_wo, div_ho;
 };
 
@@ -29,6 +31,7 @@ struct WgradReduceParams {
   int32_t Cout, Cin, kh, kw, splits;
   float alpha;
   int32_t accumulate;
+  int32_t thin, ICp;     // layout of part: [split][tap][Cout][Cin], or thin: [split][Cout][tap][ICp]
 };
 
 void plan_wgrad(WgradParams& p, WgradLaunch& l);

@@ -22,7 +22,9 @@ __device__ __forceinline__ int wswz(int k) {
   return ROWB == 256 ? ((k & 3) | (((k >> 3) & 1) << 2)) : (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
 }
 
-template <typename T, int TO, int TC, bool X3, bool ALIGNED>
+// THIN: up to 32 input channels (RGB images ...): one tile's columns cover (tap, channel) pairs, so a 3-channel 4x4
+// filter is one 64-column tile instead of sixteen 97 %-empty ones.
+template <typename T, int TO, int TC, bool X3, bool ALIGNED, bool THIN>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int PL = X3 ? 2 : 1;
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
   const int wo = wave >> 1, wc = wave & 1;
   const int tile = blockIdx.x;
   const int co0 = (tile / p.n_ci_tiles) * TO, ci0 = (tile % p.n_ci_tiles) * TC;
-  const int tap = blockIdx.y, r = tap / p.kw, s = tap % p.kw;
+  const int tap = THIN ? 0 : blockIdx.y, r = tap / p.kw, s = tap % p.kw;
   const int split = blockIdx.z;
   const int kb0 = split * p.k_per_split;
   const int kend = min(p.K, kb0 + p.k_per_split);
@@ -50,6 +52,19 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
   const int cy = t % CPRY, cx = t % CPRX;
 
   u32x4 yreg[PY], xreg[PX];
+
+  // thin mode: this thread's chunk of columns is fixed, so the (tap, channel) of each group of 4 columns is too
+  int thin_r[EPC / 4], thin_s[EPC / 4], thin_c[EPC / 4];
+  if (THIN) {
+#pragma unroll
+    for (int sub = 0; sub < EPC / 4; sub++) {
+      const int col = ci0 + cx * EPC + sub * 4;
+      const int tp = col >> p.icp_log2;
+      thin_c[sub] = col & (p.ICp - 1);
+      thin_r[sub] = tp < p.kh * p.kw ? tp / p.kw : -100000;   // out of range -> never valid
+      thin_s[sub] = tp % p.kw;
+    }
+  }
 
   auto load_chunk = [&](const T* src, int c_first, int c_limit, bool ok) -> u32x4 {
     u32x4 v = {0u, 0u, 0u, 0u};
@@ -84,6 +99,24 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
       const int wo_ = (int)(kk - q1 * p.div_wo.d);
       const uint32_t n = fd_div(q1, p.div_ho);
       const int ho_ = (int)(q1 - n * p.div_ho.d);
+      if (THIN) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int sub = 0; sub < EPC / 4; sub++) {
+          const int ih = ho_ * p.sh - p.ph + thin_r[sub], iw = wo_ * p.sw - p.pw + thin_s[sub];
+          if (k < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+            const T* src = x + (((size_t)n * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff + thin_c[sub];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (thin_c[sub] + q < p.Cin) {
+                if (sizeof(T) == 4) v[q] = reinterpret_cast<const uint32_t*>(src)[q];
+                else v[sub * 2 + (q >> 1)] |= (uint32_t)reinterpret_cast<const uint16_t*>(src)[q] << (16 * (q & 1));
+              }
+          }
+        }
+        xreg[i] = v;
+        continue;
+      }
       const int ih = ho_ * p.sh - p.ph + r, iw = wo_ * p.sw - p.pw + s;
       const bool ok = k < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       const int c = ci0 + cx * EPC;
@@ -173,7 +206,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
     __syncthreads();
   }
 
-  float* part = p.part + ((size_t)split * (p.kh * p.kw) + tap) * p.Cout * p.Cin;
+  const int ncols = THIN ? p.ncols : p.Cin;
+  float* part = THIN ? p.part + (size_t)split * p.Cout * ncols : p.part + ((size_t)split * (p.kh * p.kw) + tap) * p.Cout * p.Cin;
 #pragma unroll
   for (int i = 0; i < FO; i++)
 #pragma unroll
@@ -182,24 +216,41 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int co = co0 + wo * (TO / 2) + i * 16 + (lane >> 4) * 4 + e;
-        if (co < p.Cout && ci < p.Cin) part[(size_t)co * p.Cin + ci] = acc[i][j][e];
+        if (co < p.Cout && ci < ncols) part[(size_t)co * ncols + ci] = acc[i][j][e];
       }
     }
 }
 
+// Sums the split-K partials in a fixed order, scales and scatters into the caller's weight-gradient layout.
+// Workgroup = 64 consecutive partial elements x 4 split lanes (reads coalesced along the partial layout).
 __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const WgradReduceParams p) {
-  const size_t per_tap = (size_t)p.Cout * p.Cin;
-  const size_t total = per_tap * p.kh * p.kw;
-  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
-    float sum = 0.f;
-    for (int sp = 0; sp < p.splits; sp++) sum += p.part[(size_t)sp * total + e];
-    const int tap = (int)(e / per_tap);
-    const size_t rem = e - (size_t)tap * per_tap;
-    const int co = (int)(rem / p.Cin), ci = (int)(rem - (size_t)co * p.Cin);
-    float* dst = p.gw + co * p.s_co + ci * p.s_ci + (tap / p.kw) * p.s_r + (tap % p.kw) * p.s_s;
-    const float v = p.alpha * sum;
-    *dst = p.accumulate ? *dst + v : v;
+  __shared__ float red[kThreads];
+  const int T = p.kh * p.kw;
+  const int inner = p.thin ? p.ICp : p.Cin;
+  const size_t total = (size_t)T * p.Cout * inner;      // elements of one partial slab
+  const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
+  float sum = 0.f;
+  if (e < total)
+    for (int sp = sl; sp < p.splits; sp += 4) sum += p.part[(size_t)sp * total + e];
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (sl != 0 || e >= total) return;
+  sum = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192];
+  int co, ci, tap;
+  if (p.thin) {          // [Cout][tap][ICp]
+    ci = (int)(e % p.ICp);
+    tap = (int)((e / p.ICp) % T);
+    co = (int)(e / ((size_t)p.ICp * T));
+    if (ci >= p.Cin) return;
+  } else {               // [tap][Cout][Cin]
+    ci = (int)(e % p.Cin);
+    co = (int)((e / p.Cin) % p.Cout);
+    tap = (int)(e / ((size_t)p.Cin * p.Cout));
   }
+  float* dst = p.gw + co * p.s_co + ci * p.s_ci + (tap / p.kw) * p.s_r + (tap % p.kw) * p.s_s;
+  const float v = p.alpha * sum;
+  *dst = p.accumulate ? *dst + v : v;
 }
 
 // gb[c] += sum over pixels of gy[k][c]; gb is zeroed by the launcher.  One block sums a run of pixels.
@@ -232,40 +283,56 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(const T* gy, float* gb
 // ---------------------------------------------------------------------------------------------------------
 void plan_wgrad(WgradParams& p, WgradLaunch& l) {
   l.to = p.Cout <= 64 ? 64 : 128;
-  l.tc = p.Cin <= 64 ? 64 : 128;
+  p.thin = p.Cin <= 32;
+  if (p.thin) {
+    p.ICp = 4;
+    while (p.ICp < p.Cin) p.ICp *= 2;
+    for (p.icp_log2 = 0; (1 << p.icp_log2) < p.ICp; p.icp_log2++) {}
+    p.ncols = p.kh * p.kw * p.ICp;
+    l.tc = p.ncols <= 64 ? 64 : 128;
+    p.n_ci_tiles = (p.ncols + l.tc - 1) / l.tc;
+  } else {
+    l.tc = p.Cin <= 64 ? 64 : 128;
+    p.n_ci_tiles = (p.Cin + l.tc - 1) / l.tc;
+  }
   p.n_co_tiles = (p.Cout + l.to - 1) / l.to;
-  p.n_ci_tiles = (p.Cin + l.tc - 1) / l.tc;
-  const long tiles = (long)p.n_co_tiles * p.n_ci_tiles * p.kh * p.kw;
+  const long tiles = (long)p.n_co_tiles * p.n_ci_tiles * (p.thin ? 1 : p.kh * p.kw);
   if (p.K <= 0) { p.k_per_split = kWBK; p.splits = 1; return; }
-  // enough splits for about four workgroups per CU, each split at least 8 reduction steps long
-  long want = (4 * 256 + tiles - 1) / tiles;
+  // enough splits for about two workgroups per CU, each split at least 8 reduction steps long
+  long want = (2 * 256 + tiles - 1) / tiles;
   const long max_splits = (p.K + 8 * kWBK - 1) / (8 * kWBK);
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
-  if (want > 64) want = 64;
+  if (want > 512) want = 512;
   long kps = (p.K + want - 1) / want;
   kps = (kps + kWBK - 1) / kWBK * kWBK;
   p.k_per_split = (int)kps;
   p.splits = (int)((p.K + kps - 1) / kps);
 }
 
-template <typename T, int TO, int TC, bool X3, bool ALIGNED>
+template <typename T, int TO, int TC, bool X3, bool ALIGNED, bool THIN>
 static int launch_one(const WgradParams& p, double flops, hipStream_t stream) {
   char name[64];
-  snprintf(name, sizeof(name), "gc::conv_wgrad_kernel<%s, %d, %d, %s, %s>", sizeof(T) == 4 ? "float" : "unsigned short", TO, TC,
-           X3 ? "true" : "false", ALIGNED ? "true" : "false");
+  snprintf(name, sizeof(name), "gc::conv_wgrad_kernel<%s, %d, %d, %s, %s, %s>", sizeof(T) == 4 ? "float" : "unsigned short", TO, TC,
+           X3 ? "true" : "false", ALIGNED ? "true" : "false", THIN ? "true" : "false");
   ProfScope ps(name, flops, stream);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, TO, TC, X3, ALIGNED>),
-                     dim3(p.n_co_tiles * p.n_ci_tiles, p.kh * p.kw, p.splits), dim3(kThreads), 0, stream, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TO, TC, X3, ALIGNED, THIN>),
+                     dim3(p.n_co_tiles * p.n_ci_tiles, THIN ? 1 : p.kh * p.kw, p.splits), dim3(kThreads), 0, stream, p);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
 }
 
 template <typename T, bool X3, bool ALIGNED>
 static int launch_tile(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
-  if (l.to == 128 && l.tc == 128) return launch_one<T, 128, 128, X3, ALIGNED>(p, l.flops, s);
-  if (l.to == 128 && l.tc == 64) return launch_one<T, 128, 64, X3, ALIGNED>(p, l.flops, s);
-  if (l.to == 64 && l.tc == 128) return launch_one<T, 64, 128, X3, ALIGNED>(p, l.flops, s);
-  return launch_one<T, 64, 64, X3, ALIGNED>(p, l.flops, s);
+  if (p.thin) {   // the gy side decides ALIGNED here; the thin x side always uses element loads
+    if (l.to == 128 && l.tc == 128) return launch_one<T, 128, 128, X3, ALIGNED, true>(p, l.flops, s);
+    if (l.to == 128 && l.tc == 64) return launch_one<T, 128, 64, X3, ALIGNED, true>(p, l.flops, s);
+    if (l.to == 64 && l.tc == 128) return launch_one<T, 64, 128, X3, ALIGNED, true>(p, l.flops, s);
+    return launch_one<T, 64, 64, X3, ALIGNED, true>(p, l.flops, s);
+  }
+  if (l.to == 128 && l.tc == 128) return launch_one<T, 128, 128, X3, ALIGNED, false>(p, l.flops, s);
+  if (l.to == 128 && l.tc == 64) return launch_one<T, 128, 64, X3, ALIGNED, false>(p, l.flops, s);
+  if (l.to == 64 && l.tc == 128) return launch_one<T, 64, 128, X3, ALIGNED, false>(p, l.flops, s);
+  return launch_one<T, 64, 64, X3, ALIGNED, false>(p, l.flops, s);
 }
 
 int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
@@ -276,10 +343,9 @@ int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
 }
 
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
-  const size_t total = (size_t)p.Cout * p.Cin * p.kh * p.kw;
+  const size_t total = (size_t)p.Cout * (p.thin ? p.ICp : p.Cin) * p.kh * p.kw;
   if (total == 0) return GC_OK;
-  size_t blocks = (total + kThreads - 1) / kThreads;
-  if (blocks > 2048) blocks = 2048;
+  const size_t blocks = (total + 63) / 64;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
   return check_hip(hipGetLastError(), "wgrad_reduce launch");
 }

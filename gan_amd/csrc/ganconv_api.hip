@@ -55,19 +55,19 @@ ProfScope::~ProfScope() {
 }
 
 // ---- weight repack -------------------------------------------------------------------------------------
-// dst[plane][row][tap][col] (bf16, col padded with zeros to colp) from fp32 w[co][ci][r][s] with strides.
-// transpose == 0: row = co, col = ci (forward image); transpose == 1: row = ci, col = co (data-gradient image).
+// dst[plane][row][pitch] (bf16), a row being [tap][colp] followed by zeros up to `pitch`, from fp32 w[co][ci][r][s]
+// with strides.  transpose == 0: row = co, col = ci (forward image); transpose == 1: row = ci, col = co
+// (data-gradient image).
 __global__ __launch_bounds__(kThreads) void pack_weight_kernel(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_s,
-                                                                uint16_t* dst, int rows, int cols, int colp, int kh, int kw,
+                                                                uint16_t* dst, int rows, int cols, int colp, int pitch, int kh, int kw,
                                                                 int transpose, int planes, float alpha) {
-  const size_t total = (size_t)rows * kh * kw * colp;
+  const size_t total = (size_t)rows * pitch;
   for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
-    const int col = (int)(e % colp);
-    size_t q = e / colp;
-    const int tap = (int)(q % (kh * kw));
-    const int row = (int)(q / (kh * kw));
+    const int k = (int)(e % pitch);
+    const int row = (int)(e / pitch);
+    const int col = k % colp, tap = k / colp;
     float v = 0.f;
-    if (col < cols) {
+    if (col < cols && tap < kh * kw) {
       const int co = transpose ? col : row, ci = transpose ? row : col;
       v = alpha * w[co * s_co + ci * s_ci + (tap / kw) * s_r + (tap % kw) * s_s];
     }
@@ -138,7 +138,8 @@ static int validate(const gc_conv_desc* d) {
   if (d->x_dtype != d->y_dtype) { set_error("mixed activation dtypes are not supported"); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->precision == GC_PREC_F32X3 && d->x_dtype != GC_F32) { set_error("GC_PREC_F32X3 needs fp32 activations"); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->kh * d->kw > kMaxTaps) { set_error("filters larger than %d taps are not supported", kMaxTaps); return GC_UNSUPPORTED_GEOMETRY; }
-  if (d->stride_h * d->stride_w > kMaxClasses) { set_error("stride %dx%d is not supported", d->stride_h, d->stride_w); return GC_UNSUPPORTED_GEOMETRY; }
+  if (d->stride_h * d->stride_w > 4) { set_error("stride %dx%d is not supported", d->stride_h, d->stride_w); return GC_UNSUPPORTED_GEOMETRY; }
+  if (d->H >= 32768 || d->W >= 32768) { set_error("spatial extent too large"); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->kh > 127 || d->kw > 127 || d->pad_h > 127 || d->pad_w > 127) { set_error("filter or padding too large"); return GC_UNSUPPORTED_GEOMETRY; }
   if ((long)d->N * d->H * d->W >= (1l << 31) || (long)d->N * d->Ho * d->Wo >= (1l << 31)) { set_error("more than 2^31 pixels"); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->x_cstride != 0 && d->x_cstride < d->x_coff + d->Cin) { set_error("x channel slice exceeds x_cstride"); return GC_BAD_DESC; }
@@ -173,6 +174,21 @@ static int check_epilogue(const gc_epilogue* ep) {
   return GC_OK;
 }
 
+// The data gradient of a conv whose window covers its whole (unpadded) input -- one output pixel per sample, e.g.
+// the 4x4 -> 1x1 layers at both ends of the DCGAN nets -- does not depend on the stride.  Treating the stride as the
+// filter size gives every input pixel its own class with exactly one tap instead of kh*kw mostly-masked ones.
+static int dgrad_class_stride(const gc_conv_desc* d) {
+  if (d->Ho == 1 && d->Wo == 1 && d->pad_h == 0 && d->pad_w == 0 && d->H == d->kh && d->W == d->kw && d->kh == d->kw &&
+      d->kh * d->kw <= kMaxClasses)
+    return d->kh;
+  return d->stride_h;
+}
+
+static PackGeom geom_for(const gc_conv_desc* d, int pass) {
+  if (pass == GC_PASS_FPROP) return pack_geom(d->Cin, d->kh * d->kw, true);
+  return pack_geom(d->Cout, d->kh * d->kw, dgrad_class_stride(d) == 1);
+}
+
 }  // namespace gc
 
 using namespace gc;
@@ -186,11 +202,12 @@ const char* gc_last_error(void) { return g_err; }
 size_t gc_packed_weight_bytes(const gc_conv_desc* d, int pass) {
   if (validate(d) != GC_OK) return 0;
   const int planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
-  const size_t taps = (size_t)d->kh * d->kw;
-  if (pass == GC_PASS_FPROP) return (size_t)planes * d->Cout * taps * round_up(d->Cin, kBK) * 2;
-  if (pass == GC_PASS_DGRAD) return (size_t)planes * d->Cin * taps * round_up(d->Cout, kBK) * 2;
-  set_error("gc_packed_weight_bytes: pass must be GC_PASS_FPROP or GC_PASS_DGRAD");
-  return 0;
+  if (pass != GC_PASS_FPROP && pass != GC_PASS_DGRAD) {
+    set_error("gc_packed_weight_bytes: pass must be GC_PASS_FPROP or GC_PASS_DGRAD");
+    return 0;
+  }
+  const PackGeom g = geom_for(d, pass);
+  return (size_t)planes * (pass == GC_PASS_FPROP ? d->Cout : d->Cin) * g.row_pitch * 2;
 }
 
 int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_t w_strides[4], float alpha, void* packed,
@@ -202,14 +219,15 @@ int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_
   if (!aligned16(packed)) { set_error("gc_pack_weight: packed buffer must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
   const int transpose = pass == GC_PASS_DGRAD;
   const int rows = transpose ? d->Cin : d->Cout, cols = transpose ? d->Cout : d->Cin;
-  const int colp = round_up(cols, kBK);
+  const PackGeom g = geom_for(d, pass);
+  const int colp = g.icp;
   const int planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
-  const size_t total = (size_t)rows * d->kh * d->kw * colp;
+  const size_t total = (size_t)rows * g.row_pitch;
   size_t blocks = (total + kThreads - 1) / kThreads;
   if (blocks > 4096) blocks = 4096;
   ProfScope ps("gc::pack_weight_kernel", 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, w, w_strides[0], w_strides[1],
-                     w_strides[2], w_strides[3], (uint16_t*)packed, rows, cols, colp, d->kh, d->kw, transpose, planes, alpha);
+                     w_strides[2], w_strides[3], (uint16_t*)packed, rows, cols, colp, g.row_pitch, d->kh, d->kw, transpose, planes, alpha);
   return check_hip(hipGetLastError(), "pack_weight launch");
 }
 
@@ -224,16 +242,17 @@ int gc_conv2d_fprop(const gc_conv_desc* d, const void* x, const void* packed_w, 
   memset(&p, 0, sizeof(p));
   p.in = x; p.wp = (const uint16_t*)packed_w; p.out = y;
   fill_epilogue(p, ep);
-  p.N = d->N; p.IH = d->H; p.IW = d->W; p.IC = d->Cin; p.ICp = round_up(d->Cin, kBK);
+  const PackGeom g = geom_for(d, GC_PASS_FPROP);
+  p.N = d->N; p.IH = d->H; p.IW = d->W; p.IC = d->Cin; p.ICp = g.icp; p.row_pitch = g.row_pitch;
   p.OH = d->Ho; p.OW = d->Wo; p.OC = d->Cout; p.T = d->kh * d->kw;
   p.a = d->stride_h; p.b = 1;
   if (d->stride_h != d->stride_w) { set_error("anisotropic stride is not supported"); return GC_UNSUPPORTED_GEOMETRY; }
   p.in_cstride = x_cs(d); p.in_coff = d->x_coff; p.out_cstride = y_cs(d); p.out_coff = d->y_coff;
-  p.plane_stride = (int64_t)d->Cout * p.T * p.ICp;
+  p.plane_stride = (int64_t)d->Cout * g.row_pitch;
   p.tt.n_classes = 1;
   p.tt.cls_tap_start[0] = 0;
   for (int c = 1; c <= kMaxClasses; c++) p.tt.cls_tap_start[c] = p.T;
-  p.tt.cls_ph[0] = p.tt.cls_pw[0] = 0; p.tt.cls_oh[0] = d->Ho; p.tt.cls_ow[0] = d->Wo;
+  p.tt.cls_ph[0] = p.tt.cls_pw[0] = 0; p.tt.cls_oh[0] = (int16_t)d->Ho; p.tt.cls_ow[0] = (int16_t)d->Wo;
   for (int r = 0; r < d->kh; r++)
     for (int s = 0; s < d->kw; s++) {
       const int i = r * d->kw + s;
@@ -242,7 +261,9 @@ int gc_conv2d_fprop(const gc_conv_desc* d, const void* x, const void* packed_w, 
   GatherLaunch l;
   l.in_bf16 = d->x_dtype == GC_BF16; l.x3 = d->precision == GC_PREC_F32X3;
   const int epc = elems_per_chunk(d->x_dtype);
-  l.aligned = aligned16(x) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
+  const bool vec = aligned16(x) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
+  l.mode = g.thin ? kThinInput : (vec ? kVecLoads : kElemLoads);
+  for (p.icp_log2 = 0; (1 << p.icp_log2) < g.icp; p.icp_log2++) {}
   p.out_vec = (reinterpret_cast<uintptr_t>(y) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
   plan_gather(p, l);
   l.flops = conv_flops(d);
@@ -257,16 +278,17 @@ int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w,
   if (gy == nullptr || packed_w == nullptr || gx == nullptr) { set_error("gc_conv2d_dgrad: null pointer"); return GC_BAD_ARGUMENT; }
   if (!aligned16(packed_w)) { set_error("gc_conv2d_dgrad: packed weights must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
   if (d->stride_h != d->stride_w) { set_error("anisotropic stride is not supported"); return GC_UNSUPPORTED_GEOMETRY; }
-  const int b = d->stride_h;
+  const int b = dgrad_class_stride(d);
+  const PackGeom g = geom_for(d, GC_PASS_DGRAD);
   GatherParams p;
   memset(&p, 0, sizeof(p));
   p.in = gy; p.wp = (const uint16_t*)packed_w; p.out = gx;
   fill_epilogue(p, ep);
-  p.N = d->N; p.IH = d->Ho; p.IW = d->Wo; p.IC = d->Cout; p.ICp = round_up(d->Cout, kBK);
+  p.N = d->N; p.IH = d->Ho; p.IW = d->Wo; p.IC = d->Cout; p.ICp = g.icp; p.row_pitch = g.row_pitch;
   p.OH = d->H; p.OW = d->W; p.OC = d->Cin; p.T = d->kh * d->kw;
   p.a = 1; p.b = b;
   p.in_cstride = y_cs(d); p.in_coff = d->y_coff; p.out_cstride = x_cs(d); p.out_coff = d->x_coff;
-  p.plane_stride = (int64_t)d->Cin * p.T * p.ICp;
+  p.plane_stride = (int64_t)d->Cin * g.row_pitch;
   // x pixel (h, w) receives gy[(h + pad - r)/b, (w + pad - s)/b] * w[r][s] for every tap with an exact quotient:
   // class (ph, pw) = (h mod b, w mod b) sees the taps r = (ph + pad) mod b, +b, ... at the fixed offset
   // dh = (ph + pad - r)/b from the class-local row h' = h / b.
@@ -276,8 +298,8 @@ int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w,
     for (int pw = 0; pw < b; pw++) {
       const int c = ph * b + pw;
       p.tt.cls_tap_start[c] = e;
-      p.tt.cls_ph[c] = ph; p.tt.cls_pw[c] = pw;
-      p.tt.cls_oh[c] = (d->H - ph + b - 1) / b; p.tt.cls_ow[c] = (d->W - pw + b - 1) / b;
+      p.tt.cls_ph[c] = (int8_t)ph; p.tt.cls_pw[c] = (int8_t)pw;
+      p.tt.cls_oh[c] = (int16_t)((d->H - ph + b - 1) / b); p.tt.cls_ow[c] = (int16_t)((d->W - pw + b - 1) / b);
       for (int r = (ph + d->pad_h) % b; r < d->kh; r += b)
         for (int s = (pw + d->pad_w) % b; s < d->kw; s += b) {
           const int dh = (ph + d->pad_h - r) / b, dw = (pw + d->pad_w - s) / b;  // exact; may be negative
@@ -289,7 +311,9 @@ int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w,
   GatherLaunch l;
   l.in_bf16 = d->y_dtype == GC_BF16; l.x3 = d->precision == GC_PREC_F32X3;
   const int epc = elems_per_chunk(d->y_dtype);
-  l.aligned = aligned16(gy) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
+  const bool vec = aligned16(gy) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
+  l.mode = g.thin ? kThinInput : (vec ? kVecLoads : kElemLoads);
+  for (p.icp_log2 = 0; (1 << p.icp_log2) < g.icp; p.icp_log2++) {}
   p.out_vec = (reinterpret_cast<uintptr_t>(gx) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
   plan_gather(p, l);
   l.flops = conv_flops(d);
@@ -311,7 +335,7 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
   if (validate(d) != GC_OK) return 0;
   WgradParams p; WgradLaunch l;
   wgrad_setup(d, p, l);
-  return (size_t)p.splits * d->kh * d->kw * d->Cout * d->Cin * sizeof(float);
+  return (size_t)p.splits * d->kh * d->kw * d->Cout * (p.thin ? p.ICp : d->Cin) * sizeof(float);
 }
 
 int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float* gw, const int64_t gw_strides[4], float alpha,
@@ -321,7 +345,7 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   if (x == nullptr || gy == nullptr || gw == nullptr || gw_strides == nullptr) { set_error("gc_conv2d_wgrad: null pointer"); return GC_BAD_ARGUMENT; }
   WgradParams p; WgradLaunch l;
   wgrad_setup(d, p, l);
-  const size_t need = (size_t)p.splits * d->kh * d->kw * d->Cout * d->Cin * sizeof(float);
+  const size_t need = (size_t)p.splits * d->kh * d->kw * d->Cout * (p.thin ? p.ICp : d->Cin) * sizeof(float);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("gc_conv2d_wgrad: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
     return GC_WORKSPACE_TOO_SMALL;
@@ -329,15 +353,16 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   if (!aligned16(workspace)) { set_error("gc_conv2d_wgrad: workspace must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
   p.x = x; p.gy = gy; p.part = (float*)workspace;
   const int epc = elems_per_chunk(d->x_dtype);
-  l.aligned = aligned16(x) && aligned16(gy) && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0) &&
-              (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
+  const bool x_vec = aligned16(x) && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0);
+  const bool y_vec = aligned16(gy) && (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
+  l.aligned = y_vec && (p.thin || x_vec);
   l.flops = conv_flops(d);
   if ((rc = launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
   WgradReduceParams r;
   r.part = p.part; r.gw = gw;
   r.s_co = gw_strides[0]; r.s_ci = gw_strides[1]; r.s_r = gw_strides[2]; r.s_s = gw_strides[3];
   r.Cout = d->Cout; r.Cin = d->Cin; r.kh = d->kh; r.kw = d->kw; r.splits = d->N == 0 ? 0 : p.splits;
-  r.alpha = alpha; r.accumulate = accumulate;
+  r.alpha = alpha; r.accumulate = accumulate; r.thin = p.thin; r.ICp = p.ICp;
   {
     ProfScope ps("gc::wgrad_reduce_kernel", 0.0, (hipStream_t)stream);
     if ((rc = launch_wgrad_reduce(r, (hipStream_t)stream)) != GC_OK) return rc;

@@ -36,11 +36,13 @@ def _desc(**kw):
 def test_sizes_and_descriptor_validation():
     L = _lib.lib()
     d = _desc()
-    # forward image: [Cout][16 taps][Cin padded to 64] bf16
-    assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == 16 * 16 * 64 * 2
+    # forward image, thin input (Cin <= 32): [Cout][16 taps x 8 channels] bf16; wide input: [Cout][16 taps][Cin padded to 64]
+    assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == 16 * 16 * 8 * 2
+    assert L.gc_packed_weight_bytes(ctypes.byref(_desc(Cin=72)), _lib.GC_PASS_FPROP) == 16 * 16 * 128 * 2
+    # data-gradient image of a stride-2 conv: [Cin][16 taps][Cout padded to 64]
     assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_DGRAD) == 8 * 16 * 64 * 2
     d.precision = _lib.GC_PREC_F32X3
-    assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == 2 * 16 * 16 * 64 * 2
+    assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == 2 * 16 * 16 * 8 * 2
     assert L.gc_wgrad_workspace_bytes(ctypes.byref(d)) % (16 * 16 * 8 * 4) == 0 and L.gc_wgrad_workspace_bytes(ctypes.byref(d)) > 0
     bad = _desc(Ho=9)
     assert L.gc_packed_weight_bytes(ctypes.byref(bad), _lib.GC_PASS_FPROP) == 0
