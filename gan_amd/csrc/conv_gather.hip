@@ -89,12 +89,14 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
     __syncthreads();
   }
 
-  u32x4 areg[AR][AC];
-  u32x4 wreg[PL][WR];
+  struct Regs {
+    u32x4 a[AR][AC];
+    u32x4 w[PL][WR];
+  };
 
   // thin-input mode: `tap` is the reduction step; chunk ch of a row holds elements step*64 + ch*EPC .. of the
   // joint (tap, channel) index, each aligned group of 4 belonging to one tap
-  auto load_tile_thin = [&](int step) {
+  auto load_tile_thin = [&](Regs& R, int step) {
 #pragma unroll
     for (int i = 0; i < AR; i++) {
 #pragma unroll
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
             }
           }
         }
-        areg[i][j] = v;
+        R.a[i][j] = v;
       }
     }
     if (TO >= 32 || t < TO * 8) {
@@ -129,13 +131,13 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
           const int oc = oc0 + (t >> 3) + 32 * i;
           u32x4 v = {0u, 0u, 0u, 0u};
           if (oc < p.OC) v = *reinterpret_cast<const u32x4*>(p.wp + pl * p.plane_stride + (size_t)oc * p.row_pitch + step * kBK + (t & 7) * 8);
-          wreg[pl][i] = v;
+          R.w[pl][i] = v;
         }
     }
   };
 
-  auto load_tile = [&](int tap, int c0) {
-    if (THIN) { load_tile_thin(tap); return; }
+  auto load_tile = [&](Regs& R, int tap, int c0) {
+    if (THIN) { load_tile_thin(R, tap); return; }
     const int dh = p.tt.dh[tap], dw = p.tt.dw[tap], wt = p.tt.wtap[tap];
 #pragma unroll
     for (int i = 0; i < AR; i++) {
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
             }
           }
         }
-        areg[i][j] = v;
+        R.a[i][j] = v;
       }
     }
     if (TO >= 32 || t < TO * 8) {
@@ -173,12 +175,12 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
           u32x4 v = {0u, 0u, 0u, 0u};
           if (oc < p.OC)
             v = *reinterpret_cast<const u32x4*>(p.wp + pl * p.plane_stride + (size_t)oc * p.row_pitch + wt * p.ICp + c0 + (t & 7) * 8);
-          wreg[pl][i] = v;
+          R.w[pl][i] = v;
         }
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Regs& R, int buf) {
     char* wb = smem + buf * STAGE;
     char* ab = wb + PL * W_BYTES;
 #pragma unroll
@@ -188,13 +190,13 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
       for (int j = 0; j < AC; j++) {
         const int ch = (t & 3) + 4 * j;
         if (sizeof(TIn) == 4) {
-          const f32x4 v = __builtin_bit_cast(f32x4, areg[i][j]);
+          const f32x4 v = __builtin_bit_cast(f32x4, R.a[i][j]);
           const u32x2 hi = cvt_bf16x4(v);
           const int off = row * 128 + (((ch >> 1) ^ swz(row)) << 4) + (ch & 1) * 8;
           *reinterpret_cast<u32x2*>(ab + off) = hi;
           if (X3) *reinterpret_cast<u32x2*>(ab + A_BYTES + off) = cvt_bf16x4(v - widen_bf16x4(hi));
         } else {
-          *reinterpret_cast<u32x4*>(ab + row * 128 + ((ch ^ swz(row)) << 4)) = areg[i][j];
+          *reinterpret_cast<u32x4*>(ab + row * 128 + ((ch ^ swz(row)) << 4)) = R.a[i][j];
         }
       }
     }
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
 #pragma unroll
         for (int i = 0; i < WR; i++) {
           const int row = (t >> 3) + 32 * i;
-          *reinterpret_cast<u32x4*>(wb + pl * W_BYTES + row * 128 + (((t & 7) ^ swz(row)) << 4)) = wreg[pl][i];
+          *reinterpret_cast<u32x4*>(wb + pl * W_BYTES + row * 128 + (((t & 7) ^ swz(row)) << 4)) = R.w[pl][i];
         }
     }
   };
@@ -256,20 +258,23 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
   const int step0 = split * per_split;
   const int nsteps = max(0, min(total_steps, step0 + per_split) - step0);
   int tap = THIN ? step0 : tap_begin + step0 / csteps, cs = THIN ? 0 : step0 % csteps;
-  if (nsteps > 0) {
-    load_tile(tap, cs * kBK);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int it = 0; it < nsteps; it++) {
-    const bool more = it + 1 < nsteps;
-    if (more) {
-      if (++cs == csteps) { cs = 0; tap++; }
-      load_tile(tap, cs * kBK);
+  auto advance = [&]() {
+    if (++cs == csteps) { cs = 0; tap++; }
+  };
+  {
+    Regs R;
+    if (nsteps > 0) {
+      load_tile(R, tap, cs * kBK);
+      store_tile(R, 0);
     }
-    compute(it & 1);
-    if (more) store_tile((it + 1) & 1);
     __syncthreads();
+    for (int it = 0; it < nsteps; it++) {
+      const bool more = it + 1 < nsteps;
+      if (more) { advance(); load_tile(R, tap, cs * kBK); }
+      compute(it & 1);
+      if (more) store_tile(R, (it + 1) & 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------
@@ -384,7 +389,8 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   p.ksplit = 1;
   const long blocks = (long)tiles * p.n_oc_tiles;
   const bool can_split = !l.in_bf16 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
-  if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16) {
+  // (only for small outputs: the partial tiles are added with per-lane fp32 atomics whose access shape is slow)
+  if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= 65536) {
     long want = (256 + blocks - 1) / blocks;
     if (want > min_steps / 8) want = min_steps / 8;
     if (want > 32) want = 32;
