@@ -1,0 +1,145 @@
+"""Pix2Pix U-Net generator, 70x70 PatchGAN discriminator and the training step of the reference on the gan_amd
+convolution modules.
+
+Graphs and parameter names follow Pix2Pix/models.py:4-147 (Generator, DownSample, UpSample) and :221-243
+(Discriminator); the step follows Pix2Pix/train.py:94-145.  Reference quirks kept: the U-Net is pre-activation
+(LeakyReLU -> conv -> BN going down, ReLU -> transposed conv -> BN going up, `UpSample.leaky_relu` is a ReLU), the
+discriminator uses ReLU, dropout(0.5) is always on after the first three up blocks, `interpolation` is ignored.
+The dropout masks can be passed in so that a step is repeatable across devices.
+"""
+import torch
+
+from .. import nn as gnn
+
+
+class DownSample(torch.nn.Module):
+    def __init__(self, in_ch, out_ch, inplace=False, use_bn=True):
+        super().__init__()
+        self.downsample = gnn.Conv2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1)
+        self.relu = torch.nn.LeakyReLU(0.2, inplace=inplace)
+        self.batch_norm = torch.nn.BatchNorm2d(out_ch) if use_bn else torch.nn.Identity()
+
+    def forward(self, x):
+        return self.batch_norm(self.downsample(self.relu(x)))
+
+
+class UpSample(torch.nn.Module):
+    def __init__(self, in_ch, out_ch, interpolation=False, use_bn=True):
+        super().__init__()
+        if interpolation:
+            raise RuntimeError("the bilinear-upsample variant is not on the reference's path (Generator never enables it)")
+        self.up_sample = gnn.ConvTranspose2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1)
+        self.batch_norm = torch.nn.BatchNorm2d(out_ch) if use_bn else torch.nn.Identity()
+        self.leaky_relu = torch.nn.ReLU()
+
+    def forward(self, x):
+        return self.batch_norm(self.up_sample(self.leaky_relu(x)))
+
+
+class Generator(torch.nn.Module):
+    def __init__(self, ch=64, image_dim=3, interpolation=True):
+        super().__init__()
+        self.interpolation = interpolation   # accepted and ignored, as in the reference
+        self.downsample_1 = gnn.Conv2d(image_dim, ch, kernel_size=4, stride=2, padding=1)
+        self.downsample_2 = DownSample(ch, ch * 2)
+        self.downsample_3 = DownSample(ch * 2, ch * 4)
+        self.downsample_4 = DownSample(ch * 4, ch * 8)
+        self.downsample_5 = DownSample(ch * 8, ch * 8)
+        self.downsample_6 = DownSample(ch * 8, ch * 8)
+        self.downsample_7 = DownSample(ch * 8, ch * 8)
+        self.downsample_8 = DownSample(ch * 8, ch * 8, use_bn=False)
+        self.upsample_1 = UpSample(ch * 8, ch * 8)
+        self.upsample_2 = UpSample(ch * 8 * 2, ch * 8)
+        self.upsample_3 = UpSample(ch * 8 * 2, ch * 8)
+        self.upsample_4 = UpSample(ch * 8 * 2, ch * 8)
+        self.upsample_5 = UpSample(ch * 8 * 2, ch * 4)
+        self.upsample_6 = UpSample(ch * 4 * 2, ch * 2)
+        self.upsample_7 = UpSample(ch * 2 * 2, ch)
+        self.upsample_8 = UpSample(ch * 2, image_dim, use_bn=False)
+
+    def forward(self, x, dropout_masks=None):
+        """dropout_masks: optional three tensors (already scaled by 1/(1-p)) multiplied onto the outputs of
+        upsample_1..3; default draws them like F.dropout(x, 0.5, training=True)."""
+        def drop(t, i):
+            if dropout_masks is None:
+                return torch.nn.functional.dropout(t, 0.5, training=True)
+            return t * dropout_masks[i]
+
+        x1 = self.downsample_1(x)
+        x2 = self.downsample_2(x1)
+        x3 = self.downsample_3(x2)
+        x4 = self.downsample_4(x3)
+        x5 = self.downsample_5(x4)
+        x6 = self.downsample_6(x5)
+        x7 = self.downsample_7(x6)
+        x8 = self.downsample_8(x7)
+        out = drop(self.upsample_1(x8), 0)
+        out = drop(self.upsample_2(torch.cat((out, x7), dim=1)), 1)
+        out = drop(self.upsample_3(torch.cat((out, x6), dim=1)), 2)
+        out = self.upsample_4(torch.cat((out, x5), dim=1))
+        out = self.upsample_5(torch.cat((out, x4), dim=1))
+        out = self.upsample_6(torch.cat((out, x3), dim=1))
+        out = self.upsample_7(torch.cat((out, x2), dim=1))
+        out = self.upsample_8(torch.cat((out, x1), dim=1))
+        return torch.tanh(out)
+
+
+class Discriminator(torch.nn.Module):
+    def __init__(self, image_dim=6, ch=64):
+        super().__init__()
+        self.conv_1 = gnn.Conv2d(image_dim, ch, 4, 2, 1)
+        self.conv_2 = gnn.Conv2d(ch, ch * 2, 4, 2, 1)
+        self.batch_norm_1 = torch.nn.BatchNorm2d(ch * 2)
+        self.conv_3 = gnn.Conv2d(ch * 2, ch * 4, 4, 2, 1)
+        self.batch_norm_2 = torch.nn.BatchNorm2d(ch * 4)
+        self.conv_4 = gnn.Conv2d(ch * 4, ch * 8, 4, 1, 1)
+        self.batch_norm_3 = torch.nn.BatchNorm2d(ch * 8)
+        self.conv_5 = gnn.Conv2d(ch * 8, 1, 4, 1, 1)
+
+    def forward(self, x, y, return_features=False):
+        relu = torch.nn.functional.relu
+        o1 = relu(self.conv_1(torch.cat((x, y), dim=1)))
+        o2 = relu(self.batch_norm_1(self.conv_2(o1)))
+        o3 = relu(self.batch_norm_2(self.conv_3(o2)))
+        o4 = relu(self.batch_norm_3(self.conv_4(o3)))
+        o5 = self.conv_5(o4)
+        return torch.sigmoid(o5), ([o1, o2, o3, o4, o5] if return_features else None)
+
+
+def requires_grad(model, flag=True):
+    """Pix2Pix/utils.py:43-45."""
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def discriminator_phase(net_G, net_D, real, label, dropout_masks=None, on_last_backward=None):
+    """Pix2Pix/train.py:94-109 up to (not including) optimizer_D.step().  Returns the loss tensor."""
+    bce = torch.nn.functional.binary_cross_entropy
+    requires_grad(net_G, False)
+    requires_grad(net_D, True)
+    d_x, _ = net_D(real, label)
+    d_x = bce(d_x, torch.ones_like(d_x))
+    fake = net_G(label, dropout_masks)
+    d_g_z1, _ = net_D(fake.detach(), label)
+    d_g_z1 = bce(d_g_z1, torch.zeros_like(d_g_z1))
+    loss = (d_x + d_g_z1) * 0.5
+    if on_last_backward is not None:
+        on_last_backward()
+    loss.backward()
+    return loss.detach()
+
+
+def generator_phase(net_G, net_D, real, label, lmbd=100.0, dropout_masks=None, on_last_backward=None):
+    """Pix2Pix/train.py:118-139 up to (not including) optimizer_G.step(); BCE + lambda * L1."""
+    bce = torch.nn.functional.binary_cross_entropy
+    requires_grad(net_G, True)
+    requires_grad(net_D, False)
+    fake = net_G(label, dropout_masks)
+    d_g_z2, _ = net_D(fake, label)
+    g_error = bce(d_g_z2, torch.ones_like(d_g_z2)) + lmbd * torch.nn.functional.l1_loss(fake, real)
+    if on_last_backward is not None:
+        on_last_backward()
+    g_error.backward()
+    requires_grad(net_G, False)
+    requires_grad(net_D, True)
+    return g_error.detach(), fake.detach()

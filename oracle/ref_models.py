@@ -14,6 +14,9 @@ Restated from (paths relative to the reference checkout):
   BasicGANs/loss_functions.py:41-76  get_minimax_loss     -> minimax_step
   BasicGANs/DCGAN.py:165-181    one DCGAN G+D step   -> dcgan_train_step
   BasicGANs/train.py:95-119     one WGAN-GP cycle    -> wgangp_train_cycle
+  Pix2Pix/models.py:4-147       Generator, DownSample, UpSample -> P2PGenerator, P2PDownSample, P2PUpSample
+  Pix2Pix/models.py:221-243     Discriminator        -> P2PDiscriminator
+  Pix2Pix/train.py:94-145       one Pix2Pix step     -> pix2pix_discriminator_phase, pix2pix_generator_phase
 
 The convolution layers are taken from a module namespace `nn` (default torch.nn) so that a test can build
 the very same graph on top of another Conv2d / ConvTranspose2d implementation and compare.
@@ -166,3 +169,118 @@ def synth_inputs(gen, B, nz, res, n_z):
     real = torch.rand(B, 3, res, res, generator=gen) * 2 - 1
     zs = [torch.randn(B, nz, 1, 1, generator=gen) for _ in range(n_z)]
     return real, zs
+
+
+# ---- Pix2Pix ------------------------------------------------------------------------------------------------------
+class P2PDownSample(torch.nn.Module):
+    def __init__(self, in_ch, out_ch, inplace=False, use_bn=True):
+        super().__init__()
+        self.downsample = torch.nn.Conv2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1)
+        self.relu = torch.nn.LeakyReLU(0.2, inplace=inplace)
+        self.batch_norm = torch.nn.BatchNorm2d(out_ch) if use_bn else torch.nn.Identity()
+
+    def forward(self, x):
+        return self.batch_norm(self.downsample(self.relu(x)))
+
+
+class P2PUpSample(torch.nn.Module):
+    def __init__(self, in_ch, out_ch, use_bn=True):
+        super().__init__()
+        self.up_sample = torch.nn.ConvTranspose2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1)
+        self.batch_norm = torch.nn.BatchNorm2d(out_ch) if use_bn else torch.nn.Identity()
+        self.leaky_relu = torch.nn.ReLU()
+
+    def forward(self, x):
+        return self.batch_norm(self.up_sample(self.leaky_relu(x)))
+
+
+class P2PGenerator(torch.nn.Module):
+    """U-Net: 8 stride-2 convs down (256 -> 1), 8 stride-2 transposed convs up with skip concatenation, dropout
+    0.5 (always on) after the first three up blocks, tanh.  Construction order = the reference's, so that a seeded
+    default initialisation reproduces the reference's initial weights."""
+
+    def __init__(self, ch=64, image_dim=3):
+        super().__init__()
+        self.downsample_1 = torch.nn.Conv2d(image_dim, ch, kernel_size=4, stride=2, padding=1)
+        self.downsample_2 = P2PDownSample(ch, ch * 2)
+        self.downsample_3 = P2PDownSample(ch * 2, ch * 4)
+        self.downsample_4 = P2PDownSample(ch * 4, ch * 8)
+        self.downsample_5 = P2PDownSample(ch * 8, ch * 8)
+        self.downsample_6 = P2PDownSample(ch * 8, ch * 8)
+        self.downsample_7 = P2PDownSample(ch * 8, ch * 8)
+        self.downsample_8 = P2PDownSample(ch * 8, ch * 8, use_bn=False)
+        self.upsample_1 = P2PUpSample(ch * 8, ch * 8)
+        self.upsample_2 = P2PUpSample(ch * 8 * 2, ch * 8)
+        self.upsample_3 = P2PUpSample(ch * 8 * 2, ch * 8)
+        self.upsample_4 = P2PUpSample(ch * 8 * 2, ch * 8)
+        self.upsample_5 = P2PUpSample(ch * 8 * 2, ch * 4)
+        self.upsample_6 = P2PUpSample(ch * 4 * 2, ch * 2)
+        self.upsample_7 = P2PUpSample(ch * 2 * 2, ch)
+        self.upsample_8 = P2PUpSample(ch * 2, image_dim, use_bn=False)
+
+    def forward(self, x, dropout_masks=None):
+        def drop(t, i):
+            return torch.nn.functional.dropout(t, 0.5, training=True) if dropout_masks is None else t * dropout_masks[i]
+        x1 = self.downsample_1(x); x2 = self.downsample_2(x1); x3 = self.downsample_3(x2); x4 = self.downsample_4(x3)
+        x5 = self.downsample_5(x4); x6 = self.downsample_6(x5); x7 = self.downsample_7(x6); x8 = self.downsample_8(x7)
+        out = drop(self.upsample_1(x8), 0)
+        out = drop(self.upsample_2(torch.cat((out, x7), dim=1)), 1)
+        out = drop(self.upsample_3(torch.cat((out, x6), dim=1)), 2)
+        out = self.upsample_4(torch.cat((out, x5), dim=1))
+        out = self.upsample_5(torch.cat((out, x4), dim=1))
+        out = self.upsample_6(torch.cat((out, x3), dim=1))
+        out = self.upsample_7(torch.cat((out, x2), dim=1))
+        out = self.upsample_8(torch.cat((out, x1), dim=1))
+        return torch.tanh(out)
+
+
+class P2PDiscriminator(torch.nn.Module):
+    """70x70 PatchGAN on cat(image, label): k4 convs s2,s2,s2,s1,s1 with BatchNorm on 2-4, ReLU, sigmoid."""
+
+    def __init__(self, image_dim=6, ch=64):
+        super().__init__()
+        self.conv_1 = torch.nn.Conv2d(image_dim, ch, 4, 2, 1)
+        self.conv_2 = torch.nn.Conv2d(ch, ch * 2, 4, 2, 1)
+        self.batch_norm_1 = torch.nn.BatchNorm2d(ch * 2)
+        self.conv_3 = torch.nn.Conv2d(ch * 2, ch * 4, 4, 2, 1)
+        self.batch_norm_2 = torch.nn.BatchNorm2d(ch * 4)
+        self.conv_4 = torch.nn.Conv2d(ch * 4, ch * 8, 4, 1, 1)
+        self.batch_norm_3 = torch.nn.BatchNorm2d(ch * 8)
+        self.conv_5 = torch.nn.Conv2d(ch * 8, 1, 4, 1, 1)
+
+    def forward(self, x, y):
+        relu = torch.nn.functional.relu
+        o = relu(self.conv_1(torch.cat((x, y), dim=1)))
+        o = relu(self.batch_norm_1(self.conv_2(o)))
+        o = relu(self.batch_norm_2(self.conv_3(o)))
+        o = relu(self.batch_norm_3(self.conv_4(o)))
+        return torch.sigmoid(self.conv_5(o))
+
+
+def _set_requires_grad(model, flag):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def pix2pix_discriminator_phase(net_G, net_D, real, label, dropout_masks=None):
+    bce = torch.nn.functional.binary_cross_entropy
+    _set_requires_grad(net_G, False); _set_requires_grad(net_D, True)
+    d_x = net_D(real, label)
+    d_x = bce(d_x, torch.ones_like(d_x))
+    fake = net_G(label, dropout_masks)
+    d_g_z1 = net_D(fake.detach(), label)
+    d_g_z1 = bce(d_g_z1, torch.zeros_like(d_g_z1))
+    loss = (d_x + d_g_z1) * 0.5
+    loss.backward()
+    return loss.detach()
+
+
+def pix2pix_generator_phase(net_G, net_D, real, label, lmbd=100.0, dropout_masks=None):
+    bce = torch.nn.functional.binary_cross_entropy
+    _set_requires_grad(net_G, True); _set_requires_grad(net_D, False)
+    fake = net_G(label, dropout_masks)
+    d_g_z2 = net_D(fake, label)
+    g_error = bce(d_g_z2, torch.ones_like(d_g_z2)) + lmbd * torch.nn.functional.l1_loss(fake, real)
+    g_error.backward()
+    _set_requires_grad(net_G, False); _set_requires_grad(net_D, True)
+    return g_error.detach(), fake.detach()

@@ -15,6 +15,8 @@ imported by path (BasicGANs/models.py, BasicGANs/loss_functions.py):
                        BasicGANs/train.py:95-119) incl. the gradient-penalty double backward, reduced model
   dcgan_losses.json    loss scalars of 3 full-size DCGAN-64 steps (hidden 64, batch 128) with Adam
   wgangp_losses.json   loss scalars of 1 full cycle (5 critic + 1 generator) WGAN-GP-64 at batch 64 with Adam
+  pix2pix_trace.npz    one Pix2Pix step (Pix2Pix/models.py, step order of Pix2Pix/train.py:94-145) at 256x256, ch 8,
+                       batch 2: losses, discriminator gradients, sampled generator gradients, output crops, masks
 
 Usage:  python tests/golden/make_golden.py [--ref /root/reference] [--out tests/golden]
 """
@@ -236,6 +238,71 @@ def make_wgangp_trace(ref, out):
     print("wgangp_trace.npz:", len(blob), "arrays; scalars", blob["critic.scalars"], blob["gen.scalars"])
 
 
+def make_pix2pix_trace(ref, out):
+    """One Pix2Pix step (Pix2Pix/train.py:94-145) on the reference's models at 256x256 with ch=8, batch 2.  The
+    nets keep PyTorch's default initialisation (the script applies none), regenerated from the seed by the tests
+    and pinned here by checksums; dropout masks are captured."""
+    models = load_by_path("ref_p2p_models", os.path.join(ref, "Pix2Pix/models.py"))
+    seed_all()
+    B, ch = 2, 8
+    net_G = models.Generator(ch=ch)
+    net_D = models.Discriminator(ch=ch)
+    blob = {"cfg": np.array([B, ch], np.int64)}
+    rec = {"param_count": {"G": sum(p.numel() for p in net_G.parameters()), "D": sum(p.numel() for p in net_D.parameters())},
+           "init_checksum": {"G": checksum(torch.cat([p.flatten() for p in net_G.parameters()])),
+                             "D": checksum(torch.cat([p.flatten() for p in net_D.parameters()]))}}
+    gen = torch.Generator().manual_seed(SEED + 2)
+    real = torch.rand(B, 3, 256, 256, generator=gen) * 2 - 1
+    label = torch.rand(B, 3, 256, 256, generator=gen)
+    rec["input_checksum"] = {"real": checksum(real), "label": checksum(label)}
+    masks = []
+    orig_dropout = F.dropout
+
+    def dropout_spy(x, p=0.5, training=True, inplace=False):
+        m = (torch.rand(x.shape, generator=gen) >= p).to(x.dtype) / (1 - p)
+        masks.append(m)
+        return x * m
+    F.dropout = dropout_spy
+    torch.nn.functional.dropout = dropout_spy
+    try:
+        bce = torch.nn.BCELoss(); l1 = torch.nn.L1Loss()
+        req = lambda m, f: [p.requires_grad_(f) for p in m.parameters()]
+        req(net_G, False); req(net_D, True)
+        D_x, _ = net_D(real, label)
+        ones = torch.ones_like(D_x)
+        D_x = bce(D_x, ones)
+        fake = net_G(label)
+        D_G_z1, _ = net_D(fake.detach(), label)
+        D_G_z1 = bce(D_G_z1, torch.zeros_like(D_G_z1))
+        d_loss = (D_x + D_G_z1) * 0.5
+        d_loss.backward()
+        blob["d.loss"] = np.array([d_loss.item(), D_x.item(), D_G_z1.item()])
+        for k, p in net_D.named_parameters():
+            blob["d.gradD." + k] = p.grad.clone().numpy()
+        blob["d.fake_crop"] = fake.detach()[:, :, 96:160, 96:160].numpy()
+        n_d_masks = len(masks)
+        req(net_G, True); req(net_D, False)
+        fake1 = net_G(label)
+        D_G_z2, _ = net_D(fake1, label)
+        g_err = bce(D_G_z2, ones) + 100.0 * l1(fake1, real)
+        g_err.backward()
+        blob["g.loss"] = np.array([g_err.item()])
+        blob["g.fake_crop"] = fake1.detach()[:, :, 96:160, 96:160].numpy()
+        for k, p in net_G.named_parameters():      # small tensors in full, big ones as a strided sample
+            g = p.grad.clone().numpy()
+            blob["g.gradG." + k] = g if g.size <= 20000 else g.ravel()[::max(1, g.size // 4096)][:4096].copy()
+            blob["g.gradG_norm." + k] = np.array([np.linalg.norm(g.astype(np.float64))])
+    finally:
+        F.dropout = orig_dropout
+        torch.nn.functional.dropout = orig_dropout
+    for i, m in enumerate(masks):
+        blob[f"mask{i}"] = m.numpy().astype(np.uint8) if False else m.numpy()
+    blob["n_d_masks"] = np.array([n_d_masks])
+    np.savez_compressed(os.path.join(out, "pix2pix_trace.npz"), **blob)
+    json.dump(rec, open(os.path.join(out, "pix2pix_trace.json"), "w"), indent=1)
+    print("pix2pix_trace.npz:", len(blob), "arrays; losses", blob["d.loss"], blob["g.loss"], rec["param_count"])
+
+
 # --------------------------------------------------------------------------------------- loss curves
 def synth_inputs(gen, B, nz, res, n_z):
     """Synthetic inputs drawn from a dedicated CPU generator so that the same numbers can be regenerated
@@ -328,9 +395,10 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses"]
+    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace"]
     if "ops" in todo: make_ops(a.out)
     if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
     if "wgangp_trace" in todo: make_wgangp_trace(a.ref, a.out)
     if "dcgan_losses" in todo: make_dcgan_losses(a.ref, a.out)
     if "wgangp_losses" in todo: make_wgangp_losses(a.ref, a.out)
+    if "pix2pix_trace" in todo: make_pix2pix_trace(a.ref, a.out)

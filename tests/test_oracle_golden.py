@@ -148,3 +148,50 @@ def test_restated_dcgan_full_size_losses(golden_dir):
     out = R.dcgan_train_step(G, D, opt_G, opt_D, real, noise)
     for k, v in rec["steps"][0].items():
         assert abs(out[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, out[k], v)
+
+
+def _checksum(t):
+    import hashlib
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+def pix2pix_setup(golden_dir, make_G, make_D):
+    """Nets re-initialised from the reference's seed (PyTorch default init, as the reference applies none),
+    inputs regenerated from the data seed, dropout masks from the fixture."""
+    z = np.load(os.path.join(golden_dir, "pix2pix_trace.npz"))
+    rec = json.load(open(os.path.join(golden_dir, "pix2pix_trace.json")))
+    B, ch = [int(v) for v in z["cfg"]]
+    torch.manual_seed(5000)
+    G = make_G(ch); D = make_D(ch)
+    gen = torch.Generator().manual_seed(5002)
+    real = torch.rand(B, 3, 256, 256, generator=gen) * 2 - 1
+    label = torch.rand(B, 3, 256, 256, generator=gen)
+    assert _checksum(real) == rec["input_checksum"]["real"] and _checksum(label) == rec["input_checksum"]["label"]
+    n_d = int(z["n_d_masks"][0])
+    masks = [torch.from_numpy(z[f"mask{i}"]) for i in range(2 * n_d)]
+    return z, rec, G, D, real, label, masks[:n_d], masks[n_d:]
+
+
+def test_restated_pix2pix_step_matches_reference(golden_dir):
+    z, rec, G, D, real, label, masks_d, masks_g = pix2pix_setup(golden_dir, lambda ch: R.P2PGenerator(ch=ch), lambda ch: R.P2PDiscriminator(ch=ch))
+    assert sum(p.numel() for p in G.parameters()) == rec["param_count"]["G"]
+    assert _checksum(torch.cat([p.flatten() for p in G.parameters()])) == rec["init_checksum"]["G"]
+    assert _checksum(torch.cat([p.flatten() for p in D.parameters()])) == rec["init_checksum"]["D"]
+    d_loss = R.pix2pix_discriminator_phase(G, D, real, label, masks_d)
+    assert abs(d_loss.item() - z["d.loss"][0]) < 1e-6
+    for k, p in D.named_parameters():
+        assert rel_err(p.grad.numpy(), z["d.gradD." + k]) < 1e-5, k
+    g_err, fake = R.pix2pix_generator_phase(G, D, real, label, 100.0, masks_g)
+    assert abs(g_err.item() - z["g.loss"][0]) < 1e-5 * z["g.loss"][0]
+    assert rel_err(fake[:, :, 96:160, 96:160].numpy(), z["g.fake_crop"]) < 1e-5
+    for k, p in G.named_parameters():
+        g = p.grad.numpy()
+        assert abs(np.linalg.norm(g.astype(np.float64)) - z["g.gradG_norm." + k][0]) < 1e-4 * z["g.gradG_norm." + k][0], k
+
+
+def test_full_size_pix2pix_parameter_counts():
+    G, D = R.P2PGenerator(), R.P2PDiscriminator()
+    assert sum(p.numel() for p in G.parameters()) == 54419459
+    assert sum(p.numel() for p in D.parameters()) == 2769601
+    with torch.no_grad():
+        assert D(torch.zeros(1, 3, 256, 256), torch.zeros(1, 3, 256, 256)).shape == (1, 1, 30, 30)
