@@ -17,6 +17,8 @@ imported by path (BasicGANs/models.py, BasicGANs/loss_functions.py):
   wgangp_losses.json   loss scalars of 1 full cycle (5 critic + 1 generator) WGAN-GP-64 at batch 64 with Adam
   pix2pix_trace.npz    one Pix2Pix step (Pix2Pix/models.py, step order of Pix2Pix/train.py:94-145) at 256x256, ch 8,
                        batch 2: losses, discriminator gradients, sampled generator gradients, output crops, masks
+  stylegan_trace.npz   StyleGAN-v1 (StyleGAN/model.py) at 128x128 (pg step 5), batch 2: critic phase with style mixing and
+                       gradient penalty, generator phase, a fade-in forward pass; all internal random draws recorded
 
 Usage:  python tests/golden/make_golden.py [--ref /root/reference] [--out tests/golden]
 """
@@ -303,6 +305,89 @@ def make_pix2pix_trace(ref, out):
     print("pix2pix_trace.npz:", len(blob), "arrays; losses", blob["d.loss"], blob["g.loss"], rec["param_count"])
 
 
+def _sample(g, n=4096):
+    g = np.asarray(g)
+    return g if g.size <= 20000 else g.ravel()[::max(1, g.size // n)][:n].copy()
+
+
+def make_stylegan_trace(ref, out):
+    """StyleGAN-v1 at progressive-growing step 5 (128x128, the first resolution with the fused up/down-sampling
+    blocks), batch 2: one critic phase with style mixing and gradient penalty, one generator phase, and a
+    forward-only fade-in (alpha = 0.5) pass, on the reference's StyleGAN/model.py + BasicGANs/loss_functions.py.
+    Weights are re-created from the seed by the tests (checksums here); every random draw made inside forward /
+    the loss (noise images, crossover, epsilon) is recorded."""
+    import random as _random
+    models = load_by_path("ref_sg_models", os.path.join(ref, "StyleGAN/model.py"))
+    losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
+    seed_all()
+    B, pg = 2, 5
+    net_G = models.StyleBasedGenerator(fused=True)
+    net_D = models.Discriminator(fused=True, use_activations=True)
+    rec = {"param_count": {"G": sum(p.numel() for p in net_G.parameters()), "D": sum(p.numel() for p in net_D.parameters())},
+           "init_checksum": {"G": checksum(torch.cat([p.flatten() for p in net_G.parameters()])),
+                             "D": checksum(torch.cat([p.flatten() for p in net_D.parameters()]))},
+           "B": B, "pg_step": pg}
+    gen = torch.Generator().manual_seed(SEED + 3)
+    real = torch.rand(B, 3, 128, 128, generator=gen) * 2 - 1
+    zs = torch.randn(4, B, 512, generator=gen)
+    rec["input_checksum"] = {"real": checksum(real), "zs": checksum(zs)}
+    blob = {}
+    drawn = {"randn": [], "rand": [], "randint": []}
+    o_randn, o_rand, o_randint = torch.randn, torch.rand, _random.randint
+
+    def randn_spy(*a, **kw):
+        t = o_randn(*a, **kw); drawn["randn"].append(t.detach().clone()); return t
+
+    def rand_spy(*a, **kw):
+        t = o_rand(*a, **kw); drawn["rand"].append(t.detach().clone()); return t
+
+    def randint_spy(a, b):
+        v = o_randint(a, b); drawn["randint"].append(v); return v
+    torch.randn, torch.rand = randn_spy, rand_spy
+    models.random.randint = randint_spy
+    req = lambda m, f: [p.requires_grad_(f) for p in m.parameters()]
+    try:
+        req(net_G, False); req(net_D, True)
+        D_x, D_G_z1, gp = losses.get_wasserstein_loss(net_G, net_D, real, [zs[0], zs[1]], progressive_growing_phase=pg, alpha=1)
+        blob["critic.scalars"] = np.array([D_x.item(), D_G_z1, gp.item()])
+        for i, t in enumerate(drawn["randn"]):
+            blob[f"critic.noise{i}"] = t.numpy()
+        blob["critic.eps"] = drawn["rand"][0].numpy()
+        blob["critic.crossover"] = np.array(drawn["randint"])
+        for k, p in net_D.named_parameters():
+            if p.grad is not None:
+                blob["critic.gradD." + k] = _sample(p.grad.numpy())
+                blob["critic.gradD_norm." + k] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64))])
+        for k in drawn: drawn[k].clear()
+        req(net_G, True); req(net_D, False)
+        G_error, D_G_z2 = losses.get_wasserstein_loss(net_G, net_D, noise_vector=[zs[2], zs[3]], discriminator=False,
+                                                      progressive_growing_phase=pg, alpha=1)
+        blob["gen.scalars"] = np.array([G_error.item(), D_G_z2])
+        for i, t in enumerate(drawn["randn"]):
+            blob[f"gen.noise{i}"] = t.numpy()
+        blob["gen.crossover"] = np.array(drawn["randint"])
+        for k, p in net_G.named_parameters():
+            if p.grad is not None:
+                blob["gen.gradG." + k] = _sample(p.grad.numpy())
+                blob["gen.gradG_norm." + k] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64))])
+        for k in drawn: drawn[k].clear()
+        with torch.no_grad():
+            img = net_G(zs[0], progressive_growing_phase=pg, alpha=0.5)
+            score = net_D(img, progressive_growing_phase=pg, alpha=0.5)
+            img1 = net_G(zs[0], progressive_growing_phase=pg, alpha=1)
+        for i, t in enumerate(drawn["randn"]):
+            blob[f"fade.noise{i}"] = t.numpy()
+        blob["fade.image_crop"] = img[:, :, 32:96, 32:96].numpy()
+        blob["fade.score"] = score.numpy()
+        blob["fade.image_alpha1_crop"] = img1[:, :, 32:96, 32:96].numpy()
+    finally:
+        torch.randn, torch.rand = o_randn, o_rand
+        models.random.randint = o_randint
+    np.savez_compressed(os.path.join(out, "stylegan_trace.npz"), **blob)
+    json.dump(rec, open(os.path.join(out, "stylegan_trace.json"), "w"), indent=1)
+    print("stylegan_trace.npz:", len(blob), "arrays;", blob["critic.scalars"], blob["gen.scalars"], rec["param_count"], blob["critic.crossover"], blob["gen.crossover"])
+
+
 # --------------------------------------------------------------------------------------- loss curves
 def synth_inputs(gen, B, nz, res, n_z):
     """Synthetic inputs drawn from a dedicated CPU generator so that the same numbers can be regenerated
@@ -395,10 +480,11 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace"]
+    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "stylegan_trace"]
     if "ops" in todo: make_ops(a.out)
     if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
     if "wgangp_trace" in todo: make_wgangp_trace(a.ref, a.out)
     if "dcgan_losses" in todo: make_dcgan_losses(a.ref, a.out)
     if "wgangp_losses" in todo: make_wgangp_losses(a.ref, a.out)
     if "pix2pix_trace" in todo: make_pix2pix_trace(a.ref, a.out)
+    if "stylegan_trace" in todo: make_stylegan_trace(a.ref, a.out)

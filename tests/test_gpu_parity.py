@@ -442,3 +442,36 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
             assert_grad_close(g, ref, tol, 2 * coarse, k)
     finally:
         gan.set_precision("bf16")
+
+
+@pytest.mark.parametrize("prec,tol,coarse", [("fp32x3", 5e-4, 5e-2), ("bf16", 5e-2, 3e-1)])
+def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse):
+    """StyleGAN-v1 at 128x128 (pg step 5, fused blocks, style mixing, minibatch stddev, 513-channel conv): critic phase
+    with gradient penalty, generator phase and a fade-in forward pass against the reference trace."""
+    from gan_amd.harness import stylegan as S
+    from test_oracle_golden import check_grads, stylegan_setup
+    gan.set_precision(prec)
+    try:
+        z, rec, G, D, real, zs, noises = stylegan_setup(golden_dir, lambda: S.StyleBasedGenerator(fused=True),
+                                                        lambda: S.Discriminator(fused=True, use_activations=True))
+        G.cuda(); D.cuda()
+        real, zs = real.cuda(), zs.cuda()
+        noises = {k: [t.cuda() for t in v] for k, v in noises.items()}
+        pg = rec["pg_step"]
+        with torch.no_grad():   # forward only first: smooth in the rounding error
+            img = G(zs[0], progressive_growing_phase=pg, alpha=0.5, noises=noises["fade"])
+            score = D(img, progressive_growing_phase=pg, alpha=0.5)
+        assert rel(img[:, :, 32:96, 32:96], z["fade.image_crop"]) < tol
+        assert rel(score, z["fade.score"]) < 20 * tol
+        d_x, d_g, gp, _ = S.critic_phase(G, D, real, [zs[0], zs[1]], cu(z["critic.eps"]), pg, 1, 10.0, noises["critic"],
+                                         int(z["critic.crossover"][0]))
+        want = z["critic.scalars"]
+        assert abs(d_x.item() - want[0]) < 20 * tol * max(1, abs(want[0]))
+        assert abs(d_g.item() - want[1]) < 20 * tol * max(1, abs(want[1]))
+        assert abs(gp.item() - want[2]) < (20 * tol if prec == "fp32x3" else 0.3) * abs(want[2])
+        assert check_grads(D.named_parameters(), z, "critic.gradD", coarse) > 20
+        g_err, _ = S.generator_phase(G, D, [zs[2], zs[3]], pg, 1, noises["gen"], int(z["gen.crossover"][0]))
+        assert abs(g_err.item() - z["gen.scalars"][0]) < 20 * tol * max(1, abs(z["gen.scalars"][0]))
+        assert check_grads(G.named_parameters(), z, "gen.gradG", coarse) > 40
+    finally:
+        gan.set_precision("bf16")

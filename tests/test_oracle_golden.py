@@ -195,3 +195,63 @@ def test_full_size_pix2pix_parameter_counts():
     assert sum(p.numel() for p in D.parameters()) == 2769601
     with torch.no_grad():
         assert D(torch.zeros(1, 3, 256, 256), torch.zeros(1, 3, 256, 256)).shape == (1, 1, 30, 30)
+
+
+def stylegan_setup(golden_dir, make_G, make_D):
+    z = np.load(os.path.join(golden_dir, "stylegan_trace.npz"))
+    rec = json.load(open(os.path.join(golden_dir, "stylegan_trace.json")))
+    torch.manual_seed(5000)
+    G = make_G(); D = make_D()
+    gen = torch.Generator().manual_seed(5003)
+    real = torch.rand(rec["B"], 3, 128, 128, generator=gen) * 2 - 1
+    zs = torch.randn(4, rec["B"], 512, generator=gen)
+    assert _checksum(real) == rec["input_checksum"]["real"] and _checksum(zs) == rec["input_checksum"]["zs"]
+    noises = {ph: [torch.from_numpy(z[f"{ph}.noise{i}"]) for i in range(rec["pg_step"] + 1)] for ph in ("critic", "gen", "fade")}
+    return z, rec, G, D, real, zs, noises
+
+
+def check_grads(named_params, z, prefix, tol, report=None):
+    """Sampled gradient entries and full norms recorded by make_golden._sample."""
+    biggest = max(z[k][0] for k in z.files if k.startswith(prefix + "_norm."))
+    n = 0
+    for k, p in named_params:
+        key = prefix + "." + k
+        if key not in z.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        g = p.grad.detach().cpu().numpy()
+        want_norm = z[prefix + "_norm." + k][0]
+        if want_norm < 1e-6 * biggest:
+            assert np.linalg.norm(g) < 1e-4 * biggest, k
+            continue
+        gs = g if g.size <= 20000 else g.ravel()[::max(1, g.size // 4096)][:4096]
+        err = rel_err(gs, z[key])
+        if report is not None:
+            report[k] = err
+        assert err < tol, (k, err)
+        assert abs(np.linalg.norm(g.astype(np.float64)) - want_norm) < tol * want_norm, k
+        n += 1
+    return n
+
+
+def test_restated_stylegan_matches_reference(golden_dir):
+    from oracle import ref_stylegan as S
+    z, rec, G, D, real, zs, noises = stylegan_setup(golden_dir, lambda: S.StyleBasedGenerator(fused=True),
+                                                    lambda: S.Discriminator(fused=True, use_activations=True))
+    assert sum(p.numel() for p in G.parameters()) == rec["param_count"]["G"] == 26219115
+    assert sum(p.numel() for p in D.parameters()) == rec["param_count"]["D"] == 26054017
+    assert _checksum(torch.cat([p.flatten() for p in G.parameters()])) == rec["init_checksum"]["G"]
+    assert _checksum(torch.cat([p.flatten() for p in D.parameters()])) == rec["init_checksum"]["D"]
+    pg = rec["pg_step"]
+    d_x, d_g, gp, _ = S.critic_phase(G, D, real, [zs[0], zs[1]], torch.from_numpy(z["critic.eps"]), pg, 1, 10.0,
+                                     noises["critic"], int(z["critic.crossover"][0]))
+    np.testing.assert_allclose([d_x.item(), d_g.item(), gp.item()], z["critic.scalars"], rtol=2e-4)
+    assert check_grads(D.named_parameters(), z, "critic.gradD", 2e-3) > 20
+    g_err, _ = S.generator_phase(G, D, [zs[2], zs[3]], pg, 1, noises["gen"], int(z["gen.crossover"][0]))
+    np.testing.assert_allclose(g_err.item(), z["gen.scalars"][0], rtol=2e-4)
+    assert check_grads(G.named_parameters(), z, "gen.gradG", 2e-3) > 40
+    with torch.no_grad():
+        img = G(zs[0], progressive_growing_phase=pg, alpha=0.5, noises=noises["fade"])
+        score = D(img, progressive_growing_phase=pg, alpha=0.5)
+    assert rel_err(img[:, :, 32:96, 32:96].numpy(), z["fade.image_crop"]) < 1e-5
+    assert rel_err(score.numpy(), z["fade.score"]) < 1e-4
