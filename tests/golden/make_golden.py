@@ -19,6 +19,8 @@ imported by path (BasicGANs/models.py, BasicGANs/loss_functions.py):
                        batch 2: losses, discriminator gradients, sampled generator gradients, output crops, masks
   stylegan_trace.npz   StyleGAN-v1 (StyleGAN/model.py) at 128x128 (pg step 5), batch 2: critic phase with style mixing and
                        gradient penalty, generator phase, a fade-in forward pass; all internal random draws recorded
+  biggan_trace.npz     BigGAN (BigGAN/model.py) at 128x128 with ch 8, 4 classes, batch 4: hinge discriminator and generator
+                       phases with orthogonal init / regularisation
 
 Usage:  python tests/golden/make_golden.py [--ref /root/reference] [--out tests/golden]
 """
@@ -388,6 +390,65 @@ def make_stylegan_trace(ref, out):
     print("stylegan_trace.npz:", len(blob), "arrays;", blob["critic.scalars"], blob["gen.scalars"], rec["param_count"], blob["critic.crossover"], blob["gen.crossover"])
 
 
+def make_biggan_trace(ref, out):
+    """BigGAN 128x128 with ch = 8, 4 classes, batch 4 on the reference's BigGAN/model.py: hinge discriminator phase
+    and generator phase (BasicGANs/loss_functions.py:79-99) with orthogonal init and orthogonal regularisation
+    restated from BigGAN/train.py:108-127 (that script imports cv2 / tensorboard and cannot be imported)."""
+    models = load_by_path("ref_bg_models", os.path.join(ref, "BigGAN/model.py"))
+    losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
+    seed_all()
+    B, ch, ncls = 4, 8, 4
+    net_G = models.Generator(n_classes=ncls, ch=ch)
+    net_D = models.Discriminator(n_classes=ncls, ch=ch)
+
+    def orthogonal_init(model):
+        for module in model.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.Linear, torch.nn.Embedding)):
+                torch.nn.init.orthogonal_(module.weight)
+
+    def orth_reg(module, beta=1e-4):
+        with torch.no_grad():
+            for p in module.parameters():
+                if len(p.shape) > 2:
+                    w = p.view(p.shape[0], -1)
+                    p.grad.data += beta * (2 * torch.mm(torch.mm(w, w.t()) * (1. - torch.eye(w.shape[0])), w)).view(p.shape)
+    orthogonal_init(net_G); orthogonal_init(net_D)
+    rec = {"B": B, "ch": ch, "n_classes": ncls,
+           "param_count": {"G": sum(p.numel() for p in net_G.parameters()), "D": sum(p.numel() for p in net_D.parameters())},
+           "init_checksum": {"G": checksum(torch.cat([p.flatten() for p in net_G.parameters()])),
+                             "D": checksum(torch.cat([p.flatten() for p in net_D.parameters()]))}}
+    gen = torch.Generator().manual_seed(SEED + 4)
+    real = torch.rand(B, 3, 128, 128, generator=gen) * 2 - 1
+    z1 = torch.rand(B, 120, generator=gen); z2 = torch.rand(B, 120, generator=gen)
+    labels = torch.randint(0, ncls - 1, (3, B), generator=gen)
+    rec["input_checksum"] = {"real": checksum(real), "z1": checksum(z1), "labels": labels.tolist()}
+    blob = {}
+    req = lambda m, f: [p.requires_grad_(f) for p in m.parameters()]
+    req(net_G, False); req(net_D, True)
+    D_x, D_G_z1 = losses.get_hinge_loss(net_G, net_D, real, labels[0], z1, labels[1])
+    orth_reg(net_D)
+    blob["d.scalars"] = np.array([D_x.item(), D_G_z1.item()])
+    for k, p in net_D.named_parameters():
+        blob["d.gradD." + k] = _sample(p.grad.numpy())
+        blob["d.gradD_norm." + k] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64))])
+    req(net_G, True); req(net_D, False)
+    G_error = losses.get_hinge_loss(net_G, net_D, noise_vector=z2, fake_label=labels[2], discriminator=False)
+    orth_reg(net_G)
+    blob["g.scalars"] = np.array([G_error.item()])
+    for k, p in net_G.named_parameters():
+        blob["g.gradG." + k] = _sample(p.grad.numpy())
+        blob["g.gradG_norm." + k] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64))])
+    with torch.no_grad():
+        img = net_G(z1, labels[1])
+    blob["image_crop"] = img[:, :, 32:96, 32:96].numpy()
+    for k, v in net_G.state_dict().items():
+        if "U_vector" in k and v.numel() <= 64:
+            blob["after.G." + k] = v.clone().numpy()
+    np.savez_compressed(os.path.join(out, "biggan_trace.npz"), **blob)
+    json.dump(rec, open(os.path.join(out, "biggan_trace.json"), "w"), indent=1)
+    print("biggan_trace.npz:", len(blob), "arrays;", blob["d.scalars"], blob["g.scalars"], rec["param_count"])
+
+
 # --------------------------------------------------------------------------------------- loss curves
 def synth_inputs(gen, B, nz, res, n_z):
     """Synthetic inputs drawn from a dedicated CPU generator so that the same numbers can be regenerated
@@ -480,7 +541,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "stylegan_trace"]
+    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "stylegan_trace", "biggan_trace"]
     if "ops" in todo: make_ops(a.out)
     if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
     if "wgangp_trace" in todo: make_wgangp_trace(a.ref, a.out)
@@ -488,3 +549,4 @@ if __name__ == "__main__":
     if "wgangp_losses" in todo: make_wgangp_losses(a.ref, a.out)
     if "pix2pix_trace" in todo: make_pix2pix_trace(a.ref, a.out)
     if "stylegan_trace" in todo: make_stylegan_trace(a.ref, a.out)
+    if "biggan_trace" in todo: make_biggan_trace(a.ref, a.out)

@@ -475,3 +475,28 @@ def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coa
         assert check_grads(G.named_parameters(), z, "gen.gradG", coarse) > 40
     finally:
         gan.set_precision("bf16")
+
+
+@pytest.mark.parametrize("prec,tol,coarse", [("fp32x3", 5e-4, 5e-2), ("bf16", 5e-2, 3e-1)])
+def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse):
+    """BigGAN 128x128 (spectral-norm 3x3 / 1x1 convs incl. the attention projections, conditional BN, nearest
+    upsampling, projection discriminator): hinge phases with orthogonal regularisation against the reference trace."""
+    from gan_amd.harness import biggan as Bg
+    from test_oracle_golden import biggan_setup, check_grads
+    gan.set_precision(prec)
+    try:
+        z, rec, G, D, real, z1, z2, labels = biggan_setup(golden_dir, Bg)
+        G.cuda(); D.cuda()
+        real, z1, z2, labels = real.cuda(), z1.cuda(), z2.cuda(), labels.cuda()
+        d_x, d_g = Bg.discriminator_phase(G, D, real, labels[0], z1, labels[1])
+        assert abs(d_x.item() - z["d.scalars"][0]) < 20 * tol * z["d.scalars"][0]
+        assert abs(d_g.item() - z["d.scalars"][1]) < 20 * tol
+        assert check_grads(D.named_parameters(), z, "d.gradD", coarse) > 20
+        g_err = Bg.generator_phase(G, D, z2, labels[2])
+        assert abs(g_err.item() - z["g.scalars"][0]) < 20 * tol * abs(z["g.scalars"][0])
+        assert check_grads(G.named_parameters(), z, "g.gradG", coarse) > 40
+        with torch.no_grad():
+            img = G(z1, labels[1])
+        assert rel(img[:, :, 32:96, 32:96], z["image_crop"]) < 20 * tol
+    finally:
+        gan.set_precision("bf16")

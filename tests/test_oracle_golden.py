@@ -255,3 +255,43 @@ def test_restated_stylegan_matches_reference(golden_dir):
         score = D(img, progressive_growing_phase=pg, alpha=0.5)
     assert rel_err(img[:, :, 32:96, 32:96].numpy(), z["fade.image_crop"]) < 1e-5
     assert rel_err(score.numpy(), z["fade.score"]) < 1e-4
+
+
+def biggan_setup(golden_dir, M):
+    z = np.load(os.path.join(golden_dir, "biggan_trace.npz"))
+    rec = json.load(open(os.path.join(golden_dir, "biggan_trace.json")))
+    torch.manual_seed(5000)
+    G = M.Generator(n_classes=rec["n_classes"], ch=rec["ch"]); D = M.Discriminator(n_classes=rec["n_classes"], ch=rec["ch"])
+    M.orthogonal_init(G); M.orthogonal_init(D)
+    gen = torch.Generator().manual_seed(5004)
+    B = rec["B"]
+    real = torch.rand(B, 3, 128, 128, generator=gen) * 2 - 1
+    z1 = torch.rand(B, 120, generator=gen); z2 = torch.rand(B, 120, generator=gen)
+    labels = torch.randint(0, rec["n_classes"] - 1, (3, B), generator=gen)
+    assert _checksum(real) == rec["input_checksum"]["real"] and labels.tolist() == rec["input_checksum"]["labels"]
+    return z, rec, G, D, real, z1, z2, labels
+
+
+def test_restated_biggan_matches_reference(golden_dir):
+    from oracle import ref_biggan as Bg
+    z, rec, G, D, real, z1, z2, labels = biggan_setup(golden_dir, Bg)
+    assert _checksum(torch.cat([p.flatten() for p in G.parameters()])) == rec["init_checksum"]["G"]
+    assert _checksum(torch.cat([p.flatten() for p in D.parameters()])) == rec["init_checksum"]["D"]
+    d_x, d_g = Bg.discriminator_phase(G, D, real, labels[0], z1, labels[1])
+    np.testing.assert_allclose([d_x.item(), d_g.item()], z["d.scalars"], rtol=1e-5, atol=1e-7)
+    assert check_grads(D.named_parameters(), z, "d.gradD", 1e-4) > 20
+    g_err = Bg.generator_phase(G, D, z2, labels[2])
+    np.testing.assert_allclose(g_err.item(), z["g.scalars"][0], rtol=1e-5)
+    assert check_grads(G.named_parameters(), z, "g.gradG", 1e-4) > 40
+    with torch.no_grad():
+        img = G(z1, labels[1])
+    assert rel_err(img[:, :, 32:96, 32:96].numpy(), z["image_crop"]) < 1e-5
+    for k, v in G.state_dict().items():
+        if "after.G." + k in z.files:
+            assert rel_err(v.numpy(), z["after.G." + k]) < 1e-5, k
+
+
+def test_full_size_biggan_parameter_counts():
+    from oracle import ref_biggan as Bg
+    assert sum(p.numel() for p in Bg.Generator(n_classes=4, ch=64).parameters()) == 31859620
+    assert sum(p.numel() for p in Bg.Discriminator(n_classes=4, ch=64).parameters()) == 39478034
