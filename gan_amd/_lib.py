@@ -86,7 +86,7 @@ def profile_enable(on):
 
 
 def profile_collect(max_entries=32):
-    names = ((ctypes.c_char * 64) * max_entries)()
+    names = ((ctypes.c_char * 96) * max_entries)()
     launches = (ctypes.c_int64 * max_entries)()
     total_ms = (ctypes.c_double * max_entries)()
     flops = (ctypes.c_double * max_entries)()

@@ -44,6 +44,7 @@ struct GatherLaunch {
   int to, tp;          // tile: output channels x pixels
   bool in_bf16, x3;
   int mode;            // GatherMode
+  bool big_tile_ok;    // the caller allows the 256-pixel tile of the LDS-DMA path
   double flops;        // algorithmic FLOPs of this launch (for the optional event timing)
 };
 
@@ -56,5 +57,7 @@ PackGeom pack_geom(int ic, int taps, bool allow_thin);
 // Chooses the tile for a problem; fills n_pix_tiles / n_oc_tiles / ksplit and the class tile prefix in p.tt.
 void plan_gather(GatherParams& p, GatherLaunch& l);
 int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t stream);
+// LDS-DMA fast path: bf16 input, vector-aligned channels, 64- or 128-channel tile, no reduction split.
+int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 
 }  // namespace gc

@@ -374,6 +374,12 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   l.to = p.OC <= 16 ? 16 : (p.OC <= 64 ? 64 : 128);
   l.tp = l.to == 16 ? 256 : 128;
   p.n_oc_tiles = (p.OC + l.to - 1) / l.to;
+  // LDS-DMA path, large problems: 128 channels x 256 pixels per 8-wave workgroup (one per CU, three-deep ring)
+  if (l.in_bf16 && l.mode == kVecLoads && l.to == 128 && l.big_tile_ok) {
+    long pix = 0;
+    for (int c = 0; c < p.tt.n_classes; c++) pix += (long)p.N * p.tt.cls_oh[c] * p.tt.cls_ow[c];
+    if ((pix / 256) * p.n_oc_tiles >= 1024) l.tp = 256;
+  }
   int tiles = 0, min_steps = 1 << 30;
   for (int c = 0; c < p.tt.n_classes; c++) {
     p.tt.cls_tile_start[c] = tiles;
@@ -415,7 +421,7 @@ static int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
     if (check_hip(hipMemsetAsync(p.out, 0, bytes, stream), "hipMemsetAsync")) return GC_HIP_ERROR;
   }
   const unsigned nblocks = (unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles * (unsigned)p.ksplit;
-  char name[64];  // the demangled kernel name as a profiler prints it
+  char name[96];  // the demangled kernel name as a profiler prints it
   snprintf(name, sizeof(name), "gc::conv_gather_kernel<%s, %d, %d, %s, %d>", sizeof(TIn) == 4 ? "float" : "unsigned short", TO, TP,
            X3 ? "true" : "false", MODE);
   ProfScope ps(name, flops, stream);

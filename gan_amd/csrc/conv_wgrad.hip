@@ -312,7 +312,7 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l) {
 
 template <typename T, int TO, int TC, bool X3, bool ALIGNED, bool THIN>
 static int launch_one(const WgradParams& p, double flops, hipStream_t stream) {
-  char name[64];
+  char name[96];
   snprintf(name, sizeof(name), "gc::conv_wgrad_kernel<%s, %d, %d, %s, %s, %s>", sizeof(T) == 4 ? "float" : "unsigned short", TO, TC,
            X3 ? "true" : "false", ALIGNED ? "true" : "false", THIN ? "true" : "false");
   ProfScope ps(name, flops, stream);

@@ -135,8 +135,8 @@ static int validate(const gc_conv_desc* d) {
     set_error("Ho/Wo (%d,%d) do not match the convolution of H/W (%d,%d): expected (%d,%d)", d->Ho, d->Wo, d->H, d->W, ho_full, wo_full);
     return GC_BAD_DESC;
   }
-  if (d->x_dtype != d->y_dtype) { set_error("mixed activation dtypes are not supported"); return GC_UNSUPPORTED_GEOMETRY; }
-  if (d->precision == GC_PREC_F32X3 && d->x_dtype != GC_F32) { set_error("GC_PREC_F32X3 needs fp32 activations"); return GC_UNSUPPORTED_GEOMETRY; }
+  // mixed dtypes: only "bf16 read, fp32 written" (checked per pass, see pass_dtypes)
+  if (d->precision == GC_PREC_F32X3 && (d->x_dtype != GC_F32 || d->y_dtype != GC_F32)) { set_error("GC_PREC_F32X3 needs fp32 activations"); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->kh * d->kw > kMaxTaps) { set_error("filters larger than %d taps are not supported", kMaxTaps); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->stride_h * d->stride_w > 4) { set_error("stride %dx%d is not supported", d->stride_h, d->stride_w); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->H >= 32768 || d->W >= 32768) { set_error("spatial extent too large"); return GC_UNSUPPORTED_GEOMETRY; }
@@ -153,6 +153,30 @@ static inline int x_cs(const gc_conv_desc* d) { return d->x_cstride ? d->x_cstri
 static inline int y_cs(const gc_conv_desc* d) { return d->y_cstride ? d->y_cstride : d->Cout; }
 static inline int elems_per_chunk(int dtype) { return dtype == GC_BF16 ? 8 : 4; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Input / output dtype of a pass and whether the combination is one the kernels implement.
+static int pass_dtypes(const gc_conv_desc* d, int pass, int* in_dt, int* out_dt) {
+  *in_dt = pass == GC_PASS_FPROP ? d->x_dtype : d->y_dtype;
+  *out_dt = pass == GC_PASS_FPROP ? d->y_dtype : d->x_dtype;
+  if (pass == GC_PASS_WGRAD) {
+    if (d->x_dtype != d->y_dtype) { set_error("wgrad needs x and gy of one dtype"); return GC_UNSUPPORTED_GEOMETRY; }
+    return GC_OK;
+  }
+  if (*in_dt == GC_F32 && *out_dt == GC_BF16) { set_error("fp32 input with bf16 output is not supported"); return GC_UNSUPPORTED_GEOMETRY; }
+  return GC_OK;
+}
+
+static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream) {
+  l.big_tile_ok = true;
+  plan_gather(p, l);
+  const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 128 || l.to == 64);
+  if (dma) return launch_gather_dma(p, l, out_dt == GC_F32, stream);
+  if (l.in_bf16 != (out_dt == GC_BF16)) {
+    set_error("bf16 input with fp32 output needs channel counts that are multiples of 8 (and more than 32)");
+    return GC_UNSUPPORTED_GEOMETRY;
+  }
+  return launch_gather(p, l, stream);
+}
 
 static double conv_flops(const gc_conv_desc* d) {
   return 2.0 * d->N * d->Ho * d->Wo * (double)d->Cout * d->Cin * d->kh * d->kw;
@@ -264,10 +288,11 @@ int gc_conv2d_fprop(const gc_conv_desc* d, const void* x, const void* packed_w, 
   const bool vec = aligned16(x) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
   l.mode = g.thin ? kThinInput : (vec ? kVecLoads : kElemLoads);
   for (p.icp_log2 = 0; (1 << p.icp_log2) < g.icp; p.icp_log2++) {}
-  p.out_vec = (reinterpret_cast<uintptr_t>(y) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
-  plan_gather(p, l);
+  int in_dt, out_dt;
+  if ((rc = pass_dtypes(d, GC_PASS_FPROP, &in_dt, &out_dt)) != GC_OK) return rc;
+  p.out_vec = (reinterpret_cast<uintptr_t>(y) % (out_dt == GC_BF16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
   l.flops = conv_flops(d);
-  return launch_gather(p, l, (hipStream_t)stream);
+  return run_gather(p, l, out_dt, (hipStream_t)stream);
 }
 
 int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w, void* gx, const gc_epilogue* ep, void* stream) {
@@ -314,10 +339,11 @@ int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w,
   const bool vec = aligned16(gy) && (p.in_cstride % epc == 0) && (p.in_coff % epc == 0) && (p.IC % epc == 0);
   l.mode = g.thin ? kThinInput : (vec ? kVecLoads : kElemLoads);
   for (p.icp_log2 = 0; (1 << p.icp_log2) < g.icp; p.icp_log2++) {}
-  p.out_vec = (reinterpret_cast<uintptr_t>(gx) % (l.in_bf16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
-  plan_gather(p, l);
+  int in_dt, out_dt;
+  if ((rc = pass_dtypes(d, GC_PASS_DGRAD, &in_dt, &out_dt)) != GC_OK) return rc;
+  p.out_vec = (reinterpret_cast<uintptr_t>(gx) % (out_dt == GC_BF16 ? 8 : 16) == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0);
   l.flops = conv_flops(d);
-  return launch_gather(p, l, (hipStream_t)stream);
+  return run_gather(p, l, out_dt, (hipStream_t)stream);
 }
 
 static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l) {
@@ -400,7 +426,7 @@ int gc_profile_enable(int on) {
   return GC_OK;
 }
 
-int gc_profile_collect(int max_entries, char names[][64], int64_t* launches, double* total_ms, double* flops) {
+int gc_profile_collect(int max_entries, char names[][96], int64_t* launches, double* total_ms, double* flops) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   int n = 0;
   for (auto& r : g_prof) {
@@ -408,10 +434,10 @@ int gc_profile_collect(int max_entries, char names[][64], int64_t* launches, dou
     if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
       int i = 0;
       for (; i < n; i++)
-        if (strncmp(names[i], r.name.c_str(), 63) == 0) break;
+        if (strncmp(names[i], r.name.c_str(), 95) == 0) break;
       if (i == n && n < max_entries) {
-        strncpy(names[n], r.name.c_str(), 63);
-        names[n][63] = 0;
+        strncpy(names[n], r.name.c_str(), 95);
+        names[n][95] = 0;
         launches[n] = 0; total_ms[n] = 0.0; flops[n] = 0.0;
         n++;
       }

@@ -12,6 +12,7 @@ import math
 import torch
 
 from .. import nn as gnn
+from .. import ops as gops
 
 
 def _seq(*m):
@@ -200,6 +201,7 @@ class WganGpTrainer:
             self.red_G.finish()
         self.opt_G.step()
         out.append(g_err)
+        gops.clear_cast_cache()
         self.last = torch.stack([o.reshape(()) for o in out])
         return self.last
 

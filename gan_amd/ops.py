@@ -79,13 +79,45 @@ def _nhwc(t):
     return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
 
 
-def _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, dtype_code, precision):
+def _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, dtype_code, precision, y_dtype_code=None):
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
     d.kh, d.kw, d.stride_h, d.stride_w, d.pad_h, d.pad_w = kh, kw, stride, stride, padding, padding
-    d.x_dtype = d.y_dtype = dtype_code
-    d.precision = precision if dtype_code == _lib.GC_F32 else _lib.GC_PREC_BF16
+    d.x_dtype = dtype_code
+    d.y_dtype = dtype_code if y_dtype_code is None else y_dtype_code
+    d.precision = precision if (d.x_dtype == _lib.GC_F32 and d.y_dtype == _lib.GC_F32) else _lib.GC_PREC_BF16
     return d
+
+
+# ---- bf16 operand copies ------------------------------------------------------------------------------------------
+# In the bf16 arithmetic mode the kernels round their fp32 operands to bf16 anyway.  Wide layers run faster when that
+# rounding is done once per tensor (16-byte LDS-DMA loads of bf16 straight into LDS, half the bytes) instead of in
+# every kernel that reads it: an activation is read by the forward conv and by the weight-gradient conv, a gradient
+# by the data-gradient and the weight-gradient conv.  The cache entry keeps the source tensor alive, so its address
+# cannot be re-used by another tensor while the entry exists; a version bump (in-place write) misses.
+_cast_cache = {}
+_CAST_CACHE_MAX = 48
+
+
+def clear_cast_cache():
+    _cast_cache.clear()
+
+
+def _to_bf16(t):
+    key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
+    ent = _cast_cache.get(key)
+    if ent is not None:
+        return ent[1]
+    tb = t.to(torch.bfloat16, memory_format=torch.channels_last)
+    if len(_cast_cache) >= _CAST_CACHE_MAX:
+        _cast_cache.pop(next(iter(_cast_cache)))
+    _cast_cache[key] = (t, tb)
+    return tb
+
+
+def _dma_ok(t, ic, oc, precision):
+    """fp32 activation in bf16 mode whose conv qualifies for the LDS-DMA kernel (bf16 in, fp32 out)."""
+    return precision == _lib.GC_PREC_BF16 and t.dtype == torch.float32 and ic % 8 == 0 and ic > 32 and oc > 16
 
 
 def _packed(desc, w, pass_, wkey):
@@ -132,7 +164,11 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
     x = _nhwc(x)
     y = torch.empty((N, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
+    if _dma_ok(x, Cin, Cout, precision):
+        x = _to_bf16(x)
+        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _lib.GC_BF16, precision, _lib.GC_F32)
+    else:
+        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
     wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey)
     ep, keep = _epilogue(bias)
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
@@ -162,7 +198,11 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
         raise RuntimeError(f"ganconv: input size ({H}x{W}) is inconsistent with the gradient's ({Ho}x{Wo})")
     gy = _nhwc(gy)
     gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
-    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gy), precision)
+    if _dma_ok(gy, Cout, Cin, precision):
+        gy = _to_bf16(gy)
+        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _lib.GC_F32, precision, _lib.GC_BF16)
+    else:
+        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gy), precision)
     wp = _packed(d, w, _lib.GC_PASS_DGRAD, wkey)
     ep, keep = _epilogue(bias)
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
@@ -187,6 +227,8 @@ def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: in
     if x.dtype != gy.dtype:
         gy = gy.to(x.dtype)
     x, gy = _nhwc(x), _nhwc(gy)
+    if precision == _lib.GC_PREC_BF16 and x.dtype == torch.float32:
+        x, gy = _to_bf16(x), _to_bf16(gy)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
     L = _lib.lib()
     gw = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)

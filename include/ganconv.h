@@ -151,7 +151,7 @@ int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, flo
  * the caller's arrays (at most max_entries) and resets the records.  flops[] holds the algorithmic FLOPs
  * (2 * MACs, necessary taps only) of the launches counted in launches[]. */
 int gc_profile_enable(int on);
-int gc_profile_collect(int max_entries, char names[][64], int64_t* launches, double* total_ms, double* flops);
+int gc_profile_collect(int max_entries, char names[][96], int64_t* launches, double* total_ms, double* flops);
 
 #ifdef __cplusplus
 }

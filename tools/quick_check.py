@@ -35,5 +35,20 @@ for prec_name in ("fp32x3", "bf16"):
         flag = "" if max(e) < tol else "  <-- FAIL"
         bad += max(e) >= tol
         print(f"{prec_name:7s} N{N} C{Cin}->{Cout} {H}x{W} k{k}s{s}p{p}: fprop {e[0]:.2e} dgrad {e[1]:.2e} wgrad {e[2]:.2e}{flag}")
+# bf16 storage (LDS-DMA fast path where channels allow): compare against CPU conv on the same bf16-rounded inputs
+for (N, Cin, H, W, Cout, k, s, p) in CASES:
+    prec = _lib.GC_PREC_BF16
+    x = torch.randn(N, Cin, H, W).bfloat16(); w = (torch.randn(Cout, Cin, k, k) * 0.1).bfloat16().float(); b = torch.randn(Cout)
+    y = TF.conv2d(x.float(), w, b, s, p); gy = torch.randn_like(y).bfloat16()
+    gx = torch.nn.grad.conv2d_input(x.shape, w, gy.float(), s, p)
+    gw = torch.nn.grad.conv2d_weight(x.float(), w.shape, gy.float(), s, p)
+    y2 = ops.conv_fprop(x.cuda(), w.cuda(), b.cuda(), s, p, prec, 0)
+    gx2 = ops.conv_dgrad(gy.cuda(), w.cuda(), None, H, W, s, p, prec, 0)
+    gw2 = ops.conv_wgrad(x.cuda(), gy.cuda(), k, k, s, p, prec)
+    torch.cuda.synchronize()
+    e = (rel(y2.float(), y), rel(gx2.float(), gx), rel(gw2, gw))
+    flag = "" if max(e) < 4e-3 else "  <-- FAIL"
+    bad += max(e) >= 4e-3
+    print(f"bf16io  N{N} C{Cin}->{Cout} {H}x{W} k{k}s{s}p{p}: fprop {e[0]:.2e} dgrad {e[1]:.2e} wgrad {e[2]:.2e}{flag}")
 print("FAILURES:", bad)
 sys.exit(1 if bad else 0)
