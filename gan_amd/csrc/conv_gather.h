@@ -34,7 +34,10 @@ struct GatherParams {
   int32_t icp_log2;    // log2(ICp) in the thin-input mode (reduction over (tap, channel) jointly, 64 per step)
   int32_t ksplit;      // > 1: the reduction is split over ksplit workgroups that add into a zeroed fp32 output
   int32_t n_pix_tiles, n_oc_tiles;
+  int32_t cls_interleave;  // 1: pixel tiles are ordered (tile, class) so that the classes sharing input rows run side by side
   int64_t plane_stride;  // elements between the hi and lo planes of wp
+  int64_t in_bytes, w_bytes;  // extents of the input tensor and the packed weights (LDS-DMA path: buffer ranges)
+  int32_t a_bias;        // LDS-DMA path: bytes by which the activation buffer starts before `in` (most negative tap offset)
   TapTable tt;
 };
 

@@ -17,6 +17,7 @@
 // Small problems (few tiles, long reduction: 4x4 -> 1x1 "full window" layers) split the reduction over several
 // workgroups that add their partial tiles into a zeroed fp32 output.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "conv_gather.h"
 
@@ -60,11 +61,16 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
   lid /= p.ksplit;
   const int pix_tile = lid / p.n_oc_tiles;
   const int oc0 = (lid % p.n_oc_tiles) * TO;
-  int cls = 0;
+  int cls = 0, m0;
+  if (p.cls_interleave) {   // equal-sized classes: (tile, class) order, the classes of one image region are neighbours
+    cls = pix_tile % p.tt.n_classes;
+    m0 = (pix_tile / p.tt.n_classes) * TP;
+  } else {
 #pragma unroll
-  for (int c = 1; c < kMaxClasses; c++)
-    if (c < p.tt.n_classes && pix_tile >= p.tt.cls_tile_start[c]) cls = c;
-  const int m0 = (pix_tile - p.tt.cls_tile_start[cls]) * TP;
+    for (int c = 1; c < kMaxClasses; c++)
+      if (c < p.tt.n_classes && pix_tile >= p.tt.cls_tile_start[c]) cls = c;
+    m0 = (pix_tile - p.tt.cls_tile_start[cls]) * TP;
+  }
   const int OHc = p.tt.cls_oh[cls], OWc = p.tt.cls_ow[cls];
   const int Mc = p.N * OHc * OWc;
   const int tap_begin = p.tt.cls_tap_start[cls], tap_end = p.tt.cls_tap_start[cls + 1];
@@ -373,6 +379,11 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   // 16-channel tile (thin outputs such as RGB images or critic scores).
   l.to = p.OC <= 16 ? 16 : (p.OC <= 64 ? 64 : 128);
   l.tp = l.to == 16 ? 256 : 128;
+  if (l.to == 128) {   // too few 128-channel tiles to cover the CUs: halve the channel tile
+    long pix_tiles = 0;
+    for (int c = 0; c < p.tt.n_classes; c++) pix_tiles += ((long)p.N * p.tt.cls_oh[c] * p.tt.cls_ow[c] + l.tp - 1) / l.tp;
+    if (pix_tiles * ((p.OC + 127) / 128) <= 300) l.to = 64;
+  }
   p.n_oc_tiles = (p.OC + l.to - 1) / l.to;
   // LDS-DMA path, large problems: 128 channels x 256 pixels per 8-wave workgroup (one per CU, three-deep ring)
   if (l.in_bf16 && l.mode == kVecLoads && l.to == 128 && l.big_tile_ok) {
@@ -391,6 +402,13 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   }
   for (int c = p.tt.n_classes; c <= kMaxClasses; c++) p.tt.cls_tile_start[c] = tiles;
   p.n_pix_tiles = tiles;
+  p.cls_interleave = 0;
+  if (p.tt.n_classes > 1) {
+    p.cls_interleave = 1;
+    const int per = p.tt.cls_tile_start[1] - p.tt.cls_tile_start[0];
+    for (int c = 1; c < p.tt.n_classes; c++)
+      if (p.tt.cls_tile_start[c + 1] - p.tt.cls_tile_start[c] != per) p.cls_interleave = 0;
+  }
   // Split the reduction when the grid cannot fill the chip and the output can take fp32 adds.
   p.ksplit = 1;
   const long blocks = (long)tiles * p.n_oc_tiles;

@@ -1,20 +1,23 @@
 // Fast path of the gather-GEMM convolution (forward and data gradient) for bf16 activations whose channel count
-// is a multiple of 8: both operands go global -> LDS directly (LDS-DMA, `global_load_lds_dwordx4`), no register
+// is a multiple of 8: both operands go global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`), no register
 // staging, no conversion, no LDS writes by the waves.  Same tile geometry, LDS image (128-byte rows, 16-byte
 // chunks XOR-swizzled by (row >> 1) & 7) and MFMA loop as conv_gather_kernel; the swizzle is applied on the
-// per-lane SOURCE address because an LDS-DMA wave-instruction writes 1 KiB linearly (8 rows x 128 bytes).
+// per-lane SOURCE offset because an LDS-DMA wave-instruction writes 1 KiB linearly (8 rows x 128 bytes).
+//
+// Addressing is kept off the vector ALU: a lane's byte offset into the activation tensor is fixed for the whole
+// kernel, the filter tap and channel step move only the scalar offset of the buffer instruction, and a lane whose
+// pixel falls into the zero padding (or past the end of the tile) swaps its offset for one beyond the buffer's
+// range, which the hardware answers with zeros.  Both tensors therefore have to be smaller than 2 GiB.
 //
 // A ring of STAGES LDS buffers keeps STAGES-1 reduction steps in flight: the loads of step k+STAGES-1 are issued
 // before the MFMAs of step k, a counted `s_waitcnt vmcnt` retires only the oldest step, and one raw `s_barrier`
 // per step both publishes the landed tile and frees the buffer that was just consumed.
-// Pixels outside the image (zero padding) and channels past the end read from a small zero block instead.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "conv_gather.h"
 
 namespace gc {
-
-__device__ __attribute__((aligned(16))) const uint32_t g_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
 template <int TO, int TP, int NW>
 struct DmaCfg {
@@ -27,17 +30,12 @@ struct DmaCfg {
 __device__ __forceinline__ int dswz(int row) { return (row >> 1) & 7; }
 
 template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+__device__ __forceinline__ void wait_vmcnt() {   // s_waitcnt vmcnt(N) alone (expcnt / lgkmcnt fields at "no wait")
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr uint32_t kOutOfRange = 0x80000000u;   // beyond any buffer this kernel accepts: the load returns zeros
 
 template <typename TOut, int TO, int TP, int STAGES, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherParams p) {
@@ -58,68 +56,90 @@ __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherPa
   const uint32_t lid = xcd_remap(blockIdx.x, nblocks);
   const int pix_tile = lid / p.n_oc_tiles;
   const int oc0 = (lid % p.n_oc_tiles) * TO;
-  int cls = 0;
+  int cls = 0, m0;
+  if (p.cls_interleave) {   // equal-sized classes: (tile, class) order, the classes of one image region are neighbours
+    cls = pix_tile % p.tt.n_classes;
+    m0 = (pix_tile / p.tt.n_classes) * TP;
+  } else {
 #pragma unroll
-  for (int c = 1; c < kMaxClasses; c++)
-    if (c < p.tt.n_classes && pix_tile >= p.tt.cls_tile_start[c]) cls = c;
-  const int m0 = (pix_tile - p.tt.cls_tile_start[cls]) * TP;
+    for (int c = 1; c < kMaxClasses; c++)
+      if (c < p.tt.n_classes && pix_tile >= p.tt.cls_tile_start[c]) cls = c;
+    m0 = (pix_tile - p.tt.cls_tile_start[cls]) * TP;
+  }
   const int OHc = p.tt.cls_oh[cls], OWc = p.tt.cls_ow[cls];
   const int Mc = p.N * OHc * OWc;
   const int tap_begin = p.tt.cls_tap_start[cls], tap_end = p.tt.cls_tap_start[cls + 1];
 
+  // The activation descriptor starts a_bias bytes before the tensor so that every tap's scalar offset is >= 0.
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.in)) - p.a_bias, 0, (int)(p.in_bytes + p.a_bias), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wp), 0, (int)p.w_bytes, 0x00020000);
+
   // ---- this lane's rows: wave-instruction j of this wave covers tile rows (wave*J + j)*8 .. +7, lane>>3 picks the row
   const int sub_row = lane >> 3, pos = lane & 7;
-  int a_base[AJ], a_ih[AJ], a_iw[AJ], a_chunk[AJ];
-  bool a_ok[AJ];
+  uint32_t a_off[AJ];          // byte offset of (pixel at tap offset (0,0), source chunk) in the activation tensor
+  int a_ih[AJ], a_iw[AJ];      // input coordinates at tap offset (0,0); far negative for rows past the end of the class
+  int a_chunk[AJ];             // first channel of the source chunk (for the check against the channel count)
 #pragma unroll
   for (int j = 0; j < AJ; j++) {
     const int row = (wave * AJ + j) * 8 + sub_row;
     const int m = m0 + row;
-    a_ok[j] = m < Mc;
-    const int mm = a_ok[j] ? m : 0;
+    const bool ok = m < Mc;
+    const int mm = ok ? m : 0;
     const int ow = mm % OWc, tmp = mm / OWc;
     const int oh = tmp % OHc, n = tmp / OHc;
-    a_base[j] = n * p.IH * p.IW;
-    a_ih[j] = oh * p.a;
+    a_ih[j] = ok ? oh * p.a : -(1 << 20);
     a_iw[j] = ow * p.a;
     a_chunk[j] = (pos ^ dswz(row)) * 8;        // source chunk (elements) that lands at LDS position `pos` of this row
+    a_off[j] = (uint32_t)((((size_t)n * p.IH + oh * p.a) * p.IW + ow * p.a) * p.in_cstride + p.in_coff + a_chunk[j]) * 2u;
   }
-  size_t w_off[WJ];
-  int w_chunk[WJ];
-  bool w_ok[WJ];
+  uint32_t w_voff[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; j++) {
     const int row = (wave * WJ + j) * 8 + sub_row;
     const int oc = oc0 + row;
-    w_ok[j] = oc < p.OC;
-    w_off[j] = (size_t)(w_ok[j] ? oc : 0) * p.row_pitch;
-    w_chunk[j] = (pos ^ dswz(row)) * 8;
+    w_voff[j] = oc < p.OC ? (uint32_t)(((size_t)oc * p.row_pitch + (pos ^ dswz(row)) * 8) * 2) : kOutOfRange;
   }
-  const uint16_t* in = reinterpret_cast<const uint16_t*>(p.in);
-  const void* zeros = g_zero_chunk;
 
-  // The tap table is read through LDS inside the loop: an ordinary global load there would make the compiler
-  // drain the in-flight LDS-DMA (vmcnt(0)) before using its result.
+  // The tap table is read through LDS: an ordinary global load inside the loop would make the compiler drain the
+  // in-flight LDS-DMA (vmcnt(0)) before using its result.
   int* tap_lds = reinterpret_cast<int*>(smem + STAGES * STAGE);
   if (t < kMaxTaps) tap_lds[t] = ((int)p.tt.dh[t] & 0xff) | (((int)p.tt.dw[t] & 0xff) << 8) | ((int)p.tt.wtap[t] << 16);
   __syncthreads();
 
-  auto issue = [&](int stage, int tap, int c0) {
-    const int e = __builtin_amdgcn_readfirstlane(tap_lds[tap]);
-    const int dh = (int)(int8_t)(e & 0xff), dw = (int)(int8_t)((e >> 8) & 0xff), wt = e >> 16;
+  // ---- issue side: position (tap, cs) of the next step to load, with the tap's scalars decoded once per tap
+  const int csteps = p.ICp / kBK;
+  const int nsteps = (tap_end - tap_begin) * csteps;
+  int tap = tap_begin, cs = 0;
+  int s_dh = 0, s_dw = 0;
+  uint32_t s_aoff = 0, s_woff = 0;
+  auto load_tap = [&](int tp) {
+    const int e = __builtin_amdgcn_readfirstlane(tap_lds[tp]);
+    s_dh = (int)(int8_t)(e & 0xff);
+    s_dw = (int)(int8_t)((e >> 8) & 0xff);
+    s_aoff = (uint32_t)(((s_dh * p.IW + s_dw) * p.in_cstride) * 2 + p.a_bias);
+    s_woff = (uint32_t)((e >> 16) * p.ICp * 2);
+  };
+  auto issue = [&](int stage) {
     char* wb = smem + stage * STAGE;
     char* ab = wb + W_BYTES;
+    const int c0 = cs * kBK;
 #pragma unroll
-    for (int j = 0; j < WJ; j++) {
-      const void* src = w_ok[j] ? (const void*)(p.wp + w_off[j] + wt * p.ICp + c0 + w_chunk[j]) : zeros;
-      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wb + (wave * WJ + j) * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < WJ; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(wb + (wave * WJ + j) * 1024), 16, (int)w_voff[j],
+                                               (int)(s_woff + c0 * 2), 0, 0);
 #pragma unroll
     for (int j = 0; j < AJ; j++) {
-      const int ih = a_ih[j] + dh, iw = a_iw[j] + dw;
-      const bool ok = a_ok[j] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW && (c0 + a_chunk[j] < p.IC);
-      const void* src = ok ? (const void*)(in + ((size_t)(a_base[j] + ih * p.IW + iw) * p.in_cstride + p.in_coff + c0 + a_chunk[j])) : zeros;
-      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(ab + (wave * AJ + j) * 1024), 16, 0, 0);
+      // (bitwise on purpose: a short-circuit would turn into exec-mask branches)
+      const bool ok = ((unsigned)(a_ih[j] + s_dh) < (unsigned)p.IH) & ((unsigned)(a_iw[j] + s_dw) < (unsigned)p.IW) &
+                      ((c0 | a_chunk[j]) < p.IC);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(ab + (wave * AJ + j) * 1024), 16,
+                                               (int)(ok ? a_off[j] : kOutOfRange), (int)(s_aoff + c0 * 2), 0, 0);
+    }
+    if (++cs == csteps) {
+      cs = 0;
+      if (++tap < tap_end) load_tap(tap);
     }
   };
 
@@ -154,28 +174,34 @@ __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherPa
   };
 
   // ---- main loop ---------------------------------------------------------------------------------------
-  const int csteps = p.ICp / kBK;
-  const int nsteps = (tap_end - tap_begin) * csteps;
-  int tap = tap_begin, cs = 0;   // position of the NEXT step to issue
-  int issued = 0;
-  auto issue_next = [&]() {
-    issue(issued % STAGES, tap, cs * kBK);
-    issued++;
-    if (++cs == csteps) { cs = 0; tap++; }
-  };
+  int issued = 0, st_i = 0, st_c = 0;
+  auto next_stage = [](int s) { return s + 1 == STAGES ? 0 : s + 1; };
+  if (nsteps > 0) load_tap(tap_begin);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; s++)
-    if (issued < nsteps) issue_next();
-  for (int it = 0; it < nsteps; it++) {
-    // retire step `it`: at most the (issued - it - 1) younger steps may stay in flight
-    const int younger = issued - it - 1;
-    if (younger >= 2) wait_vmcnt<2 * LOADS>();
-    else if (younger == 1) wait_vmcnt<LOADS>();
-    else wait_vmcnt<0>();
+    if (issued < nsteps) { issue(st_i); st_i = next_stage(st_i); issued++; }
+  int it = 0;
+  // steady state: STAGES-1 steps are in flight at the top, the oldest of them is step `it`
+  for (; issued < nsteps; it++, issued++) {
+    wait_vmcnt<(STAGES - 2) * LOADS>();
     __builtin_amdgcn_s_barrier();                 // every wave's part of step `it` has landed; step it-1's buffer is free
     __builtin_amdgcn_sched_barrier(0);
-    if (issued < nsteps) issue_next();            // goes into the buffer consumed at step it-1
-    compute(it % STAGES);
+    issue(st_i);                                  // goes into the buffer consumed at step it-1
+    st_i = next_stage(st_i);
+    compute(st_c);
+    st_c = next_stage(st_c);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // drain: nothing left to issue
+  for (; it < nsteps; it++) {
+    const int younger = nsteps - it - 1;
+    if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
+    else if (STAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(st_c);
+    st_c = next_stage(st_c);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -266,7 +292,11 @@ static int launch_dma_one(const GatherParams& p, double flops, hipStream_t strea
 int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t s) {
   if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
   if (l.to == 128 && l.tp == 256) return out_f32 ? launch_dma_one<float, 128, 256, 3, 8>(p, l.flops, s) : launch_dma_one<uint16_t, 128, 256, 3, 8>(p, l.flops, s);
+  // At most one workgroup per CU: nothing else hides the load latency, so spend the idle LDS on a deeper ring.
+  const bool deep = (long)p.n_pix_tiles * p.n_oc_tiles <= 256;
+  if (l.to == 128 && deep) return out_f32 ? launch_dma_one<float, 128, 128, 4, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 128, 128, 4, 4>(p, l.flops, s);
   if (l.to == 128) return out_f32 ? launch_dma_one<float, 128, 128, 2, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 128, 128, 2, 4>(p, l.flops, s);
+  if (l.to == 64 && deep) return out_f32 ? launch_dma_one<float, 64, 128, 4, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 64, 128, 4, 4>(p, l.flops, s);
   if (l.to == 64) return out_f32 ? launch_dma_one<float, 64, 128, 2, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 64, 128, 2, 4>(p, l.flops, s);
   set_error("internal: no LDS-DMA variant for this tile");
   return GC_UNSUPPORTED_GEOMETRY;

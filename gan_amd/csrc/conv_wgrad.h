@@ -15,12 +15,14 @@ struct WgradParams {
   int32_t n_co_tiles, n_ci_tiles, splits;
   int32_t thin;          // 1: Cin <= 32; the tile's columns run over (tap, channel) jointly, channel padded to ICp
   int32_t ICp, icp_log2, ncols;   // thin mode: padded channels per tap, its log2, T * ICp
+  int32_t n_tap_groups, tpt, cw_log2;   // LDS-DMA kernel: a 128-column tile holds tpt taps of (1 << cw_log2) channels
   FastDiv div_wo, div_ho;
 };
 
 struct WgradLaunch {
   int to, tc;
   bool bf16, x3, aligned;
+  bool dma;   // planned for the LDS-DMA kernel (bf16 operands, channel counts and strides multiples of 8, Cin > 32)
   double flops;
 };
 
@@ -34,8 +36,9 @@ struct WgradReduceParams {
   int32_t thin, ICp;     // layout of part: [split][tap][Cout][Cin], or thin: [split][Cout][tap][ICp]
 };
 
-void plan_wgrad(WgradParams& p, WgradLaunch& l);
+void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma);
 int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
+int launch_wgrad_dma(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream);
 int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream);
 

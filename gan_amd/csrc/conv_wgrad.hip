@@ -40,10 +40,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wo = wave >> 1, wc = wave & 1;
-  const int tile = blockIdx.x;
+  // Logical order (tile, tap) fastest, split slowest, dealt to the XCDs in contiguous runs: the workgroups of one
+  // split read the same pixels of gy and x, so they should meet in one L2.
+  const uint32_t ntiles = (uint32_t)p.n_co_tiles * (uint32_t)p.n_ci_tiles, ntaps = THIN ? 1u : (uint32_t)(p.kh * p.kw);
+  uint32_t lid = xcd_remap(blockIdx.x, ntiles * ntaps * (uint32_t)p.splits);
+  const int tile = (int)(lid % ntiles);
+  lid /= ntiles;
+  const int tap = (int)(lid % ntaps), r = tap / p.kw, s = tap % p.kw;
+  const int split = (int)(lid / ntaps);
   const int co0 = (tile / p.n_ci_tiles) * TO, ci0 = (tile % p.n_ci_tiles) * TC;
-  const int tap = THIN ? 0 : blockIdx.y, r = tap / p.kw, s = tap % p.kw;
-  const int split = blockIdx.z;
   const int kb0 = split * p.k_per_split;
   const int kend = min(p.K, kb0 + p.k_per_split);
 
@@ -222,35 +227,51 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
 }
 
 // Sums the split-K partials in a fixed order, scales and scatters into the caller's weight-gradient layout.
-// Workgroup = 64 consecutive partial elements x 4 split lanes (reads coalesced along the partial layout).
+// Workgroup = 64 runs of V consecutive partial elements x 4 split lanes; each lane keeps four loads in flight.
+template <int V>
 __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const WgradReduceParams p) {
-  __shared__ float red[kThreads];
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  __shared__ vec_t red[kThreads];
   const int T = p.kh * p.kw;
   const int inner = p.thin ? p.ICp : p.Cin;
   const size_t total = (size_t)T * p.Cout * inner;      // elements of one partial slab
-  const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const size_t e0 = ((size_t)blockIdx.x * 64 + (threadIdx.x & 63)) * V;
   const int sl = threadIdx.x >> 6;
-  float sum = 0.f;
-  if (e < total)
-    for (int sp = sl; sp < p.splits; sp += 4) sum += p.part[(size_t)sp * total + e];
+  vec_t sum = 0.f;
+  if (e0 < total) {
+    const float* src = p.part + e0;
+    int sp = sl;
+    for (; sp + 12 < p.splits; sp += 16) {
+      const vec_t v0 = *reinterpret_cast<const vec_t*>(src + (size_t)sp * total);
+      const vec_t v1 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 4) * total);
+      const vec_t v2 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 8) * total);
+      const vec_t v3 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 12) * total);
+      sum += (v0 + v1) + (v2 + v3);
+    }
+    for (; sp < p.splits; sp += 4) sum += *reinterpret_cast<const vec_t*>(src + (size_t)sp * total);
+  }
   red[threadIdx.x] = sum;
   __syncthreads();
-  if (sl != 0 || e >= total) return;
+  if (sl != 0 || e0 >= total) return;
   sum = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192];
-  int co, ci, tap;
-  if (p.thin) {          // [Cout][tap][ICp]
-    ci = (int)(e % p.ICp);
-    tap = (int)((e / p.ICp) % T);
-    co = (int)(e / ((size_t)p.ICp * T));
-    if (ci >= p.Cin) return;
-  } else {               // [tap][Cout][Cin]
-    ci = (int)(e % p.Cin);
-    co = (int)((e / p.Cin) % p.Cout);
-    tap = (int)(e / ((size_t)p.Cin * p.Cout));
+#pragma unroll
+  for (int q = 0; q < V; q++) {
+    const size_t e = e0 + q;
+    int co, ci, tap;
+    if (p.thin) {          // [Cout][tap][ICp]
+      ci = (int)(e % p.ICp);
+      tap = (int)((e / p.ICp) % T);
+      co = (int)(e / ((size_t)p.ICp * T));
+      if (ci >= p.Cin) continue;
+    } else {               // [tap][Cout][Cin]
+      ci = (int)(e % p.Cin);
+      co = (int)((e / p.Cin) % p.Cout);
+      tap = (int)(e / ((size_t)p.Cin * p.Cout));
+    }
+    float* dst = p.gw + co * p.s_co + ci * p.s_ci + (tap / p.kw) * p.s_r + (tap % p.kw) * p.s_s;
+    const float v = p.alpha * sum[q];
+    *dst = p.accumulate ? *dst + v : v;
   }
-  float* dst = p.gw + co * p.s_co + ci * p.s_ci + (tap / p.kw) * p.s_r + (tap % p.kw) * p.s_s;
-  const float v = p.alpha * sum;
-  *dst = p.accumulate ? *dst + v : v;
 }
 
 // gb[c] += sum over pixels of gy[k][c]; gb is zeroed by the launcher.  One block sums a run of pixels.
@@ -281,10 +302,20 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(const T* gy, float* gb
 }
 
 // ---------------------------------------------------------------------------------------------------------
-void plan_wgrad(WgradParams& p, WgradLaunch& l) {
+void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
   l.to = p.Cout <= 64 ? 64 : 128;
   p.thin = p.Cin <= 32;
-  if (p.thin) {
+  p.n_tap_groups = p.kh * p.kw; p.tpt = 1; p.cw_log2 = 7;
+  l.dma = allow_dma && l.bf16 && !l.x3 && !p.thin && p.Cin % 8 == 0 && p.Cout % 8 == 0 && p.x_cstride % 8 == 0 &&
+          p.x_coff % 8 == 0 && p.y_cstride % 8 == 0 && p.y_coff % 8 == 0;
+  if (l.dma) {
+    l.tc = 128;
+    if (p.Cin <= 64) {   // two taps of up to 64 channels share one tile (and its gy panel)
+      p.cw_log2 = 6; p.tpt = 2; p.n_ci_tiles = 1; p.n_tap_groups = (p.kh * p.kw + 1) / 2;
+    } else {
+      p.n_ci_tiles = (p.Cin + 127) / 128;
+    }
+  } else if (p.thin) {
     p.ICp = 4;
     while (p.ICp < p.Cin) p.ICp *= 2;
     for (p.icp_log2 = 0; (1 << p.icp_log2) < p.ICp; p.icp_log2++) {}
@@ -296,7 +327,7 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l) {
     p.n_ci_tiles = (p.Cin + l.tc - 1) / l.tc;
   }
   p.n_co_tiles = (p.Cout + l.to - 1) / l.to;
-  const long tiles = (long)p.n_co_tiles * p.n_ci_tiles * (p.thin ? 1 : p.kh * p.kw);
+  const long tiles = (long)p.n_co_tiles * p.n_ci_tiles * (p.thin ? 1 : p.n_tap_groups);
   if (p.K <= 0) { p.k_per_split = kWBK; p.splits = 1; return; }
   // enough splits for about two workgroups per CU, each split at least 8 reduction steps long
   long want = (2 * 256 + tiles - 1) / tiles;
@@ -317,7 +348,7 @@ static int launch_one(const WgradParams& p, double flops, hipStream_t stream) {
            X3 ? "true" : "false", ALIGNED ? "true" : "false", THIN ? "true" : "false");
   ProfScope ps(name, flops, stream);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, TO, TC, X3, ALIGNED, THIN>),
-                     dim3(p.n_co_tiles * p.n_ci_tiles, THIN ? 1 : p.kh * p.kw, p.splits), dim3(kThreads), 0, stream, p);
+                     dim3((unsigned)(p.n_co_tiles * p.n_ci_tiles * (THIN ? 1 : p.kh * p.kw) * p.splits)), dim3(kThreads), 0, stream, p);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
 }
 
@@ -345,8 +376,13 @@ int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
   const size_t total = (size_t)p.Cout * (p.thin ? p.ICp : p.Cin) * p.kh * p.kw;
   if (total == 0) return GC_OK;
-  const size_t blocks = (total + 63) / 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+  if (total % 4 == 0) {   // slabs stay 16-byte aligned: 4 elements per lane
+    const size_t blocks = (total / 4 + 63) / 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+  } else {
+    const size_t blocks = (total + 63) / 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+  }
   return check_hip(hipGetLastError(), "wgrad_reduce launch");
 }
 

@@ -169,10 +169,21 @@ static int pass_dtypes(const gc_conv_desc* d, int pass, int* in_dt, int* out_dt)
 static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream) {
   l.big_tile_ok = true;
   plan_gather(p, l);
-  const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 128 || l.to == 64);
+  // LDS-DMA path: buffer addressing with 32-bit offsets, so both tensors have to stay below 2 GiB
+  p.in_bytes = (int64_t)p.N * p.IH * p.IW * p.in_cstride * 2;
+  p.w_bytes = (int64_t)p.OC * p.row_pitch * 2;
+  long min_off = 0;
+  for (int e = 0; e < p.tt.cls_tap_start[p.tt.n_classes]; e++) {
+    const long off = ((long)p.tt.dh[e] * p.IW + p.tt.dw[e]) * p.in_cstride * 2;
+    if (off < min_off) min_off = off;
+  }
+  p.a_bias = (int32_t)(-min_off);
+  const int64_t limit = (1ll << 31) - (1 << 20);
+  const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 128 || l.to == 64) &&
+                   p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
   if (dma) return launch_gather_dma(p, l, out_dt == GC_F32, stream);
   if (l.in_bf16 != (out_dt == GC_BF16)) {
-    set_error("bf16 input with fp32 output needs channel counts that are multiples of 8 (and more than 32)");
+    set_error("bf16 input with fp32 output needs channel counts that are multiples of 8 (and more than 32) and tensors below 2 GiB");
     return GC_UNSUPPORTED_GEOMETRY;
   }
   return launch_gather(p, l, stream);
@@ -346,7 +357,7 @@ int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w,
   return run_gather(p, l, out_dt, (hipStream_t)stream);
 }
 
-static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l) {
+static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l, bool allow_dma) {
   memset(&p, 0, sizeof(p));
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
   p.kh = d->kh; p.kw = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
@@ -354,14 +365,25 @@ static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l) {
   p.K = d->N * d->Ho * d->Wo;
   p.div_wo = make_fastdiv((uint32_t)d->Wo); p.div_ho = make_fastdiv((uint32_t)d->Ho);
   l.bf16 = d->x_dtype == GC_BF16; l.x3 = d->precision == GC_PREC_F32X3;
-  plan_wgrad(p, l);
+  plan_wgrad(p, l, allow_dma);
 }
 
+static size_t wgrad_need(const gc_conv_desc* d, const WgradParams& p) {
+  return (size_t)p.splits * d->kh * d->kw * d->Cout * (p.thin ? p.ICp : d->Cin) * sizeof(float);
+}
+
+// The LDS-DMA plan needs 16-byte aligned operands, which only the call knows: the advertised size covers both plans.
 size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
   if (validate(d) != GC_OK) return 0;
   WgradParams p; WgradLaunch l;
-  wgrad_setup(d, p, l);
-  return (size_t)p.splits * d->kh * d->kw * d->Cout * (p.thin ? p.ICp : d->Cin) * sizeof(float);
+  wgrad_setup(d, p, l, true);
+  size_t need = wgrad_need(d, p);
+  if (l.dma) {
+    wgrad_setup(d, p, l, false);
+    const size_t other = wgrad_need(d, p);
+    if (other > need) need = other;
+  }
+  return need;
 }
 
 int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float* gw, const int64_t gw_strides[4], float alpha,
@@ -370,8 +392,8 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   if (rc != GC_OK) return rc;
   if (x == nullptr || gy == nullptr || gw == nullptr || gw_strides == nullptr) { set_error("gc_conv2d_wgrad: null pointer"); return GC_BAD_ARGUMENT; }
   WgradParams p; WgradLaunch l;
-  wgrad_setup(d, p, l);
-  const size_t need = (size_t)p.splits * d->kh * d->kw * d->Cout * (p.thin ? p.ICp : d->Cin) * sizeof(float);
+  wgrad_setup(d, p, l, aligned16(x) && aligned16(gy));
+  const size_t need = wgrad_need(d, p);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("gc_conv2d_wgrad: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
     return GC_WORKSPACE_TOO_SMALL;
@@ -383,7 +405,7 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   const bool y_vec = aligned16(gy) && (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
   l.aligned = y_vec && (p.thin || x_vec);
   l.flops = conv_flops(d);
-  if ((rc = launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
+  if ((rc = l.dma ? launch_wgrad_dma(p, l, (hipStream_t)stream) : launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
   WgradReduceParams r;
   r.part = p.part; r.gw = gw;
   r.s_co = gw_strides[0]; r.s_ci = gw_strides[1]; r.s_r = gw_strides[2]; r.s_s = gw_strides[3];

@@ -156,8 +156,9 @@ class WganGpTrainer:
         self.net_G.to(self.device)
         self.net_D.to(self.device)
         cap = capturable and self.device.type == "cuda"
-        self.opt_D = torch.optim.Adam(self.net_D.parameters(), lr=lr, betas=betas, capturable=cap, foreach=True)
-        self.opt_G = torch.optim.Adam(self.net_G.parameters(), lr=lr, betas=betas, capturable=cap, foreach=True)
+        kind = {"foreach": True}
+        self.opt_D = torch.optim.Adam(self.net_D.parameters(), lr=lr, betas=betas, capturable=cap, **kind)
+        self.opt_G = torch.optim.Adam(self.net_G.parameters(), lr=lr, betas=betas, capturable=cap, **kind)
         cl = torch.channels_last
         self.real = torch.zeros(batch, 3, resolution, resolution, device=self.device).contiguous(memory_format=cl)
         self.z = torch.zeros(disc_repeats + 1, batch, z_dim, 1, 1, device=self.device)

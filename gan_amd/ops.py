@@ -117,7 +117,8 @@ def _to_bf16(t):
 
 def _dma_ok(t, ic, oc, precision):
     """fp32 activation in bf16 mode whose conv qualifies for the LDS-DMA kernel (bf16 in, fp32 out)."""
-    return precision == _lib.GC_PREC_BF16 and t.dtype == torch.float32 and ic % 8 == 0 and ic > 32 and oc > 16
+    return (precision == _lib.GC_PREC_BF16 and t.dtype == torch.float32 and ic % 8 == 0 and ic > 32 and oc > 16
+            and t.numel() * 2 < (1 << 31) - (1 << 21))   # the kernel addresses its input with 32-bit buffer offsets
 
 
 def _packed(desc, w, pass_, wkey):

@@ -15,11 +15,25 @@ prec = {"bf16": _lib.GC_PREC_BF16, "fp32x3": _lib.GC_PREC_F32X3}[a.prec]
 dt = torch.float32 if a.dtype == "f32" else torch.bfloat16
 SETS = {
     "wgan": [(3, 64, 64, 4, 2, 1), (64, 32, 128, 4, 2, 1), (128, 16, 256, 4, 2, 1), (256, 8, 512, 4, 2, 1), (512, 4, 1, 4, 1, 0), (512, 4, 100, 4, 1, 0)],
+    "ksweep": [(64, 32, 128, 4, 2, 1), (128, 32, 128, 4, 2, 1), (256, 32, 128, 4, 2, 1), (512, 32, 128, 4, 2, 1), (1024, 32, 128, 4, 2, 1),
+               (64, 32, 128, 3, 1, 1), (64, 32, 128, 1, 1, 0), (128, 32, 128, 1, 1, 0), (512, 32, 128, 1, 1, 0)],
     "big": [(256, 32, 512, 4, 2, 1), (512, 64, 512, 3, 1, 1), (128, 128, 128, 3, 1, 1), (512, 16, 512, 4, 2, 1)],
 }
 B = a.batch
 
 def timeit(fn, n=20):
+    """Median over n calls of the library kernels' own time (events around each launch), excluding weight packing."""
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    tot = sum(v["total_ms"] for k, v in prof.items() if "pack_weight" not in k)
+    return tot / n * 1e3
+
+def timeit_wall(fn, n=20):
     for _ in range(3): fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for e0, e1 in evs:
