@@ -17,6 +17,7 @@ struct WgradParams {
   int32_t ICp, icp_log2, ncols;   // thin mode: padded channels per tap, its log2, T * ICp
   int32_t n_tap_groups, tpt, cw_log2;   // LDS-DMA kernel: a 128-column tile holds tpt taps of (1 << cw_log2) channels
   FastDiv div_wo, div_ho;
+  int64_t x_bytes, y_bytes;   // extents of x and gy (buffer ranges of the LDS-DMA kernel)
 };
 
 struct WgradLaunch {

@@ -308,6 +308,10 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
   p.n_tap_groups = p.kh * p.kw; p.tpt = 1; p.cw_log2 = 7;
   l.dma = allow_dma && l.bf16 && !l.x3 && !p.thin && p.Cin % 8 == 0 && p.Cout % 8 == 0 && p.x_cstride % 8 == 0 &&
           p.x_coff % 8 == 0 && p.y_cstride % 8 == 0 && p.y_coff % 8 == 0;
+  p.x_bytes = (int64_t)p.N * p.H * p.W * p.x_cstride * 2;
+  p.y_bytes = (int64_t)p.K * p.y_cstride * 2;
+  const int64_t limit = (1ll << 31) - (1 << 20);   // 32-bit buffer offsets
+  if (p.x_bytes >= limit || p.y_bytes >= limit) l.dma = false;
   if (l.dma) {
     l.tc = 128;
     if (p.Cin <= 64) {   // two taps of up to 64 channels share one tile (and its gy panel)

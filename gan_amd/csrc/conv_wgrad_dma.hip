@@ -1,6 +1,6 @@
 // Fast path of the weight gradient for bf16 operands whose channel counts are multiples of 8: both pixel-major
 // tiles ([pixel][channel], the layout conv_wgrad_kernel keeps in LDS) are brought in by LDS-DMA
-// (`global_load_lds_dwordx4`) through a ring of STAGES buffers, so several 32-pixel reduction steps are in flight
+// (`buffer_load_dwordx4 ... lds`) through a ring of STAGES buffers, so several 32-pixel reduction steps are in flight
 // per workgroup instead of one register-staged step.  The 32-byte-segment XOR swizzle of the LDS image is applied
 // on each lane's SOURCE address (an LDS-DMA wave-instruction writes 1 KiB linearly).
 //
@@ -18,8 +18,6 @@ namespace {
 
 constexpr int kStepPix = 32;   // pixels per reduction step
 constexpr int kTC = 128;       // tile columns
-
-__device__ __attribute__((aligned(16))) const uint32_t g_wzero_chunk[4] = {0u, 0u, 0u, 0u};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -65,25 +63,26 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
   const int kb0 = split * p.k_per_split;
   const int kend = min(p.K, kb0 + p.k_per_split);
 
-  const uint16_t* gy = reinterpret_cast<const uint16_t*>(p.gy);
-  const uint16_t* x = reinterpret_cast<const uint16_t*>(p.x);
-  const void* zeros = g_wzero_chunk;
+  // Buffer addressing: a lane whose source is padding, past the channel count or past the last pixel uses an
+  // offset beyond the buffer's range and receives zeros.  Both tensors are below 2 GiB (checked by the planner).
+  constexpr uint32_t kOutOfRange = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gy), 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
 
   // ---- per-lane source geometry (fixed over the steps except for the pixel index)
   // gy: wave-instruction j of this wave covers tile rows (wave*YJ + j)*RPIY .. ; lane / CPRY picks the row
   const int y_rsub = lane / CPRY, y_pos = lane % CPRY;
   const int x_rsub = lane / CPRX, x_pos = lane % CPRX;
-  int y_ch[YJ];   // element offset of the source chunk that lands at this lane's LDS position
-  bool y_ok[YJ];
+  uint32_t y_voff[YJ];   // byte offset of (tile row, source chunk) relative to the step's first pixel
 #pragma unroll
   for (int j = 0; j < YJ; j++) {
     const int row = (wave * YJ + j) * RPIY + y_rsub;
     const int ch = (((y_pos >> 1) ^ seg_swz<ROWBY>(row)) << 1) | (y_pos & 1);
-    y_ch[j] = co0 + ch * 8;
-    y_ok[j] = y_ch[j] < p.Cout;
+    const int c = co0 + ch * 8;
+    y_voff[j] = c < p.Cout ? (uint32_t)((row * p.y_cstride + p.y_coff + c) * 2) : kOutOfRange;
   }
-  int x_coff[XJ], x_r[XJ], x_s[XJ];
-  bool x_ok[XJ];
+  uint32_t x_c2[XJ];
+  int x_r[XJ], x_s[XJ], x_row[XJ];
 #pragma unroll
   for (int j = 0; j < XJ; j++) {
     const int row = (wave * XJ + j) * RPIX + x_rsub;
@@ -91,34 +90,34 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
     const int col = ch * 8;
     const int tap = tap0 + (col >> p.cw_log2);
     const int ci = ci0 + (col & ((1 << p.cw_log2) - 1));
-    x_ok[j] = tap < T && (col >> p.cw_log2) < p.tpt && ci < p.Cin;
-    const int tp = x_ok[j] ? tap : 0;
-    x_r[j] = tp / p.kw - p.ph;
+    const bool ok = tap < T && (col >> p.cw_log2) < p.tpt && ci < p.Cin;
+    const int tp = ok ? tap : 0;
+    x_r[j] = ok ? tp / p.kw - p.ph : -(1 << 20);   // a masked column fails the row check of every pixel
     x_s[j] = tp % p.kw - p.pw;
-    x_coff[j] = p.x_coff + ci;
+    x_c2[j] = (uint32_t)((p.x_coff + ci) * 2);
+    x_row[j] = row;
   }
+  const uint32_t x_cs2 = (uint32_t)p.x_cstride * 2u;
 
   auto issue = [&](int stage, int kb) {
     char* yb = smem + stage * STAGE;
     char* xb = yb + Y_BYTES;
+    const uint32_t s_y = (uint32_t)kb * (uint32_t)p.y_cstride * 2u;   // pixels past the last one fall out of range
 #pragma unroll
-    for (int j = 0; j < YJ; j++) {
-      const int k = kb + (wave * YJ + j) * RPIY + y_rsub;
-      const void* src = (y_ok[j] && k < kend) ? (const void*)(gy + ((size_t)k * p.y_cstride + p.y_coff + y_ch[j])) : zeros;
-      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(yb + (wave * YJ + j) * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < YJ; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rs, (lds_ptr_t)(yb + (wave * YJ + j) * 1024), 16, (int)(y_voff[j] + s_y), 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < XJ; j++) {
-      const int k = kb + (wave * XJ + j) * RPIX + x_rsub;
-      const uint32_t kk = k < kend ? (uint32_t)k : 0u;
-      const uint32_t q1 = fd_div(kk, p.div_wo);
-      const int wo_ = (int)(kk - q1 * p.div_wo.d);
+      const uint32_t k = (uint32_t)(kb + x_row[j]);
+      const uint32_t q1 = fd_div(k, p.div_wo);
+      const int wo_ = (int)(k - q1 * p.div_wo.d);
       const uint32_t n = fd_div(q1, p.div_ho);
       const int ho_ = (int)(q1 - n * p.div_ho.d);
       const int ih = ho_ * p.sh + x_r[j], iw = wo_ * p.sw + x_s[j];
-      const bool ok = x_ok[j] && k < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const void* src = ok ? (const void*)(x + ((((size_t)n * p.H + ih) * p.W + iw) * p.x_cstride + x_coff[j])) : zeros;
-      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(xb + (wave * XJ + j) * 1024), 16, 0, 0);
+      const bool ok = ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+      const uint32_t pix = (n * (uint32_t)p.H + (uint32_t)ih) * (uint32_t)p.W + (uint32_t)iw;   // n >= N lands out of range
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xb + (wave * XJ + j) * 1024), 16,
+                                               (int)(ok ? pix * x_cs2 + x_c2[j] : kOutOfRange), 0, 0, 0);
     }
   };
 
@@ -185,19 +184,32 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
 
   // ---- ring: steps it+1 .. it+STAGES-1 are in flight while step it is multiplied
   const int nsteps = kend > kb0 ? (kend - kb0 + kStepPix - 1) / kStepPix : 0;
-  int issued = 0;
+  int issued = 0, st_i = 0, st_c = 0, kb = kb0;
+  auto next_stage = [](int s) { return s + 1 == STAGES ? 0 : s + 1; };
 #pragma unroll
   for (int s = 0; s < STAGES - 1; s++)
-    if (issued < nsteps) { issue(issued % STAGES, kb0 + issued * kStepPix); issued++; }
-  for (int it = 0; it < nsteps; it++) {
-    const int younger = issued - it - 1;
-    if (younger >= 2) wait_vm<2 * LOADS>();
-    else if (younger == 1) wait_vm<LOADS>();
-    else wait_vm<0>();
+    if (issued < nsteps) { issue(st_i, kb); st_i = next_stage(st_i); kb += kStepPix; issued++; }
+  int it = 0;
+  for (; issued < nsteps; it++, issued++) {   // steady state: STAGES-1 steps in flight at the top
+    wait_vm<(STAGES - 2) * LOADS>();
     __builtin_amdgcn_s_barrier();      // step `it` has landed for every wave; the buffer of step it-1 is free
     __builtin_amdgcn_sched_barrier(0);
-    if (issued < nsteps) { issue(issued % STAGES, kb0 + issued * kStepPix); issued++; }
-    compute(it % STAGES);
+    issue(st_i, kb);
+    st_i = next_stage(st_i);
+    kb += kStepPix;
+    compute(st_c);
+    st_c = next_stage(st_c);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (; it < nsteps; it++) {                 // drain
+    const int younger = nsteps - it - 1;
+    if (STAGES >= 4 && younger >= 2) wait_vm<2 * LOADS>();
+    else if (STAGES >= 3 && younger >= 1) wait_vm<LOADS>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(st_c);
+    st_c = next_stage(st_c);
     __builtin_amdgcn_sched_barrier(0);
   }
 
