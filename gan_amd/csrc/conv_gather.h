@@ -38,6 +38,9 @@ struct GatherParams {
   int64_t plane_stride;  // elements between the hi and lo planes of wp
   int64_t in_bytes, w_bytes;  // extents of the input tensor and the packed weights (LDS-DMA path: buffer ranges)
   int32_t a_bias;        // LDS-DMA path: bytes by which the activation buffer starts before `in` (most negative tap offset)
+  // few-output-channel kernel (conv_scatter): patch geometry
+  int32_t sc_dh_min, sc_dw_min, sc_ph, sc_pw, sc_tiles_h, sc_tiles_w;
+  FastDiv sc_div_oc;
   TapTable tt;
 };
 
@@ -60,6 +63,9 @@ PackGeom pack_geom(int ic, int taps, bool allow_thin);
 // Chooses the tile for a problem; fills n_pix_tiles / n_oc_tiles / ksplit and the class tile prefix in p.tt.
 void plan_gather(GatherParams& p, GatherLaunch& l);
 int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t stream);
+// Few output channels (at most 64 (tap, channel) pairs), stride-1 gather: fills the patch geometry, false if unsuitable.
+bool plan_scatter(GatherParams& p, const GatherLaunch& l);
+int launch_scatter(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // LDS-DMA fast path: bf16 input, vector-aligned channels, 64- or 128-channel tile, no reduction split.
 int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 

@@ -167,6 +167,7 @@ static int pass_dtypes(const gc_conv_desc* d, int pass, int* in_dt, int* out_dt)
 }
 
 static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream) {
+  if (plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   l.big_tile_ok = true;
   plan_gather(p, l);
   // LDS-DMA path: buffer addressing with 32-bit offsets, so both tensors have to stay below 2 GiB

@@ -96,6 +96,9 @@ SEEDED = [  # N, Cin, H, W, Cout, k, s, p   -- sized so the C oracle finishes in
     (3, 64, 32, 32, 128, 4, 2, 1), (2, 128, 16, 16, 256, 4, 2, 1), (2, 256, 8, 8, 512, 4, 2, 1), (5, 512, 4, 4, 1, 4, 1, 0),
     (2, 3, 64, 64, 64, 4, 2, 1), (1, 96, 17, 13, 72, 3, 1, 1), (2, 64, 31, 31, 40, 4, 1, 1), (3, 130, 6, 6, 66, 1, 1, 0),
     (1, 16, 20, 20, 16, 3, 2, 1), (2, 8, 12, 12, 8, 5, 1, 2),
+    # few output channels on one side (image-producing layers and their gradients): the patch kernel
+    (2, 64, 32, 32, 3, 3, 1, 1), (3, 3, 37, 29, 128, 4, 2, 1), (2, 72, 21, 19, 5, 3, 1, 1), (2, 4, 40, 24, 64, 3, 2, 1),
+    (1, 128, 48, 80, 1, 3, 1, 1),
 ]
 
 
@@ -172,6 +175,35 @@ def test_fused_epilogue_bias_activation_statistics(gan):
     assert rel(y, ref) < TOL_X3
     assert rel(stats[0], ref.sum((0, 2, 3))) < 1e-4
     assert rel(stats[1], (ref.astype(np.float64) ** 2).sum((0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_few_output_channels_transposed_conv_with_epilogue(gan, dtype):
+    """Image-producing transposed conv (64 -> 3, 4x4 stride 2) through the C ABI with bias + tanh fused, fp32 and
+    bf16 storage, written into a channel slice of a wider output tensor."""
+    import ctypes
+    L, lib = gan._lib, gan._lib.lib()
+    rng = np.random.default_rng(11)
+    N, Cimg, Hin, Cfeat, k, s, p = 3, 3, 24, 64, 4, 2, 1      # as the conv whose data gradient this is: Cimg -> Cfeat
+    Himg = Hin * 2
+    gy = oracle.round_bf16(rng.standard_normal((N, Cfeat, Hin, Hin), dtype=np.float32))
+    w = oracle.round_bf16(rng.standard_normal((Cfeat, Cimg, k, k), dtype=np.float32) * 0.1)
+    b = rng.standard_normal(Cimg).astype(np.float32)
+    code = L.GC_F32 if dtype == torch.float32 else L.GC_BF16
+    d = gan.ops._desc(N, Himg, Himg, Cimg, Hin, Hin, Cfeat, k, k, s, p, code, L.GC_PREC_BF16)
+    d.x_cstride, d.x_coff = 8, 4
+    wp = gan.ops._packed(d, cu(w), L.GC_PASS_DGRAD, 0)
+    g = cu(gy).to(dtype).contiguous(memory_format=torch.channels_last)
+    out = torch.full((N, Himg, Himg, 8), 7.0, device="cuda", dtype=dtype)
+    bias = cu(b)
+    ep = L.Epilogue()
+    ep.act, ep.bias = L.GC_ACT_TANH, bias.data_ptr()
+    L.check(lib.gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
+                                ctypes.c_void_p(out.data_ptr()), ctypes.byref(ep), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "dgrad")
+    ref = np.tanh(oracle.conv2d_dgrad(gy, w, (N, Cimg, Himg, Himg), s, p) + b[None, :, None, None])
+    got = out.float().cpu().numpy()
+    assert (got[..., :4] == 7.0).all() and (got[..., 7:] == 7.0).all()      # the rest of the tensor is untouched
+    assert rel(got[..., 4:7].transpose(0, 3, 1, 2), ref) < (TOL_EXACT if dtype == torch.float32 else 4e-3)
 
 
 def test_blur(gan, ops_golden):
