@@ -72,17 +72,29 @@ def weights_init(m):
 
 
 # ---- WGAN-GP phases (BasicGANs/loss_functions.py:4-38) --------------------------------------------------------
-def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_backward=None):
-    """Three backward passes accumulate into net_D's gradients: real batch (with the 0.001 drift term), fake
-    batch, gradient penalty (double backward).  `on_last_backward` is called right before the last one (a
-    data-parallel gradient reducer arms its hooks there).  Returns (D_x, D_G_z1, penalty) as tensors."""
-    d_real = net_D(real).view(-1)
-    d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
-    (-d_real).backward()
+def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_backward=None, batch_real_fake=False):
+    """Backward passes accumulate into net_D's gradients: real batch (with the 0.001 drift term), fake batch,
+    gradient penalty (double backward).  `on_last_backward` is called right before the last one (a data-parallel
+    gradient reducer arms its hooks there).  Returns (D_x, D_G_z1, penalty) as tensors.
 
+    batch_real_fake: run the real and the fake batch through the critic as one batch of 2B samples and backpropagate
+    the sum of the two losses once.  The critic has no cross-sample coupling (convolutions, InstanceNorm, LeakyReLU),
+    so scores and accumulated gradients are those of the two separate passes up to summation order; each
+    convolution then runs once at twice the size instead of twice."""
     fake = net_G(z)
-    d_fake = net_D(fake.detach()).view(-1).mean()
-    d_fake.backward()
+    if batch_real_fake:
+        B = real.shape[0]
+        d_both = net_D(torch.cat([real, fake.detach()])).view(-1)
+        d_real, d_fake = d_both[:B], d_both[B:]
+        d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
+        d_fake = d_fake.mean()
+        (d_fake - d_real).backward()
+    else:
+        d_real = net_D(real).view(-1)
+        d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
+        (-d_real).backward()
+        d_fake = net_D(fake.detach()).view(-1).mean()
+        d_fake.backward()
 
     eps = epsilon.detach().clone().requires_grad_(True)
     mixed = real.detach() * eps + fake.detach() * (1 - eps)
@@ -145,9 +157,10 @@ class WganGpTrainer:
     cycle can be captured into one HIP graph (no host work, no allocation, no synchronisation per cycle)."""
 
     def __init__(self, batch, hidden_dim=64, z_dim=100, resolution=64, device="cuda", lr=1e-4, betas=(0.0, 0.9),
-                 c_lambda=10.0, disc_repeats=5, seed=5000, reducer_factory=None, capturable=True):
+                 c_lambda=10.0, disc_repeats=5, seed=5000, reducer_factory=None, capturable=True, batch_real_fake=False):
         torch.manual_seed(seed)
         self.B, self.nz, self.res, self.reps, self.c_lambda = batch, z_dim, resolution, disc_repeats, c_lambda
+        self.batch_real_fake = batch_real_fake
         self.device = torch.device(device)
         self.net_G = Generator(z_dim, hidden_dim, 3, resolution)
         self.net_D = Discriminator(3, hidden_dim, resolution, is_wgan=True)
@@ -185,7 +198,8 @@ class WganGpTrainer:
         for it in range(self.reps):
             self._zero(self.net_D, self.red_D)
             arm = self.red_D.arm if self.red_D is not None else None
-            d_x, d_g_z1, gp = wgan_critic_phase(self.net_G, self.net_D, self.real, self.z[it], self.eps[it], self.c_lambda, arm)
+            d_x, d_g_z1, gp = wgan_critic_phase(self.net_G, self.net_D, self.real, self.z[it], self.eps[it], self.c_lambda, arm,
+                                                self.batch_real_fake)
             if self.red_D is not None:
                 self.red_D.finish()
             self.opt_D.step()

@@ -402,16 +402,18 @@ def test_full_size_properties(gan):
         assert rel(y12, (y + 2 * y2)) < 5e-5
 
 
-def test_wgangp_losses_against_reference_full_model(gan, golden_dir):
+@pytest.mark.parametrize("batched", [False, True], ids=["separate_passes", "real_fake_batched"])
+def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched):
     """Full-size WGAN-GP-64 (hidden 64) at batch 64 with Adam: five critic iterations + one generator iteration
-    of the reference (golden losses), fp32x3 path; weights and inputs regenerated from the recorded seeds."""
+    of the reference (golden losses), fp32x3 path; weights and inputs regenerated from the recorded seeds.
+    `batched` runs the real and fake critic passes as one batch of 2B (the benchmark's setting)."""
     from gan_amd.harness import basic_gans as H
     rec = json.load(open(os.path.join(golden_dir, "wgangp_losses.json")))
     cfg = rec["config"]
     gan.set_precision("fp32x3")
     try:
         tr = H.WganGpTrainer(cfg["B"], cfg["hidden_dim"], cfg["nz"], cfg["res"], lr=cfg["lr"], betas=tuple(cfg["betas"]),
-                             seed=cfg["seed"], capturable=False)
+                             seed=cfg["seed"], capturable=False, batch_real_fake=batched)
         # same init as the reference run: seed, then G init, then D init on the CPU generator
         torch.manual_seed(cfg["seed"])
         G = R.Generator(cfg["nz"], cfg["hidden_dim"], 3, resolution=cfg["res"]); G.apply(R.weights_init)
