@@ -1,0 +1,346 @@
+// BatchNorm2d (training-mode batch statistics or running statistics) fused with ReLU / LeakyReLU, NHWC fp32:
+// forward and first-order backward.
+//
+//   forward    y  = act(a * x + b),  a = gamma * r,  b = beta - mu * a,  mu / r = per-channel mean and
+//              rsqrt(var + eps) over all N*H*W pixels (biased variance); running_mean / running_var (unbiased) and
+//              num_batches_tracked are updated the way torch.nn.BatchNorm2d does
+//   backward   g = gy * act'(a * x + b);  gbeta = sum g;  ggamma = sum g * xh;  gx = a * (g - gbeta/P - xh * ggamma/P)
+//
+// Three launches per direction, all bitwise reproducible (no float atomics):
+//   1. partial statistics: a workgroup owns 64 channels x one slab of pixels and writes (mean, M2) of its slab
+//      (forward: mean first, then centred squares, the second sweep of the slab comes from L2) or (sum g, sum g*xh);
+//   2. finalize: one workgroup per 64 channels merges the slabs in a fixed order (Chan's parallel-variance update
+//      in the forward pass), derives a / b (or the two backward means) and updates the running statistics;
+//   3. apply: same geometry as 1, elementwise, optionally writing a bf16 copy for the convolution that reads it next.
+#include "common.h"
+
+namespace gc {
+
+struct BnParams {
+  const float* x;
+  const float* gy;
+  float* out;            // y | gx
+  uint16_t* out_bf16;    // optional bf16 copy of out
+  const float* gamma;    // may be null (1)
+  const float* beta;     // may be null (0)
+  float* running_mean;   // may be null
+  float* running_var;
+  int64_t* num_batches;  // may be null
+  float* save_mean;      // [C]
+  float* save_rstd;      // [C]
+  float* save_var;       // [C] unbiased batch variance, may be null
+  float* ggamma;         // [C]
+  float* gbeta;          // [C]
+  float* part;           // [slabs][C][2] partial statistics
+  float* coef;           // [2][C]  forward: a, b;  backward: gbeta/P, ggamma/P
+  int32_t P, C, slabs, slab_pix;
+  float eps, momentum, slope;
+  int32_t act, training;
+};
+
+constexpr int kQB = 16, kPL = 16;   // channel quads x pixel lanes of a workgroup
+
+__device__ __forceinline__ f32x4 bn_block_sum(f32x4 v, f32x4* red, int tq, int tl) {
+  red[tl * kQB + tq] = v;
+  __syncthreads();
+  if (tl == 0) {
+    f32x4 s = v;
+    for (int j = 1; j < kPL; j++) s += red[j * kQB + tq];
+    red[tq] = s;
+  }
+  __syncthreads();
+  const f32x4 r = red[tq];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ f32x4 act_mask(f32x4 pre, int act, float slope) {
+  f32x4 m;
+#pragma unroll
+  for (int e = 0; e < 4; e++) m[e] = (act == GC_ACT_NONE || pre[e] > 0.f) ? 1.f : (act == GC_ACT_RELU ? 0.f : slope);
+  return m;
+}
+
+// MODE 0: forward slab statistics (mean, M2);  MODE 1: backward slab sums (sum g, sum g * xh)
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void bn_partial_kernel(const BnParams p) {
+  __shared__ f32x4 red[kThreads];
+  const int t = threadIdx.x, tq = t & (kQB - 1), tl = t >> 4;
+  const int chunks = (p.C / 4 + kQB - 1) / kQB;
+  const int slab = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int c = (chunk * kQB + tq) * 4;
+  const bool cok = c < p.C;
+  const int p0 = slab * p.slab_pix, p1 = min(p.P, p0 + p.slab_pix);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto ld = [&](const float* ptr, int pix) -> f32x4 { return *reinterpret_cast<const f32x4*>(ptr + (size_t)pix * p.C + c); };
+  if (MODE == 0) {
+    f32x4 s = zero;
+    if (cok)
+      for (int pix = p0 + tl; pix < p1; pix += kPL) s += ld(p.x, pix);
+    const f32x4 mean = bn_block_sum(s, red, tq, tl) * (1.f / (float)(p1 - p0));
+    f32x4 s2 = zero;
+    if (cok)
+      for (int pix = p0 + tl; pix < p1; pix += kPL) {
+        const f32x4 d = ld(p.x, pix) - mean;
+        s2 += d * d;
+      }
+    s2 = bn_block_sum(s2, red, tq, tl);
+    if (cok && tl == 0) {
+      *reinterpret_cast<f32x4*>(p.part + ((size_t)slab * p.C + c) * 2) = f32x4{mean[0], s2[0], mean[1], s2[1]};
+      *reinterpret_cast<f32x4*>(p.part + ((size_t)slab * p.C + c) * 2 + 4) = f32x4{mean[2], s2[2], mean[3], s2[3]};
+    }
+  } else {
+    f32x4 sg = zero, sgx = zero;
+    if (cok) {
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(p.save_mean + c), r = *reinterpret_cast<const f32x4*>(p.save_rstd + c);
+      f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = zero;
+      if (p.gamma != nullptr) ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+      if (p.beta != nullptr) be = *reinterpret_cast<const f32x4*>(p.beta + c);
+      for (int pix = p0 + tl; pix < p1; pix += kPL) {
+        const f32x4 xh = (ld(p.x, pix) - mu) * r;
+        const f32x4 g = ld(p.gy, pix) * act_mask(ga * xh + be, p.act, p.slope);
+        sg += g;
+        sgx += g * xh;
+      }
+    }
+    sg = bn_block_sum(sg, red, tq, tl);
+    sgx = bn_block_sum(sgx, red, tq, tl);
+    if (cok && tl == 0) {
+      *reinterpret_cast<f32x4*>(p.part + ((size_t)slab * p.C + c) * 2) = f32x4{sg[0], sgx[0], sg[1], sgx[1]};
+      *reinterpret_cast<f32x4*>(p.part + ((size_t)slab * p.C + c) * 2 + 4) = f32x4{sg[2], sgx[2], sg[3], sgx[3]};
+    }
+  }
+}
+
+// One workgroup per 16 channels: thread (channel, lane) merges slabs lane, lane+16, ... then lane 0 merges the 16 lanes
+// (a fixed order, so the result does not depend on scheduling).
+constexpr int kFinCh = 16, kFinLanes = kThreads / kFinCh;
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p) {
+  __shared__ float sh_a[kThreads], sh_b[kThreads], sh_n[kThreads];
+  const int t = threadIdx.x, tc = t & (kFinCh - 1), lane = t / kFinCh;
+  const int c = blockIdx.x * kFinCh + tc;
+  const bool cok = c < p.C;
+  float n = 0.f, a = 0.f, b = 0.f;   // forward: count, mean, M2;  backward: -, sum g, sum g*xh
+  if (cok)
+    for (int s = lane; s < p.slabs; s += kFinLanes) {
+      const float2 v = *reinterpret_cast<const float2*>(p.part + ((size_t)s * p.C + c) * 2);
+      if (MODE == 0) {
+        const float nb = (float)(min(p.P, (s + 1) * p.slab_pix) - s * p.slab_pix);
+        const float tot = n + nb, delta = v.x - a;
+        a += delta * (nb / tot);
+        b += v.y + delta * delta * (n * nb / tot);
+        n = tot;
+      } else {
+        a += v.x;
+        b += v.y;
+      }
+    }
+  sh_a[t] = a; sh_b[t] = b; sh_n[t] = n;
+  __syncthreads();
+  if (lane != 0 || !cok) return;
+  for (int l = 1; l < kFinLanes; l++) {
+    const float va = sh_a[l * kFinCh + tc], vb = sh_b[l * kFinCh + tc], nb = sh_n[l * kFinCh + tc];
+    if (MODE == 0) {
+      if (nb > 0.f) {
+        const float tot = n + nb, delta = va - a;
+        a += delta * (nb / tot);
+        b += vb + delta * delta * (n * nb / tot);
+        n = tot;
+      }
+    } else {
+      a += va;
+      b += vb;
+    }
+  }
+  if (MODE == 0) {
+    const float mean = a, var = b / (float)p.P;
+    const float r = rsqrtf(var + p.eps);
+    p.save_mean[c] = mean;
+    p.save_rstd[c] = r;
+    const float ga = p.gamma != nullptr ? p.gamma[c] : 1.f, be = p.beta != nullptr ? p.beta[c] : 0.f;
+    p.coef[c] = ga * r;
+    p.coef[p.C + c] = be - mean * ga * r;
+    const float unbiased = p.P > 1 ? b / (float)(p.P - 1) : var;
+    if (p.save_var != nullptr) p.save_var[c] = unbiased;
+    if (p.running_mean != nullptr) {
+      p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+      p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * unbiased;
+    }
+    if (p.num_batches != nullptr && c == 0) p.num_batches[0] += 1;
+  } else {
+    p.gbeta[c] = a;
+    p.ggamma[c] = b;
+    p.coef[c] = a / (float)p.P;
+    p.coef[p.C + c] = b / (float)p.P;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_update_running_kernel(float* rm, float* rv, int64_t* nbt, const float* mean, const float* var,
+                                                                    int C, float momentum) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c == 0 && nbt != nullptr) nbt[0] += 1;
+  if (c >= C) return;
+  rm[c] = (1.f - momentum) * rm[c] + momentum * mean[c];
+  rv[c] = (1.f - momentum) * rv[c] + momentum * var[c];
+}
+
+// Evaluation mode: a / b from the running statistics.
+__global__ __launch_bounds__(kThreads) void bn_eval_coef_kernel(const BnParams p) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= p.C) return;
+  const float r = rsqrtf(p.running_var[c] + p.eps), mean = p.running_mean[c];
+  const float ga = p.gamma != nullptr ? p.gamma[c] : 1.f, be = p.beta != nullptr ? p.beta[c] : 0.f;
+  p.save_mean[c] = mean;
+  p.save_rstd[c] = r;
+  p.coef[c] = ga * r;
+  p.coef[p.C + c] = be - mean * ga * r;
+}
+
+// MODE 0: y = act(a x + b);  MODE 1: gx = gamma r (g - gbeta/P - xh ggamma/P)
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
+  const int t = threadIdx.x, tq = t & (kQB - 1), tl = t >> 4;
+  const int chunks = (p.C / 4 + kQB - 1) / kQB;
+  const int slab = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int c = (chunk * kQB + tq) * 4;
+  if (c >= p.C) return;
+  const int p0 = slab * p.slab_pix, p1 = min(p.P, p0 + p.slab_pix);
+  const f32x4 k0 = *reinterpret_cast<const f32x4*>(p.coef + c), k1 = *reinterpret_cast<const f32x4*>(p.coef + p.C + c);
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, r = mu, ga = {1.f, 1.f, 1.f, 1.f}, be = mu;
+  if (MODE == 1) {
+    mu = *reinterpret_cast<const f32x4*>(p.save_mean + c);
+    r = *reinterpret_cast<const f32x4*>(p.save_rstd + c);
+    if (p.gamma != nullptr) ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+    if (p.beta != nullptr) be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  }
+  for (int pix = p0 + tl; pix < p1; pix += kPL) {
+    const size_t o = (size_t)pix * p.C + c;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + o);
+    f32x4 res;
+    if (MODE == 0) {
+      const f32x4 pre = k0 * xv + k1;
+      const f32x4 m = act_mask(pre, p.act, p.slope);
+      res = pre * m;
+    } else {
+      const f32x4 xh = (xv - mu) * r;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gy + o) * act_mask(ga * xh + be, p.act, p.slope);
+      res = ga * r * (g - k0 - xh * k1);
+    }
+    *reinterpret_cast<f32x4*>(p.out + o) = res;
+    if (p.out_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out_bf16 + o) = cvt_bf16x4(res);
+  }
+}
+
+static void bn_geometry(BnParams& p) {
+  const int chunks = (p.C / 4 + kQB - 1) / kQB;
+  long slabs = (p.P + 255) / 256;              // at least 256 pixels per slab
+  const long cap = chunks >= 4 ? 128 : 512 / chunks;
+  if (slabs > cap) slabs = cap;
+  if (slabs < 1) slabs = 1;
+  p.slab_pix = (int)((p.P + slabs - 1) / slabs);
+  p.slabs = (p.P + p.slab_pix - 1) / p.slab_pix;
+}
+
+static bool misaligned(const void* q, unsigned mask) { return (reinterpret_cast<uintptr_t>(q) & mask) != 0; }
+
+}  // namespace gc
+
+using namespace gc;
+
+extern "C" {
+
+size_t gc_batchnorm_workspace_bytes(int64_t P, int32_t C) {
+  if (P <= 0 || C <= 0 || P >= (1ll << 31)) return 0;
+  BnParams p{};
+  p.P = (int32_t)P; p.C = C;
+  bn_geometry(p);
+  return ((size_t)p.slabs * C * 2 + 2 * (size_t)C) * sizeof(float);
+}
+
+int gc_batchnorm_act_fwd(const float* x, float* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, float eps, float momentum, int32_t act,
+                         float slope, int32_t training, void* stream) {
+  if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
+  if (act != GC_ACT_NONE && act != GC_ACT_RELU && act != GC_ACT_LRELU) { set_error("batchnorm: activation must be none, ReLU or LeakyReLU"); return GC_BAD_ARGUMENT; }
+  if (C % 4 != 0) { set_error("batchnorm: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
+  if (P == 0) return GC_OK;
+  if (x == nullptr || y == nullptr || save_mean == nullptr || save_rstd == nullptr || workspace == nullptr) { set_error("batchnorm: null pointer"); return GC_BAD_ARGUMENT; }
+  if (!training && (running_mean == nullptr || running_var == nullptr)) { set_error("batchnorm: evaluation mode needs running statistics"); return GC_BAD_ARGUMENT; }
+  if ((running_mean == nullptr) != (running_var == nullptr)) { set_error("batchnorm: running_mean and running_var go together"); return GC_BAD_ARGUMENT; }
+  if (misaligned(x, 15) || misaligned(y, 15) || misaligned(y_bf16, 7) || misaligned(workspace, 15) || misaligned(gamma, 15) ||
+      misaligned(beta, 15) || misaligned(save_mean, 15) || misaligned(save_rstd, 15)) {
+    set_error("batchnorm: misaligned pointer"); return GC_BAD_ARGUMENT;
+  }
+  const size_t need = gc_batchnorm_workspace_bytes(P, C);
+  if (workspace_bytes < need) { set_error("batchnorm: workspace of %zu bytes given, %zu needed", workspace_bytes, need); return GC_WORKSPACE_TOO_SMALL; }
+  BnParams p{};
+  p.x = x; p.out = y; p.out_bf16 = (uint16_t*)y_bf16; p.gamma = gamma; p.beta = beta;
+  p.running_mean = running_mean; p.running_var = running_var; p.num_batches = num_batches_tracked;
+  p.save_mean = save_mean; p.save_rstd = save_rstd; p.save_var = save_var;
+  p.P = (int32_t)P; p.C = C; p.eps = eps; p.momentum = momentum; p.slope = slope; p.act = act; p.training = training;
+  bn_geometry(p);
+  p.part = (float*)workspace;
+  p.coef = p.part + (size_t)p.slabs * C * 2;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = (C / 4 + kQB - 1) / kQB;
+  const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
+  if (training) {
+    { ProfScope ps("gc::bn_partial_kernel<0>", 0.0, s); hipLaunchKernelGGL(bn_partial_kernel<0>, grid, block, 0, s, p); }
+    { ProfScope ps("gc::bn_finalize_kernel<0>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, p); }
+  } else {
+    ProfScope ps("gc::bn_eval_coef_kernel", 0.0, s);
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + kThreads - 1) / kThreads), block, 0, s, p);
+  }
+  { ProfScope ps("gc::bn_apply_kernel<0>", 0.0, s); hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, s, p); }
+  return check_hip(hipGetLastError(), "batchnorm forward launch");
+}
+
+int gc_batchnorm_act_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_rstd, float* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
+                         size_t workspace_bytes, int64_t P, int32_t C, int32_t act, float slope, void* stream) {
+  if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
+  if (act != GC_ACT_NONE && act != GC_ACT_RELU && act != GC_ACT_LRELU) { set_error("batchnorm: activation must be none, ReLU or LeakyReLU"); return GC_BAD_ARGUMENT; }
+  if (C % 4 != 0) { set_error("batchnorm: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
+  if (x == nullptr || gy == nullptr || gx == nullptr || ggamma == nullptr || gbeta == nullptr || save_mean == nullptr ||
+      save_rstd == nullptr || workspace == nullptr) { set_error("batchnorm: null pointer"); return GC_BAD_ARGUMENT; }
+  if (misaligned(x, 15) || misaligned(gy, 15) || misaligned(gx, 15) || misaligned(gx_bf16, 7) || misaligned(workspace, 15) ||
+      misaligned(gamma, 15) || misaligned(beta, 15) || misaligned(save_mean, 15) || misaligned(save_rstd, 15)) {
+    set_error("batchnorm: misaligned pointer"); return GC_BAD_ARGUMENT;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) {
+    if (check_hip(hipMemsetAsync(ggamma, 0, sizeof(float) * C, s), "hipMemsetAsync")) return GC_HIP_ERROR;
+    return check_hip(hipMemsetAsync(gbeta, 0, sizeof(float) * C, s), "hipMemsetAsync");
+  }
+  const size_t need = gc_batchnorm_workspace_bytes(P, C);
+  if (workspace_bytes < need) { set_error("batchnorm: workspace of %zu bytes given, %zu needed", workspace_bytes, need); return GC_WORKSPACE_TOO_SMALL; }
+  BnParams p{};
+  p.x = x; p.gy = gy; p.out = gx; p.out_bf16 = (uint16_t*)gx_bf16; p.gamma = gamma; p.beta = beta;
+  p.save_mean = const_cast<float*>(save_mean); p.save_rstd = const_cast<float*>(save_rstd);
+  p.ggamma = ggamma; p.gbeta = gbeta;
+  p.P = (int32_t)P; p.C = C; p.slope = slope; p.act = act;
+  bn_geometry(p);
+  p.part = (float*)workspace;
+  p.coef = p.part + (size_t)p.slabs * C * 2;
+  const int chunks = (C / 4 + kQB - 1) / kQB;
+  const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
+  { ProfScope ps("gc::bn_partial_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_partial_kernel<1>, grid, block, 0, s, p); }
+  { ProfScope ps("gc::bn_finalize_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, p); }
+  { ProfScope ps("gc::bn_apply_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, s, p); }
+  return check_hip(hipGetLastError(), "batchnorm backward launch");
+}
+
+int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,
+                                const float* var_unbiased, int32_t C, float momentum, void* stream) {
+  if (C <= 0 || running_mean == nullptr || running_var == nullptr || mean == nullptr || var_unbiased == nullptr) {
+    set_error("batchnorm: bad argument to the running-statistics update"); return GC_BAD_ARGUMENT;
+  }
+  ProfScope ps("gc::bn_update_running_kernel", 0.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, running_mean,
+                     running_var, num_batches_tracked, mean, var_unbiased, C, momentum);
+  return check_hip(hipGetLastError(), "batchnorm running-statistics launch");
+}
+
+}  // extern "C"

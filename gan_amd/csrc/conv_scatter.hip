@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherPara
   constexpr int CPR = kBK / EPC;                      // source chunks per 64-channel row
   constexpr int RPP = kThreads / CPR;                 // rows loaded per pass
   constexpr int PASSES = kMaxPatch / RPP;
-  constexpr int X_BYTES = kMaxPatch * 128, W_BYTES = kMaxRows * 128;
+  constexpr int X_BYTES = kMaxPatch * 128;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xin = smem;                       // [patch pixel][64 ch] bf16, 16-byte chunks XOR-swizzled by (row >> 1) & 7

@@ -23,6 +23,8 @@ struct InstNormParams {
   const float* u;
   float* out0;   // z | gx | g_x
   float* out1;   // - | -  | g_gz
+  uint16_t* out0_bf16;   // optional bf16 copies of out0 / out1
+  uint16_t* out1_bf16;
   int32_t N, HW, C;
   int32_t qb_log2;   // log2 of channel quads per workgroup (<= 4)
   float eps, slope;
@@ -103,14 +105,18 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
   if (MODE == 0) {
     for (int pix = tl; pix < p.HW; pix += PL) {
       const f32x4 d = ld(p.x, pix) - mu;
-      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = d * r * mask(d);
+      const f32x4 z = d * r * mask(d);
+      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = z;
+      if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(z);
     }
   } else if (MODE == 1) {
     const f32x4 gbar = sg * inv_n, cbar = sgd * r * inv_n;   // mean(gy), mean(gy * xh)
     for (int pix = tl; pix < p.HW; pix += PL) {
       const f32x4 d = ld(p.x, pix) - mu;
       const f32x4 gy = ld(p.gz, pix) * mask(d);
-      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = r * (gy - gbar - d * r * cbar);
+      const f32x4 gx = r * (gy - gbar - d * r * cbar);
+      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = gx;
+      if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(gx);
     }
   } else {
     const float nn = (float)p.HW;
@@ -127,14 +133,17 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
       const f32x4 uu = ld(p.u, pix);
       const f32x4 pu = uu - ubar - xh * (b_ * inv_n);
       const f32x4 pg = gy - gbar - xh * (c_ * inv_n);
-      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = scale * (k0 * xh + c_ * pu + b_ * pg);
-      *reinterpret_cast<f32x4*>(p.out1 + base + (size_t)pix * p.C) = m * r * pu;
+      const f32x4 o0 = scale * (k0 * xh + c_ * pu + b_ * pg), o1 = m * r * pu;
+      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = o0;
+      *reinterpret_cast<f32x4*>(p.out1 + base + (size_t)pix * p.C) = o1;
+      if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o0);
+      if (p.out1_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out1_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o1);
     }
   }
 }
 
-static int launch_instnorm(int mode, const float* x, const float* gz, const float* u, float* out0, float* out1, int N, int HW, int C,
-                           float eps, float slope, int act, hipStream_t stream) {
+static int launch_instnorm(int mode, const float* x, const float* gz, const float* u, float* out0, float* out1, void* out0_bf16,
+                           void* out1_bf16, int N, int HW, int C, float eps, float slope, int act, hipStream_t stream) {
   if (N < 0 || HW <= 0 || C <= 0) { set_error("instnorm: bad shape"); return GC_BAD_ARGUMENT; }
   if (act != GC_ACT_NONE && act != GC_ACT_LRELU) { set_error("instnorm: activation must be none or LeakyReLU"); return GC_BAD_ARGUMENT; }
   if (act == GC_ACT_LRELU && !(slope > 0.f)) { set_error("instnorm: LeakyReLU slope must be positive"); return GC_UNSUPPORTED_GEOMETRY; }
@@ -143,7 +152,10 @@ static int launch_instnorm(int mode, const float* x, const float* gz, const floa
   const void* ptrs[5] = {x, mode >= 1 ? gz : x, mode == 2 ? u : x, out0, mode == 2 ? out1 : out0};
   for (auto q : ptrs)
     if (q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u)) { set_error("instnorm: null or misaligned pointer"); return GC_BAD_ARGUMENT; }
-  InstNormParams p{x, gz, u, out0, out1, N, HW, C, 0, eps, slope, act};
+  if ((reinterpret_cast<uintptr_t>(out0_bf16) & 7u) || (reinterpret_cast<uintptr_t>(out1_bf16) & 7u)) {
+    set_error("instnorm: misaligned bf16 output"); return GC_BAD_ARGUMENT;
+  }
+  InstNormParams p{x, gz, u, out0, out1, (uint16_t*)out0_bf16, (uint16_t*)out1_bf16, N, HW, C, 0, eps, slope, act};
   while ((1 << p.qb_log2) < C / 4 && p.qb_log2 < 4) p.qb_log2++;
   const int QB = 1 << p.qb_log2;
   const int chunks = (C / 4 + QB - 1) / QB;
@@ -160,18 +172,19 @@ static int launch_instnorm(int mode, const float* x, const float* gz, const floa
 
 extern "C" {
 
-int gc_instnorm_act_fwd(const float* x, float* z, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream) {
-  return gc::launch_instnorm(0, x, nullptr, nullptr, z, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
-}
-
-int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope,
+int gc_instnorm_act_fwd(const float* x, float* z, void* z_bf16, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope,
                         void* stream) {
-  return gc::launch_instnorm(1, x, gz, nullptr, gx, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
+  return gc::launch_instnorm(0, x, nullptr, nullptr, z, nullptr, z_bf16, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
 }
 
-int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, int32_t N, int32_t HW, int32_t C,
-                            float eps, int32_t act, float slope, void* stream) {
-  return gc::launch_instnorm(2, x, gz, u, g_x, g_gz, N, HW, C, eps, slope, act, (hipStream_t)stream);
+int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, void* gx_bf16, int32_t N, int32_t HW, int32_t C, float eps,
+                        int32_t act, float slope, void* stream) {
+  return gc::launch_instnorm(1, x, gz, nullptr, gx, nullptr, gx_bf16, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
+}
+
+int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, void* g_x_bf16, void* g_gz_bf16,
+                            int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream) {
+  return gc::launch_instnorm(2, x, gz, u, g_x, g_gz, g_x_bf16, g_gz_bf16, N, HW, C, eps, slope, act, (hipStream_t)stream);
 }
 
 }  // extern "C"

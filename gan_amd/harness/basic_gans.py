@@ -1,7 +1,8 @@
 """DCGAN / WGAN-GP generator, discriminator and training phases of the reference's BasicGANs family on the
 gan_amd convolution modules.
 
-Graphs and parameter names follow BasicGANs/models.py:6-86 (`main.{i}.0.weight` ...), the phases follow
+Graphs and parameter names follow BasicGANs/models.py:6-86 (`main.{i}.0.weight` ...; each BatchNorm2d + activation
+pair is one fused module that keeps BatchNorm2d's parameter and buffer names), the phases follow
 BasicGANs/loss_functions.py:4-76 and the step order BasicGANs/DCGAN.py:165-181 / BasicGANs/train.py:95-119.
 Differences that do not change results: no host synchronisation inside a phase (losses are returned as
 tensors, never .item()), and the WGAN-GP interpolation factor epsilon is an argument instead of a draw inside
@@ -30,7 +31,7 @@ class Generator(torch.nn.Module):
             cin = z_dim if first else int(width / 2 ** (i - 1))
             cout = image_dim if last else int(width / 2 ** i)
             conv = gnn.ConvTranspose2d(cin, cout, 4, 1 if first else 2, 0 if first else 1, bias=False)
-            layers.append(_seq(conv, torch.nn.Tanh()) if last else _seq(conv, torch.nn.BatchNorm2d(cout), torch.nn.ReLU(True)))
+            layers.append(_seq(conv, torch.nn.Tanh()) if last else _seq(conv, gnn.BatchNormAct2d(cout, activation="relu")))
         self.main = _seq(*layers)
 
     def forward(self, noise_vector):
@@ -52,7 +53,7 @@ class Discriminator(torch.nn.Module):
             elif not last and is_wgan:   # InstanceNorm2d + LeakyReLU(0.2) of the reference as one fused op (no parameters)
                 ops.append(gnn.InstanceNormAct2d(cout, negative_slope=0.2))
             elif not last:
-                ops += [torch.nn.BatchNorm2d(cout), torch.nn.LeakyReLU(0.2, inplace=True)]
+                ops.append(gnn.BatchNormAct2d(cout, activation="leaky_relu", negative_slope=0.2))
             elif not is_wgan:
                 ops.append(torch.nn.Sigmoid())
             layers.append(_seq(*ops))
@@ -66,7 +67,7 @@ def weights_init(m):
     """BasicGANs/utils.py:31-36."""
     if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
         torch.nn.init.normal_(m.weight, 0.0, 0.02)
-    if isinstance(m, torch.nn.BatchNorm2d):
+    if isinstance(m, (torch.nn.BatchNorm2d, gnn.BatchNormAct2d)):
         torch.nn.init.normal_(m.weight, 0.0, 0.02)
         torch.nn.init.constant_(m.bias, 0)
 

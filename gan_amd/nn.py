@@ -77,3 +77,63 @@ class InstanceNormAct2d(torch.nn.Module):
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, negative_slope={self.negative_slope}"
+
+
+class BatchNormAct2d(torch.nn.Module):
+    """torch.nn.BatchNorm2d followed by ReLU / LeakyReLU / nothing as fused kernels (statistics, finalize, apply; the
+    same three for the backward pass).  Parameters, buffers and their names are BatchNorm2d's (weight, bias,
+    running_mean, running_var, num_batches_tracked), so it takes the place of the reference's
+    `BatchNorm2d(out_dim), ReLU(True)` pair (BasicGANs/models.py:37) without changing a state_dict; the activation
+    module that follows it in the reference holds no state.  First-order gradients only; float32, channels % 4 == 0."""
+
+    _ACTS = {None: 0, "relu": 1, "leaky_relu": 2}
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, activation="relu",
+                 negative_slope=0.2):
+        super().__init__()
+        if activation not in self._ACTS:
+            raise ValueError(f"activation must be one of {list(self._ACTS)}")
+        if momentum is None:
+            raise ValueError("cumulative moving average (momentum=None) is not supported")
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        self.activation, self.negative_slope = activation, negative_slope
+        if affine:
+            self.weight = torch.nn.Parameter(torch.ones(num_features))
+            self.bias = torch.nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        if track_running_stats:
+            self.register_buffer("running_mean", torch.zeros(num_features))
+            self.register_buffer("running_var", torch.ones(num_features))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        else:
+            self.register_buffer("running_mean", None)
+            self.register_buffer("running_var", None)
+            self.register_buffer("num_batches_tracked", None)
+
+    def forward(self, input):
+        if input.shape[1] != self.num_features:
+            raise RuntimeError(f"expected {self.num_features} channels, got {input.shape[1]}")
+        training = self.training or not self.track_running_stats
+        act = self._ACTS[self.activation]
+        if not training and torch.is_grad_enabled() and (input.requires_grad or (self.affine and self.weight.requires_grad)):
+            # evaluation-mode statistics are constants: plain elementwise math, differentiable to any order
+            r = torch.rsqrt(self.running_var + self.eps)
+            a = r * self.weight if self.affine else r
+            b = (self.bias if self.affine else 0) - self.running_mean * a
+            y = input * a[None, :, None, None] + b[None, :, None, None]
+            if act == 1:
+                return torch.relu(y)
+            return torch.nn.functional.leaky_relu(y, self.negative_slope) if act == 2 else y
+        y, mean, _, var = ops.batchnorm_act(input, self.weight, self.bias, self.running_mean, self.running_var, training,
+                                            float(self.eps), act, float(self.negative_slope))
+        if training and self.track_running_stats:
+            with torch.no_grad():
+                ops.batchnorm_update_running_(self.running_mean, self.running_var, self.num_batches_tracked, mean, var, float(self.momentum))
+        return y
+
+    def extra_repr(self):
+        return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine={self.affine}, "
+                f"track_running_stats={self.track_running_stats}, activation={self.activation}")

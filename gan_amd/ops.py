@@ -96,7 +96,7 @@ def _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, dtype_code, preci
 # by the data-gradient and the weight-gradient conv.  The cache entry keeps the source tensor alive, so its address
 # cannot be re-used by another tensor while the entry exists; a version bump (in-place write) misses.
 _cast_cache = {}
-_CAST_CACHE_MAX = 48
+_CAST_CACHE_MAX = 128
 
 
 def clear_cast_cache():
@@ -113,6 +113,23 @@ def _to_bf16(t):
         _cast_cache.pop(next(iter(_cast_cache)))
     _cast_cache[key] = (t, tb)
     return tb
+
+
+def _bf16_twin(t):
+    """For a kernel that can write a bf16 copy of its fp32 output `t` on the side: the buffer for that copy,
+    registered as t's cast, or None when no convolution would use it (fp32x3 mode, thin or unaligned channels)."""
+    C = t.shape[1]
+    if _default_precision != _lib.GC_PREC_BF16 or t.dtype != torch.float32 or C % 8 != 0 or C <= 32 or t.numel() * 2 >= (1 << 31) - (1 << 21):
+        return None
+    tb = torch.empty_like(t, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    if len(_cast_cache) >= _CAST_CACHE_MAX:
+        _cast_cache.pop(next(iter(_cast_cache)))
+    _cast_cache[(t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))] = (t, tb)
+    return tb
+
+
+def _optr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
 def _dma_ok(t, ic, oc, precision):
@@ -351,7 +368,7 @@ def instnorm_act(x: Tensor, eps: float, act: int, slope: float) -> Tensor:
     x = _nhwc(x)
     N, HW, C = _in_args(x)
     z = torch.empty_like(x, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().gc_instnorm_act_fwd(_ptr(x), _ptr(z), N, HW, C, eps, act, slope, _stream()), "gc_instnorm_act_fwd")
+    _lib.check(_lib.lib().gc_instnorm_act_fwd(_ptr(x), _ptr(z), _optr(_bf16_twin(z)), N, HW, C, eps, act, slope, _stream()), "gc_instnorm_act_fwd")
     return z
 
 
@@ -366,7 +383,8 @@ def instnorm_act_bwd(x: Tensor, gz: Tensor, eps: float, act: int, slope: float) 
     x, gz = _nhwc(x), _nhwc(gz)
     N, HW, C = _in_args(x)
     gx = torch.empty_like(x, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().gc_instnorm_act_bwd(_ptr(x), _ptr(gz), _ptr(gx), N, HW, C, eps, act, slope, _stream()), "gc_instnorm_act_bwd")
+    _lib.check(_lib.lib().gc_instnorm_act_bwd(_ptr(x), _ptr(gz), _ptr(gx), _optr(_bf16_twin(gx)), N, HW, C, eps, act, slope, _stream()),
+               "gc_instnorm_act_bwd")
     return gx
 
 
@@ -382,7 +400,8 @@ def instnorm_act_bwd_bwd(x: Tensor, gz: Tensor, u: Tensor, eps: float, act: int,
     N, HW, C = _in_args(x)
     g_x = torch.empty_like(x, memory_format=torch.channels_last)
     g_gz = torch.empty_like(x, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().gc_instnorm_act_bwd_bwd(_ptr(x), _ptr(gz), _ptr(u), _ptr(g_x), _ptr(g_gz), N, HW, C, eps, act, slope, _stream()),
+    _lib.check(_lib.lib().gc_instnorm_act_bwd_bwd(_ptr(x), _ptr(gz), _ptr(u), _ptr(g_x), _ptr(g_gz), _optr(_bf16_twin(g_x)),
+                                                  _optr(_bf16_twin(g_gz)), N, HW, C, eps, act, slope, _stream()),
                "gc_instnorm_act_bwd_bwd")
     return g_x, g_gz
 
@@ -419,3 +438,88 @@ def _in_bwd_backward(ctx, u):
 
 
 torch.library.register_autograd("ganconv::instnorm_act_bwd", _in_bwd_backward, setup_context=_in_bwd_setup)
+
+
+# ---- BatchNorm (+ ReLU / LeakyReLU), first-order backward --------------------------------------------------------
+@torch.library.custom_op("ganconv::batchnorm_act", mutates_args=())
+def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
+                  running_var: Optional[Tensor], training: bool, eps: float, act: int, slope: float) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """act(batch_norm(x)) with torch.nn.BatchNorm2d semantics.  training: batch statistics; otherwise the running
+    ones (read only).  Returns (y, mean, rstd, unbiased variance); the caller folds the last two into its running
+    statistics with batchnorm_update_running_."""
+    _check_cuda(x, weight, bias, running_mean, running_var)
+    if x.dtype != torch.float32:
+        raise RuntimeError("ganconv: batch norm kernels take float32 tensors")
+    x = _nhwc(x)
+    N, C, H, W = x.shape
+    P = N * H * W
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    mean, rstd, var = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(3))
+    L = _lib.lib()
+    ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
+    rm, rv = (None, None) if training else (running_mean, running_var)
+    _lib.check(L.gc_batchnorm_act_fwd(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _optr(rm), _optr(rv), None,
+                                      _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), P, C, eps, 0.0, act, slope,
+                                      1 if training else 0, _stream()), "gc_batchnorm_act_fwd")
+    return y, mean, rstd, var
+
+
+@batchnorm_act.register_fake
+def _(x, weight, bias, running_mean, running_var, training, eps, act, slope):
+    C = x.shape[1]
+    return torch.empty_like(x), x.new_empty(C), x.new_empty(C), x.new_empty(C)
+
+
+@torch.library.custom_op("ganconv::batchnorm_update_running_", mutates_args=("running_mean", "running_var", "num_batches_tracked"))
+def batchnorm_update_running_(running_mean: Tensor, running_var: Tensor, num_batches_tracked: Optional[Tensor], mean: Tensor,
+                              var_unbiased: Tensor, momentum: float) -> None:
+    _check_cuda(running_mean, running_var, num_batches_tracked, mean, var_unbiased)
+    _lib.check(_lib.lib().gc_batchnorm_update_running(_ptr(running_mean), _ptr(running_var), _optr(num_batches_tracked), _ptr(mean),
+                                                      _ptr(var_unbiased), running_mean.numel(), momentum, _stream()),
+               "gc_batchnorm_update_running")
+
+
+@torch.library.custom_op("ganconv::batchnorm_act_bwd", mutates_args=())
+def batchnorm_act_bwd(x: Tensor, gy: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], mean: Tensor, rstd: Tensor,
+                      act: int, slope: float) -> tuple[Tensor, Tensor, Tensor]:
+    """(gx, gweight, gbias) of a training-mode batchnorm_act."""
+    _check_cuda(x, gy)
+    x, gy = _nhwc(x), _nhwc(gy)
+    N, C, H, W = x.shape
+    P = N * H * W
+    gx = torch.empty_like(x, memory_format=torch.channels_last)
+    gw = torch.empty(C, dtype=torch.float32, device=x.device)
+    gb = torch.empty(C, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
+    _lib.check(L.gc_batchnorm_act_bwd(_ptr(x), _ptr(gy), _optr(weight), _optr(bias), _ptr(mean), _ptr(rstd), _ptr(gx),
+                                      _optr(_bf16_twin(gx)), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), P, C, act, slope, _stream()),
+               "gc_batchnorm_act_bwd")
+    return gx, gw, gb
+
+
+@batchnorm_act_bwd.register_fake
+def _(x, gy, weight, bias, mean, rstd, act, slope):
+    C = x.shape[1]
+    return torch.empty_like(x), x.new_empty(C), x.new_empty(C)
+
+
+def _bn_setup(ctx, inputs, output):
+    x, weight, bias, _, _, training, _, act, slope = inputs
+    if not training:
+        raise RuntimeError("ganconv: batchnorm_act is differentiable in training mode only")
+    _, mean, rstd, _ = output
+    ctx.save_for_backward(x, weight, bias, mean, rstd)
+    ctx.cfg = (act, slope)
+
+
+def _bn_backward(ctx, gy, g_mean, g_rstd, g_var):
+    x, weight, bias, mean, rstd = ctx.saved_tensors
+    # (mean / rstd are returned for the backward pass only; gradients arriving at them are ignored)
+    if gy.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("ganconv: batchnorm_act has no second-order backward")
+    gx, gw, gb = batchnorm_act_bwd(x, gy, weight, bias, mean, rstd, *ctx.cfg)
+    return gx, gw if weight is not None else None, gb if bias is not None else None, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::batchnorm_act", _bn_backward, setup_context=_bn_setup)

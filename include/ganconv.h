@@ -139,12 +139,40 @@ int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_
  * fwd:      z = act((x - mean) * rsqrt(var + eps))
  * bwd:      gx = d(loss)/dx given gz = d(loss)/dz              (statistics are recomputed from x)
  * bwd_bwd:  given u = d(loss2)/d(gx):  g_x = d(loss2)/dx through gx,  g_gz = d(loss2)/d(gz)
- * The second-order kernel is what the gradient penalty's .backward() needs (BasicGANs/loss_functions.py:21-28). */
-int gc_instnorm_act_fwd(const float* x, float* z, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream);
-int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, int32_t N, int32_t HW, int32_t C, float eps, int32_t act,
-                        float slope, void* stream);
-int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, int32_t N, int32_t HW,
-                            int32_t C, float eps, int32_t act, float slope, void* stream);
+ * The second-order kernel is what the gradient penalty's .backward() needs (BasicGANs/loss_functions.py:21-28).
+ * Every *_bf16 argument may be NULL; otherwise the kernel also writes a bf16 (round-to-nearest-even) copy of that
+ * output there, same layout, for the convolution that reads it next in GC_PREC_BF16 mode. */
+int gc_instnorm_act_fwd(const float* x, float* z, void* z_bf16, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope,
+                        void* stream);
+int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, void* gx_bf16, int32_t N, int32_t HW, int32_t C, float eps,
+                        int32_t act, float slope, void* stream);
+int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, void* g_x_bf16, void* g_gz_bf16,
+                            int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream);
+
+/* BatchNorm2d fused with an optional ReLU / LeakyReLU, NHWC fp32, C a multiple of 4, P = N*H*W pixels.  Replaces
+ * aten::batch_norm (+ its backward) followed by aten::relu / aten::leaky_relu at
+ *   torch.nn.BatchNorm2d(out_dim), torch.nn.ReLU(True)          BasicGANs/models.py:37, BasicGANs/DCGAN.py:49
+ *   norm_op(out_dim), torch.nn.LeakyReLU(0.2) with BatchNorm2d  BasicGANs/models.py:79-80 (the DCGAN critic)
+ *   torch.nn.BatchNorm2d(out_ch) of the U-Net blocks            Pix2Pix/models.py:86, 127 (act = GC_ACT_NONE)
+ * training != 0: batch statistics (biased variance for the normalisation), running_mean / running_var updated with
+ *   `momentum` (unbiased variance) and *num_batches_tracked incremented, as torch.nn.BatchNorm2d does; the running
+ *   pointers may be NULL (track_running_stats = False).  training == 0: the running statistics normalise.
+ * gamma / beta may be NULL (affine = False).  save_mean / save_rstd ([C]) receive the statistics used; the backward
+ * call takes them back.  save_var (optional, [C]) receives the unbiased batch variance, for a caller that keeps the
+ * running statistics itself with gc_batchnorm_update_running (running <- (1 - momentum) running + momentum batch,
+ * counter + 1) instead of handing the running buffers to the forward call.  The backward call assumes a training-mode forward (statistics depend on x).
+ * workspace: gc_batchnorm_workspace_bytes(P, C) bytes, 16-byte aligned.  *_bf16: optional bf16 copy as above. */
+size_t gc_batchnorm_workspace_bytes(int64_t P, int32_t C);
+int gc_batchnorm_act_fwd(const float* x, float* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, float eps, float momentum, int32_t act,
+                         float slope, int32_t training, void* stream);
+int gc_batchnorm_act_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_rstd, float* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
+                         size_t workspace_bytes, int64_t P, int32_t C, int32_t act, float slope, void* stream);
+
+int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,
+                                const float* var_unbiased, int32_t C, float momentum, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around every launch while enabled.
  * gc_profile_collect synchronises on the recorded events, returns the number of kernel families written to

@@ -242,6 +242,46 @@ def test_instnorm_act_first_and_second_order(gan, shape, slope):
         assert rel(a, b) < 2e-5, name
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (256, 8, 5, 3), (3, 512, 4, 4), (2, 100, 7, 9)])
+@pytest.mark.parametrize("activation", ["relu", "leaky_relu", None])
+def test_batchnorm_act_against_torch(gan, shape, activation):
+    """Fused BatchNorm2d + activation: outputs, all three gradients, running statistics (two steps) and the
+    evaluation-mode output against torch.nn.BatchNorm2d + activation on the CPU in float64."""
+    torch.manual_seed(7)
+    N, C, H, W = shape
+    m = gan.nn.BatchNormAct2d(C, activation=activation, negative_slope=0.2).cuda()
+    ref = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(C) * 0.5 + 1); m.bias.copy_(torch.randn(C) * 0.3)
+        ref.weight.copy_(m.weight.cpu().double()); ref.bias.copy_(m.bias.cpu().double())
+    act = {"relu": torch.relu, "leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.2), None: lambda t: t}[activation]
+    for step in range(2):
+        x = (torch.randn(N, C, H, W) * 2 + 0.7).cuda().requires_grad_(True)
+        g = torch.randn(N, C, H, W).cuda()
+        xr = x.detach().cpu().double().requires_grad_(True)
+        y = m(x)
+        y.backward(g)
+        yr = act(ref(xr))
+        yr.backward(g.cpu().double())
+        assert rel(y, yr.detach().float().numpy()) < 2e-6
+        assert rel(x.grad, xr.grad.float().numpy()) < 2e-5
+        assert rel(m.weight.grad, ref.weight.grad.float().numpy()) < 2e-5
+        assert rel(m.bias.grad, ref.bias.grad.float().numpy()) < 2e-5
+        m.zero_grad(); ref.zero_grad()
+    assert rel(m.running_mean, ref.running_mean.float().numpy()) < 1e-6
+    assert rel(m.running_var, ref.running_var.float().numpy()) < 1e-6
+    assert int(m.num_batches_tracked) == 2
+    m.eval(); ref.eval()
+    x = torch.randn(N, C, H, W).cuda()
+    with torch.no_grad():
+        assert rel(m(x), act(ref(x.cpu().double())).float().numpy()) < 2e-6
+    xg = x.clone().requires_grad_(True)           # evaluation mode with gradients: elementwise path
+    m(xg).sum().backward()
+    xr = x.cpu().double().requires_grad_(True)
+    act(ref(xr)).sum().backward()
+    assert rel(xg.grad, xr.grad.float().numpy()) < 2e-6
+
+
 def _load_state(net, blob, prefix):
     sd = {k[len(prefix):]: torch.from_numpy(blob[k]) for k in blob.files if k.startswith(prefix)}
     net.load_state_dict(sd)
