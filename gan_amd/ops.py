@@ -245,7 +245,10 @@ def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: in
     if x.dtype != gy.dtype:
         gy = gy.to(x.dtype)
     x, gy = _nhwc(x), _nhwc(gy)
-    if precision == _lib.GC_PREC_BF16 and x.dtype == torch.float32:
+    # bf16 copies only where the LDS-DMA weight-gradient kernel can use them; the other kernels convert fp32 operands
+    # in registers (narrow layers are bound by reading these tensors once, a copy would only add traffic)
+    if (precision == _lib.GC_PREC_BF16 and x.dtype == torch.float32 and Cin % 8 == 0 and Cout % 8 == 0 and Cin > 32
+            and max(x.numel(), gy.numel()) * 2 < (1 << 31) - (1 << 21)):
         x, gy = _to_bf16(x), _to_bf16(gy)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
     L = _lib.lib()
