@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
 
 class Epilogue(ctypes.Structure):
     _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("bias", ctypes.c_void_p), ("ch_sum", ctypes.c_void_p),
-                ("ch_sumsq", ctypes.c_void_p), ("reserved", ctypes.c_int32 * 4)]
+                ("ch_sumsq", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("reserved", ctypes.c_int32 * 2)]
 
 
 _lib = None

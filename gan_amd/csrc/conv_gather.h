@@ -24,6 +24,7 @@ struct GatherParams {
   const float* bias;   // [OC] or null
   float* ch_sum;       // [OC] or null
   float* ch_sumsq;     // [OC] or null
+  uint16_t* out_bf16;  // null, or a bf16 copy of the fp32 output (same indexing)
   int32_t N, IH, IW, IC, ICp, OH, OW, OC, T;
   int32_t row_pitch;   // elements per packed weight row
   int32_t a, b;        // input-coordinate multiplier, output class stride

@@ -324,6 +324,8 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
       if (vec_ok && oc + 3 < p.OC) {
         if (sizeof(TIn) == 4) {
           *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
+          if (p.out_bf16 != nullptr)
+            *reinterpret_cast<u32x2*>(p.out_bf16 + pix * p.out_cstride + p.out_coff + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
         } else {
           *reinterpret_cast<u32x2*>(dst + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
         }
@@ -412,7 +414,7 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   // Split the reduction when the grid cannot fill the chip and the output can take fp32 adds.
   p.ksplit = 1;
   const long blocks = (long)tiles * p.n_oc_tiles;
-  const bool can_split = !l.in_bf16 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
+  const bool can_split = !l.in_bf16 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
   // (only for small outputs: the partial tiles are added with per-lane fp32 atomics whose access shape is slow)
   if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= 65536) {
     long want = (256 + blocks - 1) / blocks;

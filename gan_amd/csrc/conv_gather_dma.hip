@@ -238,7 +238,11 @@ __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherPa
       }
       if (!mok) continue;
       if (vec_ok && oc + 3 < p.OC) {
-        if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
+        if (sizeof(TOut) == 4) {
+          *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
+          if (p.out_bf16 != nullptr)
+            *reinterpret_cast<u32x2*>(p.out_bf16 + pix * p.out_cstride + p.out_coff + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+        }
         else *reinterpret_cast<u32x2*>(dst + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
       } else {
 #pragma unroll

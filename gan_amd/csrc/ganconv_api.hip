@@ -167,7 +167,11 @@ static int pass_dtypes(const gc_conv_desc* d, int pass, int* in_dt, int* out_dt)
 }
 
 static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream) {
-  if (plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
+  if (p.out_bf16 != nullptr && (out_dt != GC_F32 || !p.out_vec || p.OC % 4 != 0)) {
+    set_error("out_bf16 needs an fp32 output whose channel slice is a multiple of 4 channels at a multiple of 4");
+    return GC_UNSUPPORTED_GEOMETRY;
+  }
+  if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   l.big_tile_ok = true;
   plan_gather(p, l);
   // LDS-DMA path: buffer addressing with 32-bit offsets, so both tensors have to stay below 2 GiB
@@ -195,17 +199,19 @@ static double conv_flops(const gc_conv_desc* d) {
 }
 
 static void fill_epilogue(GatherParams& p, const gc_epilogue* ep) {
-  p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
+  p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.out_bf16 = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
   if (ep != nullptr) {
     p.bias = ep->bias; p.ch_sum = ep->ch_sum; p.ch_sumsq = ep->ch_sumsq; p.act = ep->act; p.slope = ep->slope;
+    p.out_bf16 = (uint16_t*)ep->out_bf16;
   }
 }
 
 static int check_epilogue(const gc_epilogue* ep) {
   if (ep == nullptr) return GC_OK;
   if (ep->act < GC_ACT_NONE || ep->act > GC_ACT_SIGMOID) { set_error("unknown activation %d", ep->act); return GC_BAD_ARGUMENT; }
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 2; i++)
     if (ep->reserved[i] != 0) { set_error("reserved epilogue fields must be zero"); return GC_BAD_ARGUMENT; }
+  if (reinterpret_cast<uintptr_t>(ep->out_bf16) & 7u) { set_error("out_bf16 must be 8-byte aligned"); return GC_BAD_ARGUMENT; }
   if (ep->ch_sumsq != nullptr && ep->ch_sum == nullptr) { set_error("ch_sumsq needs ch_sum"); return GC_BAD_ARGUMENT; }
   return GC_OK;
 }

@@ -31,19 +31,33 @@ def _check_input(x, w):
         raise RuntimeError("unreachable")
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, *, _wkey=0, precision=None):
+_ACT_CODES = {None: 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
+
+
+def _act_code(activation):
+    if activation not in _ACT_CODES:
+        raise RuntimeError(f"ganconv: activation must be one of {list(_ACT_CODES)}")
+    return _ACT_CODES[activation]
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, *, _wkey=0, precision=None, activation=None,
+           negative_slope=0.2):
+    """`activation` (None, "relu", "leaky_relu", "tanh", "sigmoid") is applied in the kernel's epilogue: the result
+    equals activation(conv2d(...)) of the unfused pair."""
     _check_input(input, weight)
     if _single(dilation, "dilation") != 1:
         raise RuntimeError("ganconv: dilation > 1 is not supported")
     if groups != 1:
         raise RuntimeError("ganconv: groups > 1 is not supported by conv2d (the StyleGAN depthwise blur is ops.blur3x3)")
     prec = ops.get_precision() if precision is None else precision
-    return ops.conv_fprop(input, weight, bias, _single(stride, "stride"), _single(padding, "padding"), prec, _wkey)
+    return ops.conv_fprop(input, weight, bias, _single(stride, "stride"), _single(padding, "padding"), prec, _wkey,
+                          _act_code(activation), float(negative_slope))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, *, _wkey=0,
-                     precision=None):
-    """weight is [Cin, Cout, kh, kw] as in torch.  Runs as the data-gradient of the mirrored convolution."""
+                     precision=None, activation=None, negative_slope=0.2):
+    """weight is [Cin, Cout, kh, kw] as in torch.  Runs as the data-gradient of the mirrored convolution.
+    `activation`: as for conv2d."""
     _check_input(input, weight)
     if _single(dilation, "dilation") != 1 or groups != 1:
         raise RuntimeError("ganconv: dilation > 1 / groups > 1 are not supported")
@@ -56,7 +70,7 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     H = (input.shape[2] - 1) * s - 2 * p + kh + op
     W = (input.shape[3] - 1) * s - 2 * p + kw + op
     prec = ops.get_precision() if precision is None else precision
-    return ops.conv_dgrad(input, weight, bias, H, W, s, p, prec, _wkey)
+    return ops.conv_dgrad(input, weight, bias, H, W, s, p, prec, _wkey, _act_code(activation), float(negative_slope))
 
 
 def blur3x3(input):

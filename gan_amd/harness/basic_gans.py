@@ -2,7 +2,8 @@
 gan_amd convolution modules.
 
 Graphs and parameter names follow BasicGANs/models.py:6-86 (`main.{i}.0.weight` ...; each BatchNorm2d + activation
-pair is one fused module that keeps BatchNorm2d's parameter and buffer names), the phases follow
+pair is one fused module that keeps BatchNorm2d's parameter and buffer names; the LeakyReLU / Tanh / Sigmoid that
+directly follows a convolution runs in that convolution's epilogue), the phases follow
 BasicGANs/loss_functions.py:4-76 and the step order BasicGANs/DCGAN.py:165-181 / BasicGANs/train.py:95-119.
 Differences that do not change results: no host synchronisation inside a phase (losses are returned as
 tensors, never .item()), and the WGAN-GP interpolation factor epsilon is an argument instead of a draw inside
@@ -30,8 +31,9 @@ class Generator(torch.nn.Module):
             first, last = i == 0, i == n_layers - 1
             cin = z_dim if first else int(width / 2 ** (i - 1))
             cout = image_dim if last else int(width / 2 ** i)
-            conv = gnn.ConvTranspose2d(cin, cout, 4, 1 if first else 2, 0 if first else 1, bias=False)
-            layers.append(_seq(conv, torch.nn.Tanh()) if last else _seq(conv, gnn.BatchNormAct2d(cout, activation="relu")))
+            conv = gnn.ConvTranspose2d(cin, cout, 4, 1 if first else 2, 0 if first else 1, bias=False,
+                                       activation="tanh" if last else None)
+            layers.append(_seq(conv) if last else _seq(conv, gnn.BatchNormAct2d(cout, activation="relu")))
         self.main = _seq(*layers)
 
     def forward(self, noise_vector):
@@ -47,15 +49,14 @@ class Discriminator(torch.nn.Module):
             first, last = i == 0, i == n_layers - 1
             cin = image_dim if first else int(hidden_dim * 2 ** (i - 1))
             cout = 1 if last else int(hidden_dim * 2 ** i)
-            ops = [gnn.Conv2d(cin, cout, 4, 1 if last else 2, 0 if last else 1, bias=False)]
+            fused = "leaky_relu" if first else ("sigmoid" if last and not is_wgan else None)
+            ops = [gnn.Conv2d(cin, cout, 4, 1 if last else 2, 0 if last else 1, bias=False, activation=fused, negative_slope=0.2)]
             if first:
-                ops.append(torch.nn.LeakyReLU(0.2, inplace=True))
+                pass
             elif not last and is_wgan:   # InstanceNorm2d + LeakyReLU(0.2) of the reference as one fused op (no parameters)
                 ops.append(gnn.InstanceNormAct2d(cout, negative_slope=0.2))
             elif not last:
                 ops.append(gnn.BatchNormAct2d(cout, activation="leaky_relu", negative_slope=0.2))
-            elif not is_wgan:
-                ops.append(torch.nn.Sigmoid())
             layers.append(_seq(*ops))
         self.main = _seq(*layers)
 

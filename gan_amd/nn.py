@@ -31,15 +31,38 @@ class _KeyedWeight:
         return key
 
 
-class Conv2d(_KeyedWeight, torch.nn.Conv2d):
+class _FusedActivation:
+    """Optional activation applied inside the convolution kernel: `activation` is None, "relu", "leaky_relu", "tanh"
+    or "sigmoid".  The module then stands for the reference's conv + activation pair (the activation module holds no
+    state, so state_dicts are unchanged)."""
+
+    def _init_activation(self, activation, negative_slope):
+        F._act_code(activation)
+        self.activation, self.negative_slope = activation, negative_slope
+
+    def extra_repr(self):
+        base = super().extra_repr()
+        return base if self.activation is None else f"{base}, activation={self.activation}"
+
+
+class Conv2d(_FusedActivation, _KeyedWeight, torch.nn.Conv2d):
+    def __init__(self, *args, activation=None, negative_slope=0.2, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._init_activation(activation, negative_slope)
+
     def _conv_forward(self, input, weight, bias):
         if self.padding_mode != "zeros":
             raise RuntimeError("ganconv: only zero padding is supported")
         key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
-        return F.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key)
+        return F.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key,
+                        activation=self.activation, negative_slope=self.negative_slope)
 
 
-class ConvTranspose2d(_KeyedWeight, torch.nn.ConvTranspose2d):
+class ConvTranspose2d(_FusedActivation, _KeyedWeight, torch.nn.ConvTranspose2d):
+    def __init__(self, *args, activation=None, negative_slope=0.2, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._init_activation(activation, negative_slope)
+
     def forward(self, input, output_size=None):
         if self.padding_mode != "zeros":
             raise RuntimeError("ganconv: only zero padding is supported")
@@ -48,7 +71,7 @@ class ConvTranspose2d(_KeyedWeight, torch.nn.ConvTranspose2d):
         weight = self.weight
         key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
         return F.conv_transpose2d(input, weight, self.bias, self.stride, self.padding, self.output_padding, self.groups,
-                                  self.dilation, _wkey=key)
+                                  self.dilation, _wkey=key, activation=self.activation, negative_slope=self.negative_slope)
 
 
 class BlurLayer(torch.nn.Module):

@@ -159,19 +159,41 @@ def _packed(desc, w, pass_, wkey):
     return buf
 
 
-def _epilogue(bias):
-    if bias is None:
+def _epilogue(bias, act=0, slope=0.0, out=None):
+    """Epilogue descriptor (or None when there is nothing to fuse) and the tensors it points to.  `out` (the fp32
+    output) gets a bf16 side copy when a later convolution can use one."""
+    twin = _bf16_twin(out) if out is not None else None
+    if bias is None and act == 0 and twin is None:
         return None, None
-    b = bias if bias.dtype == torch.float32 and bias.is_contiguous() else bias.float().contiguous()
+    b = None
     ep = Epilogue()
-    ep.act = _lib.GC_ACT_NONE
-    ep.bias = b.data_ptr()
-    return ep, b
+    ep.act, ep.slope = act, slope
+    if bias is not None:
+        b = bias if bias.dtype == torch.float32 and bias.is_contiguous() else bias.float().contiguous()
+        ep.bias = b.data_ptr()
+    if twin is not None:
+        ep.out_bf16 = twin.data_ptr()
+    return ep, (b, twin)
+
+
+def _act_backward(g, y, act, slope):
+    """Gradient through a fused epilogue activation, from its OUTPUT y (differentiable torch ops, any order)."""
+    if act == _lib.GC_ACT_NONE:
+        return g
+    if act == _lib.GC_ACT_LRELU:
+        return torch.ops.aten.leaky_relu_backward(g, y, slope, True)
+    if act == _lib.GC_ACT_RELU:
+        return torch.ops.aten.threshold_backward(g, y, 0.0)
+    if act == _lib.GC_ACT_TANH:
+        return g * (1 - y * y)
+    return g * y * (1 - y)   # sigmoid
 
 
 # ---- op implementations (run below autograd) -------------------------------------------------------------------
 @torch.library.custom_op("ganconv::conv_fprop", mutates_args=())
-def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, padding: int, precision: int, wkey: int) -> Tensor:
+def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, padding: int, precision: int, wkey: int,
+               act: int = 0, slope: float = 0.0) -> Tensor:
+    """act(conv2d(x, w) + bias); act is a gc_act code fused into the kernel's epilogue."""
     _check_cuda(x, w, bias)
     N, Cin, H, W = x.shape
     Cout, Cin_w, kh, kw = w.shape
@@ -188,7 +210,7 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     else:
         d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
     wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey)
-    ep, keep = _epilogue(bias)
+    ep, keep = _epilogue(bias, act, slope, y if (act != 0 and y.dtype == torch.float32) else None)
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_fprop")
@@ -196,7 +218,7 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
 
 
 @conv_fprop.register_fake
-def _(x, w, bias, stride, padding, precision, wkey):
+def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0):
     N, _, H, W = x.shape
     Cout, _, kh, kw = w.shape
     return x.new_empty((N, Cout, (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1))
@@ -204,7 +226,7 @@ def _(x, w, bias, stride, padding, precision, wkey):
 
 @torch.library.custom_op("ganconv::conv_dgrad", mutates_args=())
 def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, stride: int, padding: int, precision: int,
-               wkey: int) -> Tensor:
+               wkey: int, act: int = 0, slope: float = 0.0) -> Tensor:
     """gx [N, Cin, H, W] of the conv x -> y described by (w [Cout,Cin,kh,kw], stride, padding), given gy.
     `bias` ([Cin]) is added to gx: the bias of a transposed convolution whose forward pass this is."""
     _check_cuda(gy, w, bias)
@@ -222,7 +244,7 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
     else:
         d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gy), precision)
     wp = _packed(d, w, _lib.GC_PASS_DGRAD, wkey)
-    ep, keep = _epilogue(bias)
+    ep, keep = _epilogue(bias, act, slope, gx if (act != 0 and gx.dtype == torch.float32) else None)
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(gx.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_dgrad")
@@ -230,7 +252,7 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
 
 
 @conv_dgrad.register_fake
-def _(gy, w, bias, H, W, stride, padding, precision, wkey):
+def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0):
     return gy.new_empty((gy.shape[0], w.shape[1], H, W))
 
 
@@ -268,14 +290,21 @@ def _(x, gy, kh, kw, stride, padding, precision):
 
 # ---- autograd: each formula uses only the three ops above -------------------------------------------------------
 def _fprop_setup(ctx, inputs, output):
-    x, w, bias, stride, padding, precision, wkey = inputs
-    ctx.save_for_backward(x, w)
-    ctx.cfg = (stride, padding, precision, wkey, bias is not None)
+    x, w, bias, stride, padding, precision, wkey, act, slope = inputs
+    if act != 0:
+        ctx.save_for_backward(x, w, output)
+    else:
+        ctx.save_for_backward(x, w)
+    ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope)
 
 
 def _fprop_backward(ctx, gy):
-    x, w = ctx.saved_tensors
-    stride, padding, precision, wkey, has_bias = ctx.cfg
+    stride, padding, precision, wkey, has_bias, act, slope = ctx.cfg
+    if act != 0:
+        x, w, y = ctx.saved_tensors
+        gy = _act_backward(gy, y, act, slope)
+    else:
+        x, w = ctx.saved_tensors
     gx = gw = gb = None
     if ctx.needs_input_grad[0]:
         gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey)
@@ -283,21 +312,28 @@ def _fprop_backward(ctx, gy):
         gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
         gb = gy.sum((0, 2, 3))
-    return gx, gw, gb, None, None, None, None
+    return gx, gw, gb, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_fprop", _fprop_backward, setup_context=_fprop_setup)
 
 
 def _dgrad_setup(ctx, inputs, output):
-    gy, w, bias, H, W, stride, padding, precision, wkey = inputs
-    ctx.save_for_backward(gy, w)
-    ctx.cfg = (stride, padding, precision, wkey, bias is not None)
+    gy, w, bias, H, W, stride, padding, precision, wkey, act, slope = inputs
+    if act != 0:
+        ctx.save_for_backward(gy, w, output)
+    else:
+        ctx.save_for_backward(gy, w)
+    ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope)
 
 
 def _dgrad_backward(ctx, u):
-    gy, w = ctx.saved_tensors
-    stride, padding, precision, wkey, has_bias = ctx.cfg
+    stride, padding, precision, wkey, has_bias, act, slope = ctx.cfg
+    if act != 0:
+        gy, w, out = ctx.saved_tensors
+        u = _act_backward(u, out, act, slope)
+    else:
+        gy, w = ctx.saved_tensors
     g_gy = g_w = g_b = None
     if ctx.needs_input_grad[0]:
         g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey)
@@ -305,7 +341,7 @@ def _dgrad_backward(ctx, u):
         g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
         g_b = u.sum((0, 2, 3))
-    return g_gy, g_w, g_b, None, None, None, None, None, None
+    return g_gy, g_w, g_b, None, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_dgrad", _dgrad_backward, setup_context=_dgrad_setup)

@@ -83,7 +83,9 @@ typedef struct gc_epilogue {
   const float* bias;      /* float[C] or NULL */
   float* ch_sum;          /* float[C] or NULL */
   float* ch_sumsq;        /* float[C] or NULL */
-  int32_t reserved[4];    /* must be zero */
+  void* out_bf16;         /* NULL, or where to write a bf16 copy of an fp32 output (same layout and channel slice):
+                             the operand image of the convolution that reads this output next in GC_PREC_BF16 mode */
+  int32_t reserved[2];    /* must be zero */
 } gc_epilogue;
 
 int gc_version(void);

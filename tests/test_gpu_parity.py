@@ -206,6 +206,47 @@ def test_few_output_channels_transposed_conv_with_epilogue(gan, dtype):
     assert rel(got[..., 4:7].transpose(0, 3, 1, 2), ref) < (TOL_EXACT if dtype == torch.float32 else 4e-3)
 
 
+@pytest.mark.parametrize("activation", ["leaky_relu", "relu", "tanh", "sigmoid"])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_fused_activation_first_and_second_order(gan, activation, transposed):
+    """Conv2d / ConvTranspose2d with the activation in the kernel epilogue against the unfused torch CPU pair in
+    float64: output, gradients, and a gradient-penalty style double backward.  Channel counts make the kernel also
+    write its bf16 side copy, which the second convolution then consumes (bf16 mode, checked at bf16 tolerance)."""
+    torch.manual_seed(13)
+    act = {"leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.2), "relu": torch.relu, "tanh": torch.tanh,
+           "sigmoid": torch.sigmoid}[activation]
+    for prec, tol in (("fp32x3", 2e-4), ("bf16", 2e-2)):
+        gan.set_precision(prec)
+        try:
+            if transposed:
+                m1 = gan.nn.ConvTranspose2d(8, 64, 4, 2, 1, activation=activation).cuda()
+                r1 = torch.nn.ConvTranspose2d(8, 64, 4, 2, 1).double()
+            else:
+                m1 = gan.nn.Conv2d(8, 64, 3, 1, 1, activation=activation).cuda()
+                r1 = torch.nn.Conv2d(8, 64, 3, 1, 1).double()
+            m2 = gan.nn.Conv2d(64, 16, 3, 1, 1).cuda()
+            r2 = torch.nn.Conv2d(64, 16, 3, 1, 1).double()
+            r1.load_state_dict({k: v.cpu().double() for k, v in m1.state_dict().items()})
+            r2.load_state_dict({k: v.cpu().double() for k, v in m2.state_dict().items()})
+            x = torch.randn(3, 8, 10, 10).cuda().requires_grad_(True)
+            xr = x.detach().cpu().double().requires_grad_(True)
+            y, yr = m2(m1(x)), r2(act(r1(xr)))
+            assert rel(y, yr.detach().float().numpy()) < tol
+            (g,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+            (gr,) = torch.autograd.grad(yr.sum(), xr, create_graph=True)
+            # bf16 rounding moves pre-activations across the kink of a piecewise-linear activation: a few gradient
+            # entries then take the other slope, which bounds the L2 error of the gradient only coarsely
+            kink = activation in ("relu", "leaky_relu")
+            assert rel(g, gr.detach().float().numpy()) < (0.15 if kink and prec == "bf16" else tol)
+            ((g.reshape(3, -1).norm(2, dim=1) - 1) ** 2).mean().backward()
+            ((gr.reshape(3, -1).norm(2, dim=1) - 1) ** 2).mean().backward()
+            gtol = 0.3 if kink and prec == "bf16" else 10 * tol
+            assert rel(m1.weight.grad, r1.weight.grad.float().numpy()) < gtol
+            assert rel(m2.weight.grad, r2.weight.grad.float().numpy()) < gtol
+        finally:
+            gan.set_precision("bf16")
+
+
 def test_blur(gan, ops_golden):
     x = cu(ops_golden["blur.x"])
     xx = torch.cat([x, x[:, :2]], 1).requires_grad_(True)      # 8 channels (multiple of 4)
@@ -331,11 +372,14 @@ def test_dcgan_step_against_reference_trace(gan, golden_dir, prec, tol, coarse):
         G, D = H.Generator(100, hd, 3, 64), H.Discriminator(3, hd, 64)
         _load_state(G, z, "init.G."); _load_state(D, z, "init.D.")
         G.cuda(); D.cuda()
-        acts = {}
+        acts, fused = {}, {}
         for tag, net in (("G", G), ("D", D)):
             for name, mod in net.named_modules():
                 if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                    fused[(tag, name)] = mod.activation   # applied inside the conv kernel: the hook sees activation(conv)
                     mod.register_forward_hook(lambda m, i, o, key=(tag, name): acts.setdefault(key, []).append(o.detach().clone()))
+        np_act = {None: lambda v: v, "leaky_relu": lambda v: np.where(v > 0, v, 0.2 * v), "tanh": np.tanh,
+                  "sigmoid": lambda v: 1 / (1 + np.exp(-v.astype(np.float64)))}
         real, noise = cu(z["real"]), cu(z["z"])
         d_err, d_g_z1, d_x, fake = H.dcgan_discriminator_phase(G, D, real, noise)
         np.testing.assert_allclose([d_err.item(), d_g_z1.item(), d_x.item()], z["dphase.scalars"], rtol=tol)
@@ -354,7 +398,7 @@ def test_dcgan_step_against_reference_trace(gan, golden_dir, prec, tol, coarse):
             layer = ".".join(layer)
             i = counters.get((tag, layer), 0)
             counters[(tag, layer)] = i + 1
-            assert rel(acts[(tag, layer)][i], z[key]) < tol, key
+            assert rel(acts[(tag, layer)][i], np_act[fused[(tag, layer)]](z[key])) < tol, key
         for k, v in G.state_dict().items():
             if "running" in k:
                 assert rel(v, z["after.G." + k]) < tol, k
