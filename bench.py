@@ -9,7 +9,8 @@ pass, fake pass, gradient-penalty double backward, Adam step) + 1 generator iter
   value        whole-job images/s = n_gpus * 256 * K / (max over ranks of the time for K steps)
   roofline     the dominant conv kernel family: algorithmic FLOPs (2*MACs, necessary taps only) of its launches
                divided by their HIP-event time, measured on the launch stream in a profiled pass of the same
-               cycle right after the timed region; peak = dense bf16 MFMA rate of MI355X (2.5 PFLOP/s)
+               cycle right after the timed region; peak = dense bf16 MFMA rate of MI355X (2.5 PFLOP/s);
+               traffic = HBM bytes per launch of that kernel recorded by separate rocprofv3 counter passes
   cpu_baseline the same cycle on the host CPU through the oracle's restatement of the reference (stock torch
                CPU ops), rank 0 and N=1 only
 """
@@ -127,8 +128,12 @@ def main():
             name = max(conv, key=lambda k: conv[k]["total_ms"])
             v = conv[name]
             achieved = v["flops"] / (v["total_ms"] * 1e-3) / 1e12
+            traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py), if recorded
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "launches": v["launches"],
+                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "launches": v["launches"],
                         "avg_launch_us": 1e3 * v["total_ms"] / v["launches"], "avg_launch_gflop": v["flops"] / v["launches"] / 1e9,
                         "all_kernels": {k: {"launches": q["launches"], "avg_us": 1e3 * q["total_ms"] / max(q["launches"], 1),
                                             "tflops": (q["flops"] / (q["total_ms"] * 1e-3) / 1e12) if q["total_ms"] > 0 else 0.0}
