@@ -58,6 +58,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="run the cycle eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-reducer", action="store_true", help="use the data-parallel gradient reducer even with one rank (test aid)")
+    ap.add_argument("--ddp-graphs", action="store_true",
+                    help="data parallel: replay forward/backward and optimizer steps as HIP graphs with the gradient all-reduce "
+                         "between replays (experimental; the default data-parallel path launches eagerly)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32x3"])
     a = ap.parse_args()
 
@@ -70,8 +74,10 @@ def main():
         a.gpus = world
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    distributed = world > 1 or a.force_reducer
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import gan_amd
@@ -80,10 +86,10 @@ def main():
     from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
     gan_amd.set_precision(a.precision)
 
-    use_graph = not a.no_graph and world == 1
-    tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if world > 1 else None),
+    use_graph = not a.no_graph and (not distributed or a.ddp_graphs)
+    tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),
                        capturable=use_graph, batch_real_fake=True)
-    if world > 1:  # replicas start from identical parameters
+    if distributed:  # replicas start from identical parameters
         for p in list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers()):
             dist.broadcast(p.data, 0)
     gen = torch.Generator().manual_seed(5001 + rank)
@@ -94,7 +100,7 @@ def main():
         tr.capture(warmup=2)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -107,7 +113,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
@@ -158,7 +164,7 @@ def main():
             except Exception as e:  # the GPU number stands on its own
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -13,7 +13,9 @@ device 0.  Here every rank keeps its parameters resident and only gradients cros
     parameters of each bucket and launches that bucket's asynchronous all-reduce as soon as it is complete,
     while the rest of the backward pass is still running;
   * finish() launches whatever was not triggered (parameters without gradient in this phase), waits for the
-    collectives on the current stream and averages.
+    collectives on the current stream and averages;
+  * all_reduce() / average_() are the plain form for a step whose forward/backward is replayed as a HIP graph: the
+    graphs contain no collective, the buckets are reduced between two replays.
 
 Batch-coupled layers: BatchNorm statistics stay per rank (as they do under the reference's DataParallel).
 """
@@ -93,6 +95,18 @@ class GradReducer:
         for w in self._works:
             if w is not None:
                 w.wait()
+        if self.average and self.world > 1:
+            for flat in self.buckets:
+                flat.div_(self.world)
+
+    def all_reduce(self):
+        """Blocking-in-stream-order sum of every bucket over the ranks, without the hook machinery: for callers that
+        run forward/backward as a captured HIP graph and reduce between graph replays."""
+        if dist.is_available() and dist.is_initialized():
+            for flat in self.buckets:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def average_(self):
         if self.average and self.world > 1:
             for flat in self.buckets:
                 flat.div_(self.world)

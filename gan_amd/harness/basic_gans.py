@@ -223,7 +223,10 @@ class WganGpTrainer:
         return self.last
 
     def capture(self, warmup=3):
-        """Warm up on a side stream, then record one cycle into a HIP graph."""
+        """Warm up on a side stream, then record the cycle into HIP graphs.  Without gradient reducers: one graph for
+        the whole cycle.  With reducers (data parallel): per iteration one graph for zero-grad + forward/backward and
+        one for averaging + the Adam step; the gradient buckets are all-reduced between the two replays, so no
+        collective is ever captured."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -231,12 +234,56 @@ class WganGpTrainer:
                 self.cycle_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = self.cycle_eager()
-        return self.graph
+        if self.red_D is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = self.cycle_eager()
+            return self.graph
+        self.graphs, outs, pool = [], [], None
+
+        def record(fn):
+            nonlocal pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                out = fn()
+            pool = pool or g.pool()
+            return g, out
+
+        for it in range(self.reps):
+            def crit(it=it):
+                self.red_D.zero_grad()
+                return wgan_critic_phase(self.net_G, self.net_D, self.real, self.z[it], self.eps[it], self.c_lambda, None,
+                                         self.batch_real_fake)
+            g_fb, out = record(crit)
+            g_opt, _ = record(lambda: (self.red_D.average_(), self.opt_D.step(), gops.clear_cast_cache()))
+            self.graphs += [(g_fb, self.red_D), (g_opt, None)]
+            outs += list(out)
+
+        def gen():
+            self.red_G.zero_grad()
+            for p in self.net_D.parameters():
+                p.requires_grad_(False)
+            out = wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], None)
+            for p in self.net_D.parameters():
+                p.requires_grad_(True)
+            return out
+        g_fb, out = record(gen)
+        g_opt, _ = record(lambda: (self.red_G.average_(), self.opt_G.step(), gops.clear_cast_cache()))
+        self.graphs += [(g_fb, self.red_G), (g_opt, None)]
+        outs.append(out)
+        self.static_out = torch.stack([o.reshape(()) for o in outs])   # (a view-free copy made once; refreshed in cycle())
+        self._outs = outs
+        self.graph = self.graphs[0][0]
+        return self.graphs
 
     def cycle(self):
+        if getattr(self, "graphs", None):
+            for g, red in self.graphs:
+                g.replay()
+                if red is not None:
+                    red.all_reduce()
+            self.static_out = torch.stack([o.reshape(()) for o in self._outs])
+            return self.static_out
         if self.graph is not None:
             self.graph.replay()
             return self.static_out
