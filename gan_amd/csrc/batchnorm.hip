@@ -311,8 +311,8 @@ int gc_batchnorm_act_bwd(const float* x, const float* gy, const float* gamma, co
   }
   hipStream_t s = (hipStream_t)stream;
   if (P == 0) {
-    if (check_hip(hipMemsetAsync(ggamma, 0, sizeof(float) * C, s), "hipMemsetAsync")) return GC_HIP_ERROR;
-    return check_hip(hipMemsetAsync(gbeta, 0, sizeof(float) * C, s), "hipMemsetAsync");
+    if (zero_fill(ggamma, sizeof(float) * C, s) != GC_OK) return GC_HIP_ERROR;
+    return zero_fill(gbeta, sizeof(float) * C, s);
   }
   const size_t need = gc_batchnorm_workspace_bytes(P, C);
   if (workspace_bytes < need) { set_error("batchnorm: workspace of %zu bytes given, %zu needed", workspace_bytes, need); return GC_WORKSPACE_TOO_SMALL; }

@@ -80,6 +80,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// Zero-fill as an ordinary kernel (a memset node recorded into a HIP graph was seen not to take effect on replay).
+int zero_fill(void* ptr, size_t bytes, hipStream_t stream);   // bytes a multiple of 4, ptr 4-byte aligned
+
 // ---------------------------------------------------------------------------------------------------------
 // Host-side bookkeeping shared by the translation units.
 void set_error(const char* fmt, ...);

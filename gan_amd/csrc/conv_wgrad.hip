@@ -391,7 +391,7 @@ int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
 }
 
 int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream) {
-  if (check_hip(hipMemsetAsync(gb, 0, sizeof(float) * C, stream), "hipMemsetAsync")) return GC_HIP_ERROR;
+  if (zero_fill(gb, sizeof(float) * C, stream) != GC_OK) return GC_HIP_ERROR;
   if (K <= 0 || C <= 0) return GC_OK;
   int kpb = (K + 1023) / 1024;
   if (kpb < 64) kpb = 64;

@@ -198,6 +198,19 @@ static double conv_flops(const gc_conv_desc* d) {
   return 2.0 * d->N * d->Ho * d->Wo * (double)d->Cout * d->Cin * d->kh * d->kw;
 }
 
+__global__ __launch_bounds__(kThreads) void zero_fill_kernel(uint32_t* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) p[i] = 0u;
+}
+
+int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
+  const size_t n = bytes / 4;
+  if (n == 0) return GC_OK;
+  size_t blocks = (n + kThreads - 1) / kThreads;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, (uint32_t*)ptr, n);
+  return check_hip(hipGetLastError(), "zero_fill launch");
+}
+
 static void fill_epilogue(GatherParams& p, const gc_epilogue* ep) {
   p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.out_bf16 = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
   if (ep != nullptr) {

@@ -234,6 +234,10 @@ class WganGpTrainer:
                 self.cycle_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # images packed during the warm-up must not be hit inside the capture: their pack kernels would be missing
+        # from the graph and replays would keep reading the weights of the moment of recording
+        gops.clear_weight_cache()
+        gops.clear_cast_cache()
         if self.red_D is None:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):

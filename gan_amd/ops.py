@@ -103,6 +103,13 @@ def clear_cast_cache():
     _cast_cache.clear()
 
 
+def clear_weight_cache():
+    """Forget every packed weight image.  Needed before recording a HIP graph: an image packed before the capture
+    would be a cache hit inside it, the pack kernel would not be part of the graph, and every replay would read
+    the weights as they were when the graph was recorded."""
+    _wcache.clear()
+
+
 def _to_bf16(t):
     key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
     ent = _cast_cache.get(key)

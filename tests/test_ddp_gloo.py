@@ -57,6 +57,13 @@ def _worker(rank, world, port, q):
         # second phase re-uses the buckets: must give the same result again
         grads2 = _critic_grads(G, D, real[sl], z[sl], eps[sl], red)
         ok = all(torch.allclose(a, b, rtol=1e-10, atol=1e-14) for a, b in zip(grads, grads2))
+        # plain form (forward/backward replayed as a graph, buckets reduced between replays): same numbers
+        red.zero_grad()
+        from gan_amd.harness.basic_gans import wgan_critic_phase
+        wgan_critic_phase(G, D, real[sl], z[sl], eps[sl], 10.0, None, True)   # real + fake as one batch, no hooks armed
+        red.all_reduce(); red.average_()
+        grads3 = [p.grad.detach().clone() for p in D.parameters()]
+        ok = ok and all(torch.allclose(a, b, rtol=1e-8, atol=1e-12) for a, b in zip(grads, grads3))
         q.put((rank, [g.numpy() for g in grads], len(red.buckets), ok))
     finally:
         dist.destroy_process_group()

@@ -618,3 +618,31 @@ def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coars
         assert rel(img[:, :, 32:96, 32:96], z["image_crop"]) < 20 * tol
     finally:
         gan.set_precision("bf16")
+
+
+@pytest.mark.parametrize("with_reducer", [False, True], ids=["one_graph", "graph_per_phase"])
+def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer):
+    """The WGAN-GP cycle recorded into HIP graphs (the benchmark's mode; with a gradient reducer: one graph per
+    forward/backward and per optimizer step) must reproduce the eager cycles step for step: every loss of three
+    consecutive cycles, i.e. weights really move between replays (packed weight images are rebuilt inside the graph)
+    and nothing depends on memory that is only zero the first time."""
+    from gan_amd.ddp import GradReducer
+    from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
+    B = 8
+
+    def make():
+        tr = WganGpTrainer(B, 32, 100, 64, device="cuda:0", reducer_factory=GradReducer if with_reducer else None,
+                           capturable=True, batch_real_fake=True)
+        g = torch.Generator().manual_seed(5001)
+        real, zs = synth_inputs(g, B, 100, 64, 6)
+        tr.set_inputs(real, zs, torch.rand(5, B, 1, 1, 1, generator=g))
+        return tr
+
+    a, b = make(), make()
+    ref = [a.cycle_eager().cpu() for _ in range(2 + 3)]
+    b.capture(warmup=2)
+    for i in range(3):
+        out = b.cycle().cpu()
+        assert torch.isfinite(out).all()
+        assert torch.allclose(out, ref[2 + i], rtol=2e-3, atol=1e-4), (i, out, ref[2 + i])
+    assert not torch.allclose(ref[2], ref[4], rtol=1e-3)      # the losses do change from cycle to cycle
