@@ -59,10 +59,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the cycle eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-reducer", action="store_true", help="use the data-parallel gradient reducer even with one rank (test aid)")
-    ap.add_argument("--ddp-graphs", action="store_true",
-                    help="data parallel: replay forward/backward and optimizer steps as HIP graphs with the gradient all-reduce "
-                         "between replays (experimental; the default data-parallel path launches eagerly)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32x3"])
+    ap.add_argument("--ddp-eager", action="store_true",
+                    help="data parallel: launch every kernel eagerly (default: forward/backward and optimizer steps are HIP "
+                         "graphs, the gradient buckets are all-reduced between two replays)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,7 +85,7 @@ def main():
     from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
     gan_amd.set_precision(a.precision)
 
-    use_graph = not a.no_graph and (not distributed or a.ddp_graphs)
+    use_graph = not a.no_graph and not (distributed and a.ddp_eager)
     tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),
                        capturable=use_graph, batch_real_fake=True)
     if distributed:  # replicas start from identical parameters
