@@ -416,8 +416,7 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   const long blocks = (long)tiles * p.n_oc_tiles;
   const bool can_split = !l.in_bf16 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
   // (only for small outputs: the partial tiles are added with per-lane fp32 atomics whose access shape is slow)
-  static const bool no_split = getenv("GC_NO_KSPLIT") != nullptr;   // debugging aid
-  if (!no_split && can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= 65536) {
+  if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= 65536) {
     long want = (256 + blocks - 1) / blocks;
     if (want > min_steps / 8) want = min_steps / 8;
     if (want > 32) want = 32;

@@ -465,7 +465,7 @@ def test_double_backward_closure_against_torch_cpu(gan):
 
 
 def test_full_size_properties(gan):
-    """BASELINE-size layers (WGAN-GP-64 at batch 256), checked through properties that need no oracle run:
+    """Benchmark-size layers (WGAN-GP-64 at batch 256), checked through properties that need no oracle run:
     adjointness <conv(x), gy> = <x, dgrad(gy)> = <w, wgrad(x, gy)> and linearity in x."""
     torch.manual_seed(1)
     prec = gan._lib.GC_PREC_F32X3
