@@ -58,10 +58,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="run the cycle eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="launch weight-gradient kernels on a second stream beside the data gradient (measured: about 1 %% faster)")
     ap.add_argument("--force-reducer", action="store_true", help="use the data-parallel gradient reducer even with one rank (test aid)")
     ap.add_argument("--ddp-eager", action="store_true",
                     help="data parallel: launch every kernel eagerly (default: forward/backward and optimizer steps are HIP "
                          "graphs, the gradient buckets are all-reduced between two replays)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32x3"])
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,6 +87,7 @@ def main():
     from gan_amd.ddp import GradReducer
     from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
     gan_amd.set_precision(a.precision)
+    gan_amd.set_backward_overlap(a.overlap)   # weight-gradient kernels on a second stream, beside the data gradient
 
     use_graph = not a.no_graph and not (distributed and a.ddp_eager)
     tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),

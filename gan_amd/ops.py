@@ -69,6 +69,59 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- backward overlap: weight gradient on a second stream --------------------------------------------------------
+# The data gradient and the weight gradient of a convolution are independent given the output gradient.  With the
+# overlap switched on, the weight-gradient kernels (incl. the split reduction) are launched on a side stream that
+# forks from the current stream after the operands are ready and is joined before the autograd formula returns;
+# mid-size layers leave half the CUs idle during their load and store phases, which the other kernel then fills.
+# All memory is allocated in the current stream's context and kept alive until the join, so the caching allocator
+# never sees the side stream.  Works inside HIP-graph capture (the fork/join becomes two graph branches).
+_overlap = False
+_side_streams = {}
+_side_keep = []       # workspaces and operand copies in use on the side stream
+
+
+def set_backward_overlap(on):
+    global _overlap
+    _overlap = bool(on)
+
+
+def get_backward_overlap():
+    return _overlap
+
+
+class _SideLaunch:
+    """Context of one weight-gradient launch on the side stream (entered by the autograd formulas)."""
+    active = None
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        side = _side_streams.get(device)
+        if side is None:
+            side = _side_streams[device] = torch.cuda.Stream(device)
+        self.side = side
+        self.forked = False
+
+    def __enter__(self):
+        _SideLaunch.active = self
+        return self
+
+    def __exit__(self, *exc):
+        _SideLaunch.active = None
+
+    def fork(self, *keep):
+        """Called by the op right before its launches: everything enqueued so far (operand copies) is waited for."""
+        self.side.wait_stream(self.main)
+        self.forked = True
+        _side_keep.extend(keep)
+        return ctypes.c_void_p(self.side.cuda_stream)
+
+    def join(self):
+        if self.forked:
+            self.main.wait_stream(self.side)
+            _side_keep.clear()
+
+
 def _check_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -284,9 +337,11 @@ def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: in
     gw = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
     ws_bytes = L.gc_wgrad_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    side = _SideLaunch.active
+    stream = side.fork(ws, x, gy, gw) if side is not None else _stream()
     _lib.check(L.gc_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(gy.data_ptr()),
                                  ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), 1.0, 0, None,
-                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "gc_conv2d_wgrad")
+                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream), "gc_conv2d_wgrad")
     return gw
 
 
@@ -313,10 +368,17 @@ def _fprop_backward(ctx, gy):
     else:
         x, w = ctx.saved_tensors
     gx = gw = gb = None
-    if ctx.needs_input_grad[0]:
+    if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and gy.is_cuda:
+        with _SideLaunch(gy.device) as side:
+            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision)
         gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey)
-    if ctx.needs_input_grad[1]:
-        gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
+        side.join()
+        gw = gw.to(w.dtype)
+    else:
+        if ctx.needs_input_grad[0]:
+            gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey)
+        if ctx.needs_input_grad[1]:
+            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
         gb = gy.sum((0, 2, 3))
     return gx, gw, gb, None, None, None, None, None, None
@@ -342,10 +404,17 @@ def _dgrad_backward(ctx, u):
     else:
         gy, w = ctx.saved_tensors
     g_gy = g_w = g_b = None
-    if ctx.needs_input_grad[0]:
+    if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and u.is_cuda:
+        with _SideLaunch(u.device) as side:
+            g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision)
         g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey)
-    if ctx.needs_input_grad[1]:
-        g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
+        side.join()
+        g_w = g_w.to(w.dtype)
+    else:
+        if ctx.needs_input_grad[0]:
+            g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey)
+        if ctx.needs_input_grad[1]:
+            g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
         g_b = u.sum((0, 2, 3))
     return g_gy, g_w, g_b, None, None, None, None, None, None, None, None
