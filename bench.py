@@ -127,9 +127,10 @@ def main():
     roofline = None
     if rank == 0:
         _lib.profile_enable(True)
-        for _ in range(2):
-            tr.cycle_eager()
-        torch.cuda.synchronize()
+    for _ in range(2):        # every rank runs the cycles: with more than one rank they contain collectives
+        tr.cycle_eager()
+    torch.cuda.synchronize()
+    if rank == 0:
         prof = _lib.profile_collect()
         _lib.profile_enable(False)
         conv = {k: v for k, v in prof.items() if v["flops"] > 0}
