@@ -139,7 +139,7 @@ def main():
             v = conv[name]
             achieved = v["flops"] / (v["total_ms"] * 1e-3) / 1e12
             traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py), if recorded
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            tpath = os.path.join(ROOT, "bench_traffic.json")   # copy of the newest profiles/r*_traffic.json
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
