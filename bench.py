@@ -91,7 +91,7 @@ def main():
 
     use_graph = not a.no_graph and not (distributed and a.ddp_eager)
     tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),
-                       capturable=use_graph, batch_real_fake=True)
+                       capturable=use_graph, batch_real_fake=True, fused_adam=True)
     if distributed:  # replicas start from identical parameters
         for p in list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers()):
             dist.broadcast(p.data, 0)

@@ -20,7 +20,7 @@ EXPORTS = (
     "gc_version", "gc_last_error", "gc_packed_weight_bytes", "gc_pack_weight", "gc_conv2d_fprop", "gc_conv2d_dgrad",
     "gc_wgrad_workspace_bytes", "gc_conv2d_wgrad", "gc_dwblur3x3", "gc_profile_enable", "gc_profile_collect",
     "gc_instnorm_act_fwd", "gc_instnorm_act_bwd", "gc_instnorm_act_bwd_bwd",
-    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running",
+    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_adam_step",
 )
 
 
@@ -69,6 +69,8 @@ def lib():
     L.gc_batchnorm_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, f32, f32, i32, f32, i32, vp]
     L.gc_batchnorm_update_running.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp]
     L.gc_batchnorm_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, f32, vp]
+    L.gc_adam_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp]
+    L.gc_adam_step.restype = ctypes.c_int
     L.gc_profile_enable.argtypes = [ctypes.c_int]
     L.gc_profile_collect.argtypes = [ctypes.c_int, vp, vp, vp, vp]
     for fn in ("gc_pack_weight", "gc_conv2d_fprop", "gc_conv2d_dgrad", "gc_conv2d_wgrad", "gc_dwblur3x3", "gc_profile_enable",

@@ -15,6 +15,7 @@ import torch
 
 from .. import nn as gnn
 from .. import ops as gops
+from .. import optim as goptim
 
 
 def _seq(*m):
@@ -159,7 +160,7 @@ class WganGpTrainer:
     cycle can be captured into one HIP graph (no host work, no allocation, no synchronisation per cycle)."""
 
     def __init__(self, batch, hidden_dim=64, z_dim=100, resolution=64, device="cuda", lr=1e-4, betas=(0.0, 0.9),
-                 c_lambda=10.0, disc_repeats=5, seed=5000, reducer_factory=None, capturable=True, batch_real_fake=False):
+                 c_lambda=10.0, disc_repeats=5, seed=5000, reducer_factory=None, capturable=True, batch_real_fake=False, fused_adam=False):
         torch.manual_seed(seed)
         self.B, self.nz, self.res, self.reps, self.c_lambda = batch, z_dim, resolution, disc_repeats, c_lambda
         self.batch_real_fake = batch_real_fake
@@ -170,10 +171,13 @@ class WganGpTrainer:
         self.net_D.apply(weights_init)
         self.net_G.to(self.device)
         self.net_D.to(self.device)
-        cap = capturable and self.device.type == "cuda"
-        kind = {"foreach": True}
-        self.opt_D = torch.optim.Adam(self.net_D.parameters(), lr=lr, betas=betas, capturable=cap, **kind)
-        self.opt_G = torch.optim.Adam(self.net_G.parameters(), lr=lr, betas=betas, capturable=cap, **kind)
+        if fused_adam and self.device.type == "cuda":     # one launch per step, device-side step counter (capturable)
+            self.opt_D = goptim.Adam(self.net_D.parameters(), lr=lr, betas=betas)
+            self.opt_G = goptim.Adam(self.net_G.parameters(), lr=lr, betas=betas)
+        else:
+            cap = capturable and self.device.type == "cuda"
+            self.opt_D = torch.optim.Adam(self.net_D.parameters(), lr=lr, betas=betas, capturable=cap, foreach=True)
+            self.opt_G = torch.optim.Adam(self.net_G.parameters(), lr=lr, betas=betas, capturable=cap, foreach=True)
         cl = torch.channels_last
         self.real = torch.zeros(batch, 3, resolution, resolution, device=self.device).contiguous(memory_format=cl)
         self.z = torch.zeros(disc_repeats + 1, batch, z_dim, 1, 1, device=self.device)

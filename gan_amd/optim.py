@@ -1,0 +1,67 @@
+"""torch.optim.Adam as one fused launch (plus a one-thread counter tick) per step.
+
+Drop-in for the reference's `torch.optim.Adam(net.parameters(), lr=..., betas=...)` (BasicGANs/train.py:79-80,
+Pix2Pix/train.py, StyleGAN/train.py, BigGAN/train.py): same constructor arguments for the features the reference uses
+(lr, betas, eps; weight_decay / amsgrad / maximize must stay at their defaults), same arithmetic in the same order.
+The step counter lives on the device, so step() can be recorded into a HIP graph.  State per parameter: `exp_avg`,
+`exp_avg_sq`; per group: `step` (a device float tensor shared by the group's parameters)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False, **unused):
+        if weight_decay != 0 or amsgrad or maximize:
+            raise ValueError("gan_amd.optim.Adam supports weight_decay=0, amsgrad=False, maximize=False only")
+        if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._tables = {}
+
+    def _table(self, gi, params):
+        """Host arrays of device pointers for the parameters that have a gradient; rebuilt when anything moved."""
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+        ent = self._tables.get(gi)
+        if ent is not None and ent[0] == sig:
+            return ent[1]
+        n = len(params)
+        vp, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+        st = [self.state[p] for p in params]
+        arrays = (n, vp(*[p.data_ptr() for p in params]), vp(*[p.grad.data_ptr() for p in params]),
+                  vp(*[s["exp_avg"].data_ptr() for s in st]), vp(*[s["exp_avg_sq"].data_ptr() for s in st]),
+                  i64(*[p.numel() for p in params]))
+        self._tables[gi] = (sig, arrays)
+        return arrays
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            for p in params:
+                if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                    raise RuntimeError("gan_amd.optim.Adam: parameters and gradients must be dense float32 tensors on the GPU")
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("gan_amd.optim.Adam: parameters and gradients must be contiguous")
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if "step" not in group:
+                group["step"] = torch.zeros((), dtype=torch.float32, device=params[0].device)
+            n, pp, gp, mp, vp, ne = self._table(gi, params)
+            b1, b2 = group["betas"]
+            _lib.check(_lib.lib().gc_adam_step(n, pp, gp, mp, vp, ne, ctypes.c_void_p(group["step"].data_ptr()), float(group["lr"]),
+                                               float(b1), float(b2), float(group["eps"]),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gc_adam_step")
+            for p in params:     # the kernel wrote through raw pointers: tell autograd (and every cache keyed on the
+                torch.autograd.graph.increment_version(p)      # version, e.g. packed weight images) that p changed
+        return loss

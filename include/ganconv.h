@@ -176,6 +176,14 @@ int gc_batchnorm_act_bwd(const float* x, const float* gy, const float* gamma, co
 int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,
                                 const float* var_unbiased, int32_t C, float momentum, void* stream);
 
+/* One torch.optim.Adam step (amsgrad = false, weight_decay = 0) for n fp32 tensors in two launches.  Replaces the
+ * per-tensor / foreach kernels behind optimizer_D.step() / optimizer_G.step() of the reference's training loops (the
+ * optimizers are built at BasicGANs/train.py:79-80).  The arrays are host arrays of device
+ * pointers; *step (device float, the number of steps taken so far) is incremented first, so the call can be part of
+ * a HIP graph.  Same operation order as torch's single-tensor Adam. */
+int gc_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int64_t* numel, float* step, float lr, float beta1, float beta2, float eps, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around every launch while enabled.
  * gc_profile_collect synchronises on the recorded events, returns the number of kernel families written to
  * the caller's arrays (at most max_entries) and resets the records.  flops[] holds the algorithmic FLOPs

@@ -486,8 +486,9 @@ def test_full_size_properties(gan):
         assert rel(y12, (y + 2 * y2)) < 5e-5
 
 
-@pytest.mark.parametrize("batched", [False, True], ids=["separate_passes", "real_fake_batched"])
-def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched):
+@pytest.mark.parametrize("batched,fused_adam", [(False, False), (True, False), (True, True)],
+                         ids=["separate_passes", "real_fake_batched", "real_fake_batched_fused_adam"])
+def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched, fused_adam):
     """Full-size WGAN-GP-64 (hidden 64) at batch 64 with Adam: five critic iterations + one generator iteration
     of the reference (golden losses), fp32x3 path; weights and inputs regenerated from the recorded seeds.
     `batched` runs the real and fake critic passes as one batch of 2B (the benchmark's setting)."""
@@ -497,7 +498,7 @@ def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched):
     gan.set_precision("fp32x3")
     try:
         tr = H.WganGpTrainer(cfg["B"], cfg["hidden_dim"], cfg["nz"], cfg["res"], lr=cfg["lr"], betas=tuple(cfg["betas"]),
-                             seed=cfg["seed"], capturable=False, batch_real_fake=batched)
+                             seed=cfg["seed"], capturable=False, batch_real_fake=batched, fused_adam=fused_adam)
         # same init as the reference run: seed, then G init, then D init on the CPU generator
         torch.manual_seed(cfg["seed"])
         G = R.Generator(cfg["nz"], cfg["hidden_dim"], 3, resolution=cfg["res"]); G.apply(R.weights_init)
@@ -620,9 +621,10 @@ def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coars
         gan.set_precision("bf16")
 
 
+@pytest.mark.parametrize("fused_adam", [False, True], ids=["torch_adam", "fused_adam"])
 @pytest.mark.parametrize("overlap", [False, True], ids=["serial_backward", "wgrad_on_side_stream"])
 @pytest.mark.parametrize("with_reducer", [False, True], ids=["one_graph", "graph_per_phase"])
-def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap):
+def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused_adam):
     """The WGAN-GP cycle recorded into HIP graphs (the benchmark's mode; with a gradient reducer: one graph per
     forward/backward and per optimizer step) must reproduce the eager cycles step for step: every loss of three
     consecutive cycles, i.e. weights really move between replays (packed weight images are rebuilt inside the graph)
@@ -633,13 +635,13 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap):
 
     def make():
         tr = WganGpTrainer(B, 32, 100, 64, device="cuda:0", reducer_factory=GradReducer if with_reducer else None,
-                           capturable=True, batch_real_fake=True)
+                           capturable=True, batch_real_fake=True, fused_adam=fused_adam)
         g = torch.Generator().manual_seed(5001)
         real, zs = synth_inputs(g, B, 100, 64, 6)
         tr.set_inputs(real, zs, torch.rand(5, B, 1, 1, 1, generator=g))
         return tr
 
-    a, b = make(), make()
+    a, b = make(), make()     # same optimizer on both sides: the training dynamics amplify last-bit differences between them
     ref = [a.cycle_eager().cpu() for _ in range(2 + 3)]
     gan.set_backward_overlap(overlap)     # the recorded (and its warm-up) cycles fork the weight gradients to a side stream
     try:
@@ -651,3 +653,31 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap):
     finally:
         gan.set_backward_overlap(False)
     assert not torch.allclose(ref[2], ref[4], rtol=1e-3)      # the losses do change from cycle to cycle
+
+
+@pytest.mark.parametrize("betas", [(0.0, 0.9), (0.5, 0.999)])
+def test_fused_adam_matches_torch_adam(gan, betas):
+    """gan_amd.optim.Adam against torch.optim.Adam on the same parameters and gradients over several steps
+    (odd sizes, a parameter without gradient, a second parameter group)."""
+    torch.manual_seed(3)
+    shapes = [(64, 3, 4, 4), (128,), (5, 7, 3), (1,), (300, 129)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = gan.optim.Adam([{"params": pa[:3]}, {"params": pa[3:], "lr": 3e-3}], lr=1e-3, betas=betas)
+    ob = torch.optim.Adam([{"params": pb[:3]}, {"params": pb[3:], "lr": 3e-3}], lr=1e-3, betas=betas)
+    for step in range(6):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 2 and step < 2:
+                a.grad = b.grad = None            # joins later: its own moments start then, the group's counter is shared
+                continue
+            g = torch.randn_like(a) * (10.0 ** (step - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        va = pa[0]._version
+        oa.step(); ob.step()
+        assert pa[0]._version > va          # in-place update is visible to version-keyed caches
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        if i == 2:
+            continue      # torch counts steps per parameter, the fused optimizer per group: they differ for a late joiner
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), i
+    with pytest.raises(ValueError):
+        gan.optim.Adam(pa, weight_decay=0.1)
