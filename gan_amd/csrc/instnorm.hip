@@ -157,6 +157,8 @@ static int launch_instnorm(int mode, const float* x, const float* gz, const floa
   }
   InstNormParams p{x, gz, u, out0, out1, (uint16_t*)out0_bf16, (uint16_t*)out1_bf16, N, HW, C, 0, eps, slope, act};
   while ((1 << p.qb_log2) < C / 4 && p.qb_log2 < 4) p.qb_log2++;
+  // few samples with large images: narrower channel runs per workgroup (down to 16 channels) to fill the CUs
+  while (p.qb_log2 > 2 && (long)N * ((C / 4 + (1 << p.qb_log2) - 1) >> p.qb_log2) < 512 && HW >= 1024) p.qb_log2--;
   const int QB = 1 << p.qb_log2;
   const int chunks = (C / 4 + QB - 1) / QB;
   const dim3 grid((unsigned)N * chunks), block(kThreads);

@@ -257,7 +257,7 @@ def test_blur(gan, ops_golden):
     assert rel(xx.grad, oracle.dwblur3x3(g.cpu().numpy())) < 1e-6   # self-adjoint
 
 
-@pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 128, 16, 16), (2, 512, 4, 4), (1, 8, 5, 7)])
+@pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 128, 16, 16), (2, 512, 4, 4), (1, 8, 5, 7), (2, 64, 32, 32), (1, 40, 40, 33)])
 @pytest.mark.parametrize("slope", [0.2, None])
 def test_instnorm_act_first_and_second_order(gan, shape, slope):
     """Fused InstanceNorm (+LeakyReLU) forward, backward and double backward against stock torch CPU autograd
