@@ -65,6 +65,8 @@ def main():
                     help="data parallel: launch every kernel eagerly (default: forward/backward and optimizer steps are HIP "
                          "graphs, the gradient buckets are all-reduced between two replays)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32x3"])
+    ap.add_argument("--fp32-activations", action="store_true",
+                    help="store the activations between the layers in fp32 (default: bf16 storage, fp32 accumulation and statistics)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +93,8 @@ def main():
 
     use_graph = not a.no_graph and not (distributed and a.ddp_eager)
     tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),
-                       capturable=use_graph, batch_real_fake=True, fused_adam=True)
+                       capturable=use_graph, batch_real_fake=True, fused_adam=True,
+                       activation_dtype=torch.float32 if a.fp32_activations else torch.bfloat16)
     if distributed:  # replicas start from identical parameters
         for p in list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers()):
             dist.broadcast(p.data, 0)
@@ -155,8 +158,10 @@ def main():
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.precision == "bf16" else "bf16x3", "data": "synthetic",
             "config": {"workload": "BasicGANs WGAN-GP 64x64 (hidden 64, nz 100), batch 256 per GPU; step = 5 critic iterations "
-                                   "(real and fake critic passes batched into one 512-sample pass; gradient-penalty double backward) + 1 generator iteration, Adam; activations fp32 NHWC, "
-                                   "conv operands bf16 on MFMA with fp32 accumulate",
+                                   "(real and fake critic passes batched into one 512-sample pass; gradient-penalty double backward) + 1 generator iteration, Adam; activations " +
+                                   ("fp32" if a.fp32_activations else "stored in bf16 between layers (images, scores, normalisation statistics and all accumulation fp32)") +
+                                   ", NHWC; conv operands bf16 on MFMA with fp32 accumulate",
+                       "activation_storage": "fp32" if a.fp32_activations else "bf16",
                        "global_batch": world * BATCH, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "losses_finite": finite},
             "roofline": roofline,

@@ -20,7 +20,7 @@ EXPORTS = (
     "gc_version", "gc_last_error", "gc_packed_weight_bytes", "gc_pack_weight", "gc_conv2d_fprop", "gc_conv2d_dgrad",
     "gc_wgrad_workspace_bytes", "gc_conv2d_wgrad", "gc_dwblur3x3", "gc_profile_enable", "gc_profile_collect",
     "gc_instnorm_act_fwd", "gc_instnorm_act_bwd", "gc_instnorm_act_bwd_bwd",
-    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_adam_step",
+    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_adam_step", "gc_set_split_reduction",
 )
 
 
@@ -49,6 +49,7 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64p = ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)
     L.gc_version.restype = ctypes.c_int
+    L.gc_set_split_reduction.argtypes = [ctypes.c_int]
     L.gc_last_error.restype = ctypes.c_char_p
     L.gc_packed_weight_bytes.restype = ctypes.c_size_t
     L.gc_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int]
@@ -60,15 +61,15 @@ def lib():
     L.gc_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, i64p, ctypes.c_float, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]
     L.gc_dwblur3x3.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     f32 = ctypes.c_float
-    L.gc_instnorm_act_fwd.argtypes = [vp, vp, vp, i32, i32, i32, f32, i32, f32, vp]
-    L.gc_instnorm_act_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, vp]
-    L.gc_instnorm_act_bwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, vp]
+    L.gc_instnorm_act_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp]
+    L.gc_instnorm_act_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp]
+    L.gc_instnorm_act_bwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp]
     i64, sz = ctypes.c_int64, ctypes.c_size_t
     L.gc_batchnorm_workspace_bytes.restype = sz
     L.gc_batchnorm_workspace_bytes.argtypes = [i64, i32]
-    L.gc_batchnorm_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, f32, f32, i32, f32, i32, vp]
+    L.gc_batchnorm_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, f32, f32, i32, f32, i32, vp]
     L.gc_batchnorm_update_running.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp]
-    L.gc_batchnorm_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, f32, vp]
+    L.gc_batchnorm_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, i32, f32, vp]
     L.gc_adam_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp]
     L.gc_adam_step.restype = ctypes.c_int
     L.gc_profile_enable.argtypes = [ctypes.c_int]

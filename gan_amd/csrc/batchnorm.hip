@@ -1,4 +1,5 @@
-// BatchNorm2d (training-mode batch statistics or running statistics) fused with ReLU / LeakyReLU, NHWC fp32:
+// BatchNorm2d (training-mode batch statistics or running statistics) fused with ReLU / LeakyReLU, NHWC fp32 or bf16
+// activations (fp32 arithmetic, statistics and parameters):
 // forward and first-order backward.
 //
 //   forward    y  = act(a * x + b),  a = gamma * r,  b = beta - mu * a,  mu / r = per-channel mean and
@@ -16,10 +17,10 @@
 
 namespace gc {
 
-struct BnParams {
-  const float* x;
-  const float* gy;
-  float* out;            // y | gx
+struct BnParams {          // x / gy / out are fp32 or bf16 (template parameter), all of one type; the rest is fp32
+  const void* x;
+  const void* gy;
+  void* out;             // y | gx
   uint16_t* out_bf16;    // optional bf16 copy of out
   const float* gamma;    // may be null (1)
   const float* beta;     // may be null (0)
@@ -62,7 +63,7 @@ __device__ __forceinline__ f32x4 act_mask(f32x4 pre, int act, float slope) {
 }
 
 // MODE 0: forward slab statistics (mean, M2);  MODE 1: backward slab sums (sum g, sum g * xh)
-template <int MODE>
+template <int MODE, typename T>
 __global__ __launch_bounds__(kThreads) void bn_partial_kernel(const BnParams p) {
   __shared__ f32x4 red[kThreads];
   const int t = threadIdx.x, tq = t & (kQB - 1), tl = t >> 4;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(const BnParams p) 
   const bool cok = c < p.C;
   const int p0 = slab * p.slab_pix, p1 = min(p.P, p0 + p.slab_pix);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  auto ld = [&](const float* ptr, int pix) -> f32x4 { return *reinterpret_cast<const f32x4*>(ptr + (size_t)pix * p.C + c); };
+  auto ld = [&](const void* ptr, int pix) -> f32x4 { return load4<T>(ptr, (size_t)pix * p.C + c); };
   if (MODE == 0) {
     f32x4 s = zero;
     if (cok)
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void bn_eval_coef_kernel(const BnParams p
 }
 
 // MODE 0: y = act(a x + b);  MODE 1: gx = gamma r (g - gbeta/P - xh ggamma/P)
-template <int MODE>
+template <int MODE, typename T>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
   const int t = threadIdx.x, tq = t & (kQB - 1), tl = t >> 4;
   const int chunks = (p.C / 4 + kQB - 1) / kQB;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
   }
   for (int pix = p0 + tl; pix < p1; pix += kPL) {
     const size_t o = (size_t)pix * p.C + c;
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + o);
+    const f32x4 xv = load4<T>(p.x, o);
     f32x4 res;
     if (MODE == 0) {
       const f32x4 pre = k0 * xv + k1;
@@ -224,10 +225,10 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
       res = pre * m;
     } else {
       const f32x4 xh = (xv - mu) * r;
-      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gy + o) * act_mask(ga * xh + be, p.act, p.slope);
+      const f32x4 g = load4<T>(p.gy, o) * act_mask(ga * xh + be, p.act, p.slope);
       res = ga * r * (g - k0 - xh * k1);
     }
-    *reinterpret_cast<f32x4*>(p.out + o) = res;
+    store4<T>(p.out, o, res);
     if (p.out_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out_bf16 + o) = cvt_bf16x4(res);
   }
 }
@@ -258,10 +259,12 @@ size_t gc_batchnorm_workspace_bytes(int64_t P, int32_t C) {
   return ((size_t)p.slabs * C * 2 + 2 * (size_t)C) * sizeof(float);
 }
 
-int gc_batchnorm_act_fwd(const float* x, float* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
-                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, float eps, float momentum, int32_t act,
-                         float slope, int32_t training, void* stream) {
+                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, float eps, float momentum,
+                         int32_t act, float slope, int32_t training, void* stream) {
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("batchnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
+  if (dtype == GC_BF16 && y_bf16 != nullptr) { set_error("batchnorm: bf16 tensors need no bf16 copy"); return GC_BAD_ARGUMENT; }
   if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
   if (act != GC_ACT_NONE && act != GC_ACT_RELU && act != GC_ACT_LRELU) { set_error("batchnorm: activation must be none, ReLU or LeakyReLU"); return GC_BAD_ARGUMENT; }
   if (C % 4 != 0) { set_error("batchnorm: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
@@ -269,7 +272,8 @@ int gc_batchnorm_act_fwd(const float* x, float* y, void* y_bf16, const float* ga
   if (x == nullptr || y == nullptr || save_mean == nullptr || save_rstd == nullptr || workspace == nullptr) { set_error("batchnorm: null pointer"); return GC_BAD_ARGUMENT; }
   if (!training && (running_mean == nullptr || running_var == nullptr)) { set_error("batchnorm: evaluation mode needs running statistics"); return GC_BAD_ARGUMENT; }
   if ((running_mean == nullptr) != (running_var == nullptr)) { set_error("batchnorm: running_mean and running_var go together"); return GC_BAD_ARGUMENT; }
-  if (misaligned(x, 15) || misaligned(y, 15) || misaligned(y_bf16, 7) || misaligned(workspace, 15) || misaligned(gamma, 15) ||
+  const unsigned am = dtype == GC_F32 ? 15 : 7;
+  if (misaligned(x, am) || misaligned(y, am) || misaligned(y_bf16, 7) || misaligned(workspace, 15) || misaligned(gamma, 15) ||
       misaligned(beta, 15) || misaligned(save_mean, 15) || misaligned(save_rstd, 15)) {
     set_error("batchnorm: misaligned pointer"); return GC_BAD_ARGUMENT;
   }
@@ -287,25 +291,36 @@ int gc_batchnorm_act_fwd(const float* x, float* y, void* y_bf16, const float* ga
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
   if (training) {
-    { ProfScope ps("gc::bn_partial_kernel<0>", 0.0, s); hipLaunchKernelGGL(bn_partial_kernel<0>, grid, block, 0, s, p); }
+    {
+      ProfScope ps("gc::bn_partial_kernel<0>", 0.0, s);
+      if (dtype == GC_F32) hipLaunchKernelGGL((bn_partial_kernel<0, float>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((bn_partial_kernel<0, uint16_t>), grid, block, 0, s, p);
+    }
     { ProfScope ps("gc::bn_finalize_kernel<0>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, p); }
   } else {
     ProfScope ps("gc::bn_eval_coef_kernel", 0.0, s);
     hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + kThreads - 1) / kThreads), block, 0, s, p);
   }
-  { ProfScope ps("gc::bn_apply_kernel<0>", 0.0, s); hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, s, p); }
+  {
+    ProfScope ps("gc::bn_apply_kernel<0>", 0.0, s);
+    if (dtype == GC_F32) hipLaunchKernelGGL((bn_apply_kernel<0, float>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((bn_apply_kernel<0, uint16_t>), grid, block, 0, s, p);
+  }
   return check_hip(hipGetLastError(), "batchnorm forward launch");
 }
 
-int gc_batchnorm_act_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
-                         const float* save_rstd, float* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
-                         size_t workspace_bytes, int64_t P, int32_t C, int32_t act, float slope, void* stream) {
+int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
+                         size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream) {
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("batchnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
+  if (dtype == GC_BF16 && gx_bf16 != nullptr) { set_error("batchnorm: bf16 tensors need no bf16 copy"); return GC_BAD_ARGUMENT; }
   if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
   if (act != GC_ACT_NONE && act != GC_ACT_RELU && act != GC_ACT_LRELU) { set_error("batchnorm: activation must be none, ReLU or LeakyReLU"); return GC_BAD_ARGUMENT; }
   if (C % 4 != 0) { set_error("batchnorm: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
   if (x == nullptr || gy == nullptr || gx == nullptr || ggamma == nullptr || gbeta == nullptr || save_mean == nullptr ||
       save_rstd == nullptr || workspace == nullptr) { set_error("batchnorm: null pointer"); return GC_BAD_ARGUMENT; }
-  if (misaligned(x, 15) || misaligned(gy, 15) || misaligned(gx, 15) || misaligned(gx_bf16, 7) || misaligned(workspace, 15) ||
+  const unsigned am = dtype == GC_F32 ? 15 : 7;
+  if (misaligned(x, am) || misaligned(gy, am) || misaligned(gx, am) || misaligned(gx_bf16, 7) || misaligned(workspace, 15) ||
       misaligned(gamma, 15) || misaligned(beta, 15) || misaligned(save_mean, 15) || misaligned(save_rstd, 15)) {
     set_error("batchnorm: misaligned pointer"); return GC_BAD_ARGUMENT;
   }
@@ -326,9 +341,17 @@ int gc_batchnorm_act_bwd(const float* x, const float* gy, const float* gamma, co
   p.coef = p.part + (size_t)p.slabs * C * 2;
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
-  { ProfScope ps("gc::bn_partial_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_partial_kernel<1>, grid, block, 0, s, p); }
+  {
+    ProfScope ps("gc::bn_partial_kernel<1>", 0.0, s);
+    if (dtype == GC_F32) hipLaunchKernelGGL((bn_partial_kernel<1, float>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((bn_partial_kernel<1, uint16_t>), grid, block, 0, s, p);
+  }
   { ProfScope ps("gc::bn_finalize_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, p); }
-  { ProfScope ps("gc::bn_apply_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, s, p); }
+  {
+    ProfScope ps("gc::bn_apply_kernel<1>", 0.0, s);
+    if (dtype == GC_F32) hipLaunchKernelGGL((bn_apply_kernel<1, float>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((bn_apply_kernel<1, uint16_t>), grid, block, 0, s, p);
+  }
   return check_hip(hipGetLastError(), "batchnorm backward launch");
 }
 

@@ -39,6 +39,18 @@ __device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
   return __builtin_bit_cast(uint16_t, b);
 }
 
+// 4 consecutive channels of an fp32 or bf16 tensor as fp32 (element index idx, a multiple of 4)
+template <typename T>
+__device__ __forceinline__ f32x4 load4(const void* base, size_t idx) {
+  if (sizeof(T) == 4) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+  return widen_bf16x4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx));
+}
+template <typename T>
+__device__ __forceinline__ void store4(void* base, size_t idx, f32x4 v) {
+  if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+  else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(base) + idx) = cvt_bf16x4(v);
+}
+
 // Unsigned division by a launch-invariant divisor (Granlund-Montgomery round-up form; shift path for powers of two).
 struct FastDiv {
   uint32_t d, mul, shift, pow2;
@@ -81,6 +93,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
 }
 
 // Zero-fill as an ordinary kernel (a memset node recorded into a HIP graph was seen not to take effect on replay).
+bool split_reduction_allowed();   // process-wide switch (gc_set_split_reduction)
 int zero_fill(void* ptr, size_t bytes, hipStream_t stream);   // bytes a multiple of 4, ptr 4-byte aligned
 
 // ---------------------------------------------------------------------------------------------------------

@@ -32,6 +32,7 @@ struct GatherParams {
   int32_t act;
   float slope;
   int32_t out_vec;     // 1: 16-byte (fp32) / 8-byte (bf16) stores of 4 channels are aligned
+  int32_t out_f32;     // element type of `out`: 1 fp32, 0 bf16 (independent of the input's type)
   int32_t icp_log2;    // log2(ICp) in the thin-input mode (reduction over (tap, channel) jointly, 64 per step)
   int32_t ksplit;      // > 1: the reduction is split over ksplit workgroups that add into a zeroed fp32 output
   int32_t n_pix_tiles, n_oc_tiles;

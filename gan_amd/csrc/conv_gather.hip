@@ -291,7 +291,8 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
 #pragma unroll
     for (int r = 0; r < 4; r++) ssum[i][r] = ssq[i][r] = 0.f;
   const bool stats = p.ch_sum != nullptr;
-  TIn* out = reinterpret_cast<TIn*>(p.out);
+  const bool of32 = p.out_f32 != 0;
+  const int osz = of32 ? 4 : 2;
 #pragma unroll
   for (int j = 0; j < C::FP; j++) {
     const int m = m0 + wp_ * (TP / C::WP) + j * 16 + (lane & 15);
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
     const int ow = mm % OWc, tmp = mm / OWc;
     const int oh = tmp % OHc, n = tmp / OHc;
     const size_t pix = ((size_t)n * p.OH + (oh * p.b + p.tt.cls_ph[cls])) * p.OW + (ow * p.b + p.tt.cls_pw[cls]);
-    TIn* dst = out + pix * p.out_cstride + p.out_coff;
+    const size_t eoff = pix * p.out_cstride + p.out_coff;      // element offset of this pixel's channel slice
+    char* dst = reinterpret_cast<char*>(p.out) + eoff * osz;
 #pragma unroll
     for (int i = 0; i < C::FO; i++) {
       const int oc = oc0 + wo * (TO / C::WO) + i * 16 + (lane >> 4) * 4;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
         float x = acc[i][j][r];
         if (p.bias != nullptr && oc + r < p.OC && split == 0) x += p.bias[oc + r];
         x = apply_act(x, p.act, p.slope);
-        if (sizeof(TIn) == 2) x = bf16_bits_to_float(float_to_bf16_bits(x));
+        if (!of32) x = bf16_bits_to_float(float_to_bf16_bits(x));
         v[r] = x;
         if (stats && mok && oc + r < p.OC) { ssum[i][r] += x; ssq[i][r] += x * x; }
       }
@@ -322,18 +324,17 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
         continue;
       }
       if (vec_ok && oc + 3 < p.OC) {
-        if (sizeof(TIn) == 4) {
-          *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
-          if (p.out_bf16 != nullptr)
-            *reinterpret_cast<u32x2*>(p.out_bf16 + pix * p.out_cstride + p.out_coff + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+        if (of32) {
+          *reinterpret_cast<f32x4*>(dst + (size_t)oc * 4) = f32x4{v[0], v[1], v[2], v[3]};
+          if (p.out_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out_bf16 + eoff + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
         } else {
-          *reinterpret_cast<u32x2*>(dst + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+          *reinterpret_cast<u32x2*>(dst + (size_t)oc * 2) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; r++)
           if (oc + r < p.OC) {
-            if (sizeof(TIn) == 4) reinterpret_cast<float*>(dst)[oc + r] = v[r];
+            if (of32) reinterpret_cast<float*>(dst)[oc + r] = v[r];
             else reinterpret_cast<uint16_t*>(dst)[oc + r] = float_to_bf16_bits(v[r]);
           }
       }
@@ -414,7 +415,7 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   // Split the reduction when the grid cannot fill the chip and the output can take fp32 adds.
   p.ksplit = 1;
   const long blocks = (long)tiles * p.n_oc_tiles;
-  const bool can_split = !l.in_bf16 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
+  const bool can_split = split_reduction_allowed() && p.out_f32 != 0 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
   // (only for small outputs: the partial tiles are added with per-lane fp32 atomics whose access shape is slow)
   if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= 65536) {
     long want = (256 + blocks - 1) / blocks;

@@ -209,8 +209,7 @@ static int launch_scatter_one(const GatherParams& p, double flops, hipStream_t s
 int launch_scatter(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t s) {
   if (p.N == 0) return GC_OK;
   if (l.in_bf16) return out_f32 ? launch_scatter_one<uint16_t, float>(p, l.flops, s) : launch_scatter_one<uint16_t, uint16_t>(p, l.flops, s);
-  if (!out_f32) { set_error("fp32 input with bf16 output is not supported"); return GC_UNSUPPORTED_GEOMETRY; }
-  return launch_scatter_one<float, float>(p, l.flops, s);
+  return out_f32 ? launch_scatter_one<float, float>(p, l.flops, s) : launch_scatter_one<float, uint16_t>(p, l.flops, s);
 }
 
 }  // namespace gc

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -35,6 +36,8 @@ struct ProfRec {
   double flops;
   hipEvent_t e0, e1;
 };
+static std::atomic<bool> g_split_reduction{true};
+bool split_reduction_allowed() { return g_split_reduction.load(std::memory_order_relaxed); }
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -135,7 +138,6 @@ static int validate(const gc_conv_desc* d) {
     set_error("Ho/Wo (%d,%d) do not match the convolution of H/W (%d,%d): expected (%d,%d)", d->Ho, d->Wo, d->H, d->W, ho_full, wo_full);
     return GC_BAD_DESC;
   }
-  // mixed dtypes: only "bf16 read, fp32 written" (checked per pass, see pass_dtypes)
   if (d->precision == GC_PREC_F32X3 && (d->x_dtype != GC_F32 || d->y_dtype != GC_F32)) { set_error("GC_PREC_F32X3 needs fp32 activations"); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->kh * d->kw > kMaxTaps) { set_error("filters larger than %d taps are not supported", kMaxTaps); return GC_UNSUPPORTED_GEOMETRY; }
   if (d->stride_h * d->stride_w > 4) { set_error("stride %dx%d is not supported", d->stride_h, d->stride_w); return GC_UNSUPPORTED_GEOMETRY; }
@@ -162,11 +164,11 @@ static int pass_dtypes(const gc_conv_desc* d, int pass, int* in_dt, int* out_dt)
     if (d->x_dtype != d->y_dtype) { set_error("wgrad needs x and gy of one dtype"); return GC_UNSUPPORTED_GEOMETRY; }
     return GC_OK;
   }
-  if (*in_dt == GC_F32 && *out_dt == GC_BF16) { set_error("fp32 input with bf16 output is not supported"); return GC_UNSUPPORTED_GEOMETRY; }
   return GC_OK;
 }
 
 static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream) {
+  p.out_f32 = out_dt == GC_F32;
   if (p.out_bf16 != nullptr && (out_dt != GC_F32 || !p.out_vec || p.OC % 4 != 0)) {
     set_error("out_bf16 needs an fp32 output whose channel slice is a multiple of 4 channels at a multiple of 4");
     return GC_UNSUPPORTED_GEOMETRY;
@@ -187,10 +189,6 @@ static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t 
   const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 128 || l.to == 64) &&
                    p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
   if (dma) return launch_gather_dma(p, l, out_dt == GC_F32, stream);
-  if (l.in_bf16 != (out_dt == GC_BF16)) {
-    set_error("bf16 input with fp32 output needs channel counts that are multiples of 8 (and more than 32) and tensors below 2 GiB");
-    return GC_UNSUPPORTED_GEOMETRY;
-  }
   return launch_gather(p, l, stream);
 }
 
@@ -251,6 +249,8 @@ using namespace gc;
 extern "C" {
 
 int gc_version(void) { return GANCONV_VERSION; }
+
+int gc_set_split_reduction(int on) { return g_split_reduction.exchange(on != 0) ? 1 : 0; }
 
 const char* gc_last_error(void) { return g_err; }
 

@@ -1,4 +1,4 @@
-// InstanceNorm2d (affine = false, biased variance) fused with LeakyReLU, NHWC fp32: forward, backward and the
+// InstanceNorm2d (affine = false, biased variance) fused with LeakyReLU, NHWC fp32 or bf16 (fp32 arithmetic): forward, backward and the
 // backward of the backward (needed by the WGAN-GP gradient penalty, which differentiates the critic twice).
 //
 //   forward       z  = lrelu(xh),  xh = (x - mu) * r,  mu / r = per-(n,c) mean and rsqrt(var + eps) over H*W
@@ -17,12 +17,12 @@
 
 namespace gc {
 
-struct InstNormParams {
-  const float* x;
-  const float* gz;
-  const float* u;
-  float* out0;   // z | gx | g_x
-  float* out1;   // - | -  | g_gz
+struct InstNormParams {   // tensors are fp32 or bf16 (template parameter of the kernel), all of one type
+  const void* x;
+  const void* gz;
+  const void* u;
+  void* out0;    // z | gx | g_x
+  void* out1;    // - | -  | g_gz
   uint16_t* out0_bf16;   // optional bf16 copies of out0 / out1
   uint16_t* out1_bf16;
   int32_t N, HW, C;
@@ -45,7 +45,7 @@ __device__ __forceinline__ f32x4 block_sum(f32x4 v, f32x4* red, int tq, int tl, 
   return r;
 }
 
-template <int MODE>
+template <int MODE, typename T>
 __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams p) {
   __shared__ f32x4 red[kThreads];
   const int QB = 1 << p.qb_log2, PL = kThreads >> p.qb_log2;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
   const size_t base = (size_t)n * p.HW * p.C + (cok ? c : 0);
   const float inv_n = 1.f / (float)p.HW;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  auto ld = [&](const float* ptr, int pix) -> f32x4 { return *reinterpret_cast<const f32x4*>(ptr + base + (size_t)pix * p.C); };
+  auto ld = [&](const void* ptr, int pix) -> f32x4 { return load4<T>(ptr, base + (size_t)pix * p.C); };
   auto mask = [&](f32x4 d) -> f32x4 {
     f32x4 m;
 #pragma unroll
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
     for (int pix = tl; pix < p.HW; pix += PL) {
       const f32x4 d = ld(p.x, pix) - mu;
       const f32x4 z = d * r * mask(d);
-      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = z;
+      store4<T>(p.out0, base + (size_t)pix * p.C, z);
       if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(z);
     }
   } else if (MODE == 1) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
       const f32x4 d = ld(p.x, pix) - mu;
       const f32x4 gy = ld(p.gz, pix) * mask(d);
       const f32x4 gx = r * (gy - gbar - d * r * cbar);
-      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = gx;
+      store4<T>(p.out0, base + (size_t)pix * p.C, gx);
       if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(gx);
     }
   } else {
@@ -134,16 +134,18 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
       const f32x4 pu = uu - ubar - xh * (b_ * inv_n);
       const f32x4 pg = gy - gbar - xh * (c_ * inv_n);
       const f32x4 o0 = scale * (k0 * xh + c_ * pu + b_ * pg), o1 = m * r * pu;
-      *reinterpret_cast<f32x4*>(p.out0 + base + (size_t)pix * p.C) = o0;
-      *reinterpret_cast<f32x4*>(p.out1 + base + (size_t)pix * p.C) = o1;
+      store4<T>(p.out0, base + (size_t)pix * p.C, o0);
+      store4<T>(p.out1, base + (size_t)pix * p.C, o1);
       if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o0);
       if (p.out1_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out1_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o1);
     }
   }
 }
 
-static int launch_instnorm(int mode, const float* x, const float* gz, const float* u, float* out0, float* out1, void* out0_bf16,
+static int launch_instnorm(int mode, int dtype, const void* x, const void* gz, const void* u, void* out0, void* out1, void* out0_bf16,
                            void* out1_bf16, int N, int HW, int C, float eps, float slope, int act, hipStream_t stream) {
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("instnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
+  if (dtype == GC_BF16 && (out0_bf16 != nullptr || out1_bf16 != nullptr)) { set_error("instnorm: bf16 tensors need no bf16 copy"); return GC_BAD_ARGUMENT; }
   if (N < 0 || HW <= 0 || C <= 0) { set_error("instnorm: bad shape"); return GC_BAD_ARGUMENT; }
   if (act != GC_ACT_NONE && act != GC_ACT_LRELU) { set_error("instnorm: activation must be none or LeakyReLU"); return GC_BAD_ARGUMENT; }
   if (act == GC_ACT_LRELU && !(slope > 0.f)) { set_error("instnorm: LeakyReLU slope must be positive"); return GC_UNSUPPORTED_GEOMETRY; }
@@ -151,7 +153,7 @@ static int launch_instnorm(int mode, const float* x, const float* gz, const floa
   if (N == 0) return GC_OK;
   const void* ptrs[5] = {x, mode >= 1 ? gz : x, mode == 2 ? u : x, out0, mode == 2 ? out1 : out0};
   for (auto q : ptrs)
-    if (q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u)) { set_error("instnorm: null or misaligned pointer"); return GC_BAD_ARGUMENT; }
+    if (q == nullptr || (reinterpret_cast<uintptr_t>(q) & (dtype == GC_F32 ? 15u : 7u))) { set_error("instnorm: null or misaligned pointer"); return GC_BAD_ARGUMENT; }
   if ((reinterpret_cast<uintptr_t>(out0_bf16) & 7u) || (reinterpret_cast<uintptr_t>(out1_bf16) & 7u)) {
     set_error("instnorm: misaligned bf16 output"); return GC_BAD_ARGUMENT;
   }
@@ -164,9 +166,15 @@ static int launch_instnorm(int mode, const float* x, const float* gz, const floa
   const dim3 grid((unsigned)N * chunks), block(kThreads);
   static const char* names[3] = {"gc::instnorm_kernel<0>", "gc::instnorm_kernel<1>", "gc::instnorm_kernel<2>"};
   ProfScope ps(names[mode], 0.0, stream);
-  if (mode == 0) hipLaunchKernelGGL(instnorm_kernel<0>, grid, block, 0, stream, p);
-  else if (mode == 1) hipLaunchKernelGGL(instnorm_kernel<1>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(instnorm_kernel<2>, grid, block, 0, stream, p);
+  if (dtype == GC_F32) {
+    if (mode == 0) hipLaunchKernelGGL((instnorm_kernel<0, float>), grid, block, 0, stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((instnorm_kernel<1, float>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((instnorm_kernel<2, float>), grid, block, 0, stream, p);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((instnorm_kernel<0, uint16_t>), grid, block, 0, stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((instnorm_kernel<1, uint16_t>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((instnorm_kernel<2, uint16_t>), grid, block, 0, stream, p);
+  }
   return check_hip(hipGetLastError(), "instnorm launch");
 }
 
@@ -174,19 +182,19 @@ static int launch_instnorm(int mode, const float* x, const float* gz, const floa
 
 extern "C" {
 
-int gc_instnorm_act_fwd(const float* x, float* z, void* z_bf16, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope,
-                        void* stream) {
-  return gc::launch_instnorm(0, x, nullptr, nullptr, z, nullptr, z_bf16, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
+int gc_instnorm_act_fwd(const void* x, void* z, void* z_bf16, int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, int32_t act,
+                        float slope, void* stream) {
+  return gc::launch_instnorm(0, dtype, x, nullptr, nullptr, z, nullptr, z_bf16, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
 }
 
-int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, void* gx_bf16, int32_t N, int32_t HW, int32_t C, float eps,
-                        int32_t act, float slope, void* stream) {
-  return gc::launch_instnorm(1, x, gz, nullptr, gx, nullptr, gx_bf16, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
+int gc_instnorm_act_bwd(const void* x, const void* gz, void* gx, void* gx_bf16, int32_t N, int32_t HW, int32_t C, int32_t dtype,
+                        float eps, int32_t act, float slope, void* stream) {
+  return gc::launch_instnorm(1, dtype, x, gz, nullptr, gx, nullptr, gx_bf16, nullptr, N, HW, C, eps, slope, act, (hipStream_t)stream);
 }
 
-int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, void* g_x_bf16, void* g_gz_bf16,
-                            int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream) {
-  return gc::launch_instnorm(2, x, gz, u, g_x, g_gz, g_x_bf16, g_gz_bf16, N, HW, C, eps, slope, act, (hipStream_t)stream);
+int gc_instnorm_act_bwd_bwd(const void* x, const void* gz, const void* u, void* g_x, void* g_gz, void* g_x_bf16, void* g_gz_bf16,
+                            int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, int32_t act, float slope, void* stream) {
+  return gc::launch_instnorm(2, dtype, x, gz, u, g_x, g_gz, g_x_bf16, g_gz_bf16, N, HW, C, eps, slope, act, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -40,10 +40,21 @@ def _act_code(activation):
     return _ACT_CODES[activation]
 
 
+def _out_code(out_dtype):
+    if out_dtype is None:
+        return -1
+    if out_dtype == torch.float32:
+        return 0
+    if out_dtype == torch.bfloat16:
+        return 1
+    raise RuntimeError(f"ganconv: out_dtype must be None, torch.float32 or torch.bfloat16 (got {out_dtype})")
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, *, _wkey=0, precision=None, activation=None,
-           negative_slope=0.2):
+           negative_slope=0.2, out_dtype=None):
     """`activation` (None, "relu", "leaky_relu", "tanh", "sigmoid") is applied in the kernel's epilogue: the result
-    equals activation(conv2d(...)) of the unfused pair."""
+    equals activation(conv2d(...)) of the unfused pair.  `out_dtype` (None = the input's, torch.float32 or
+    torch.bfloat16) is the storage type of the result; accumulation is always fp32."""
     _check_input(input, weight)
     if _single(dilation, "dilation") != 1:
         raise RuntimeError("ganconv: dilation > 1 is not supported")
@@ -51,11 +62,11 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
         raise RuntimeError("ganconv: groups > 1 is not supported by conv2d (the StyleGAN depthwise blur is ops.blur3x3)")
     prec = ops.get_precision() if precision is None else precision
     return ops.conv_fprop(input, weight, bias, _single(stride, "stride"), _single(padding, "padding"), prec, _wkey,
-                          _act_code(activation), float(negative_slope))
+                          _act_code(activation), float(negative_slope), _out_code(out_dtype))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, *, _wkey=0,
-                     precision=None, activation=None, negative_slope=0.2):
+                     precision=None, activation=None, negative_slope=0.2, out_dtype=None):
     """weight is [Cin, Cout, kh, kw] as in torch.  Runs as the data-gradient of the mirrored convolution.
     `activation`: as for conv2d."""
     _check_input(input, weight)
@@ -70,7 +81,8 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     H = (input.shape[2] - 1) * s - 2 * p + kh + op
     W = (input.shape[3] - 1) * s - 2 * p + kw + op
     prec = ops.get_precision() if precision is None else precision
-    return ops.conv_dgrad(input, weight, bias, H, W, s, p, prec, _wkey, _act_code(activation), float(negative_slope))
+    return ops.conv_dgrad(input, weight, bias, H, W, s, p, prec, _wkey, _act_code(activation), float(negative_slope),
+                          _out_code(out_dtype))
 
 
 def blur3x3(input):

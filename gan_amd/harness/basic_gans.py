@@ -23,7 +23,10 @@ def _seq(*m):
 
 
 class Generator(torch.nn.Module):
-    def __init__(self, z_dim, hidden_dim, image_dim=3, resolution=128):
+    """activation_dtype: storage type of the activations between the first and the last layer (torch.float32, or
+    torch.bfloat16 for half the memory traffic; the input noise and the image stay float32 either way)."""
+
+    def __init__(self, z_dim, hidden_dim, image_dim=3, resolution=128, activation_dtype=torch.float32):
         super().__init__()
         n_layers = int(math.log2(resolution)) - 1
         width = 8 * hidden_dim
@@ -33,7 +36,8 @@ class Generator(torch.nn.Module):
             cin = z_dim if first else int(width / 2 ** (i - 1))
             cout = image_dim if last else int(width / 2 ** i)
             conv = gnn.ConvTranspose2d(cin, cout, 4, 1 if first else 2, 0 if first else 1, bias=False,
-                                       activation="tanh" if last else None)
+                                       activation="tanh" if last else None,
+                                       out_dtype=torch.float32 if last else (activation_dtype if first else None))
             layers.append(_seq(conv) if last else _seq(conv, gnn.BatchNormAct2d(cout, activation="relu")))
         self.main = _seq(*layers)
 
@@ -42,7 +46,7 @@ class Generator(torch.nn.Module):
 
 
 class Discriminator(torch.nn.Module):
-    def __init__(self, image_dim, hidden_dim, resolution=128, is_wgan=False):
+    def __init__(self, image_dim, hidden_dim, resolution=128, is_wgan=False, activation_dtype=torch.float32):
         super().__init__()
         n_layers = int(math.log2(resolution)) - 1
         layers = []
@@ -51,7 +55,8 @@ class Discriminator(torch.nn.Module):
             cin = image_dim if first else int(hidden_dim * 2 ** (i - 1))
             cout = 1 if last else int(hidden_dim * 2 ** i)
             fused = "leaky_relu" if first else ("sigmoid" if last and not is_wgan else None)
-            ops = [gnn.Conv2d(cin, cout, 4, 1 if last else 2, 0 if last else 1, bias=False, activation=fused, negative_slope=0.2)]
+            ops = [gnn.Conv2d(cin, cout, 4, 1 if last else 2, 0 if last else 1, bias=False, activation=fused, negative_slope=0.2,
+                              out_dtype=torch.float32 if last else (activation_dtype if first else None))]
             if first:
                 pass
             elif not last and is_wgan:   # InstanceNorm2d + LeakyReLU(0.2) of the reference as one fused op (no parameters)
@@ -160,13 +165,14 @@ class WganGpTrainer:
     cycle can be captured into one HIP graph (no host work, no allocation, no synchronisation per cycle)."""
 
     def __init__(self, batch, hidden_dim=64, z_dim=100, resolution=64, device="cuda", lr=1e-4, betas=(0.0, 0.9),
-                 c_lambda=10.0, disc_repeats=5, seed=5000, reducer_factory=None, capturable=True, batch_real_fake=False, fused_adam=False):
+                 c_lambda=10.0, disc_repeats=5, seed=5000, reducer_factory=None, capturable=True, batch_real_fake=False, fused_adam=False,
+                 activation_dtype=torch.float32):
         torch.manual_seed(seed)
         self.B, self.nz, self.res, self.reps, self.c_lambda = batch, z_dim, resolution, disc_repeats, c_lambda
         self.batch_real_fake = batch_real_fake
         self.device = torch.device(device)
-        self.net_G = Generator(z_dim, hidden_dim, 3, resolution)
-        self.net_D = Discriminator(3, hidden_dim, resolution, is_wgan=True)
+        self.net_G = Generator(z_dim, hidden_dim, 3, resolution, activation_dtype=activation_dtype)
+        self.net_D = Discriminator(3, hidden_dim, resolution, is_wgan=True, activation_dtype=activation_dtype)
         self.net_G.apply(weights_init)
         self.net_D.apply(weights_init)
         self.net_G.to(self.device)

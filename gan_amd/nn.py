@@ -34,11 +34,14 @@ class _KeyedWeight:
 class _FusedActivation:
     """Optional activation applied inside the convolution kernel: `activation` is None, "relu", "leaky_relu", "tanh"
     or "sigmoid".  The module then stands for the reference's conv + activation pair (the activation module holds no
-    state, so state_dicts are unchanged)."""
+    state, so state_dicts are unchanged).  `out_dtype` (None = the input's dtype, torch.float32, torch.bfloat16) picks
+    the storage type of the output: a network keeps its activations in bf16 by asking for bf16 at the first
+    convolution and for float32 at the last; every layer in between follows its input."""
 
-    def _init_activation(self, activation, negative_slope):
+    def _init_activation(self, activation, negative_slope, out_dtype=None):
         F._act_code(activation)
-        self.activation, self.negative_slope = activation, negative_slope
+        F._out_code(out_dtype)
+        self.activation, self.negative_slope, self.out_dtype = activation, negative_slope, out_dtype
 
     def extra_repr(self):
         base = super().extra_repr()
@@ -46,22 +49,22 @@ class _FusedActivation:
 
 
 class Conv2d(_FusedActivation, _KeyedWeight, torch.nn.Conv2d):
-    def __init__(self, *args, activation=None, negative_slope=0.2, **kwargs):
+    def __init__(self, *args, activation=None, negative_slope=0.2, out_dtype=None, **kwargs):
         super().__init__(*args, **kwargs)
-        self._init_activation(activation, negative_slope)
+        self._init_activation(activation, negative_slope, out_dtype)
 
     def _conv_forward(self, input, weight, bias):
         if self.padding_mode != "zeros":
             raise RuntimeError("ganconv: only zero padding is supported")
         key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
         return F.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key,
-                        activation=self.activation, negative_slope=self.negative_slope)
+                        activation=self.activation, negative_slope=self.negative_slope, out_dtype=self.out_dtype)
 
 
 class ConvTranspose2d(_FusedActivation, _KeyedWeight, torch.nn.ConvTranspose2d):
-    def __init__(self, *args, activation=None, negative_slope=0.2, **kwargs):
+    def __init__(self, *args, activation=None, negative_slope=0.2, out_dtype=None, **kwargs):
         super().__init__(*args, **kwargs)
-        self._init_activation(activation, negative_slope)
+        self._init_activation(activation, negative_slope, out_dtype)
 
     def forward(self, input, output_size=None):
         if self.padding_mode != "zeros":
@@ -71,7 +74,8 @@ class ConvTranspose2d(_FusedActivation, _KeyedWeight, torch.nn.ConvTranspose2d):
         weight = self.weight
         key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
         return F.conv_transpose2d(input, weight, self.bias, self.stride, self.padding, self.output_padding, self.groups,
-                                  self.dilation, _wkey=key, activation=self.activation, negative_slope=self.negative_slope)
+                                  self.dilation, _wkey=key, activation=self.activation, negative_slope=self.negative_slope,
+                                  out_dtype=self.out_dtype)
 
 
 class BlurLayer(torch.nn.Module):

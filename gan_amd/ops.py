@@ -81,6 +81,14 @@ _side_streams = {}
 _side_keep = []       # workspaces and operand copies in use on the side stream
 
 
+def set_split_reduction(on):
+    """Allows (default) or forbids split reductions: small convolutions whose partial sums are added with fp32 atomics,
+    which makes their last bit vary from run to run.  Forbid them to get bit-wise reproducible convolutions (bias
+    gradients stay atomically summed).  Returns the previous setting; recorded HIP graphs keep the setting they were
+    recorded with."""
+    return bool(_lib.lib().gc_set_split_reduction(1 if on else 0))
+
+
 def set_backward_overlap(on):
     global _overlap
     _overlap = bool(on)
@@ -192,6 +200,17 @@ def _optr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_OUT_SAME, _OUT_F32, _OUT_BF16 = -1, 0, 1
+
+
+def _out_dtype(t, code):
+    return t.dtype if code == _OUT_SAME else (torch.bfloat16 if code == _OUT_BF16 else torch.float32)
+
+
+def _code_of(dtype):
+    return _OUT_BF16 if dtype == torch.bfloat16 else _OUT_F32
+
+
 def _dma_ok(t, ic, oc, precision):
     """fp32 activation in bf16 mode whose conv qualifies for the LDS-DMA kernel (bf16 in, fp32 out)."""
     return (precision == _lib.GC_PREC_BF16 and t.dtype == torch.float32 and ic % 8 == 0 and ic > 32 and oc > 16
@@ -252,8 +271,9 @@ def _act_backward(g, y, act, slope):
 # ---- op implementations (run below autograd) -------------------------------------------------------------------
 @torch.library.custom_op("ganconv::conv_fprop", mutates_args=())
 def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, padding: int, precision: int, wkey: int,
-               act: int = 0, slope: float = 0.0) -> Tensor:
-    """act(conv2d(x, w) + bias); act is a gc_act code fused into the kernel's epilogue."""
+               act: int = 0, slope: float = 0.0, out_dtype: int = -1) -> Tensor:
+    """act(conv2d(x, w) + bias); act is a gc_act code fused into the kernel's epilogue.  out_dtype: -1 the input's
+    dtype, 0 float32, 1 bfloat16 (activations may be stored in either; accumulation is fp32)."""
     _check_cuda(x, w, bias)
     N, Cin, H, W = x.shape
     Cout, Cin_w, kh, kw = w.shape
@@ -263,12 +283,10 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
         raise RuntimeError(f"ganconv: kernel ({kh}x{kw}) larger than padded input ({H + 2 * padding}x{W + 2 * padding})")
     Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
     x = _nhwc(x)
-    y = torch.empty((N, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=_out_dtype(x, out_dtype), device=x.device, memory_format=torch.channels_last)
     if _dma_ok(x, Cin, Cout, precision):
         x = _to_bf16(x)
-        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _lib.GC_BF16, precision, _lib.GC_F32)
-    else:
-        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(y))
     wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey)
     ep, keep = _epilogue(bias, act, slope, y if (act != 0 and y.dtype == torch.float32) else None)
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
@@ -278,17 +296,19 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
 
 
 @conv_fprop.register_fake
-def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0):
+def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1):
     N, _, H, W = x.shape
     Cout, _, kh, kw = w.shape
-    return x.new_empty((N, Cout, (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1))
+    return x.new_empty((N, Cout, (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1),
+                       dtype=_out_dtype(x, out_dtype))
 
 
 @torch.library.custom_op("ganconv::conv_dgrad", mutates_args=())
 def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, stride: int, padding: int, precision: int,
-               wkey: int, act: int = 0, slope: float = 0.0) -> Tensor:
+               wkey: int, act: int = 0, slope: float = 0.0, out_dtype: int = -1) -> Tensor:
     """gx [N, Cin, H, W] of the conv x -> y described by (w [Cout,Cin,kh,kw], stride, padding), given gy.
-    `bias` ([Cin]) is added to gx: the bias of a transposed convolution whose forward pass this is."""
+    `bias` ([Cin]) is added to gx: the bias of a transposed convolution whose forward pass this is.
+    out_dtype as for conv_fprop."""
     _check_cuda(gy, w, bias)
     N, Cout, Ho, Wo = gy.shape
     Cout_w, Cin, kh, kw = w.shape
@@ -297,12 +317,10 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
     if (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
         raise RuntimeError(f"ganconv: input size ({H}x{W}) is inconsistent with the gradient's ({Ho}x{Wo})")
     gy = _nhwc(gy)
-    gx = torch.empty((N, Cin, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+    gx = torch.empty((N, Cin, H, W), dtype=_out_dtype(gy, out_dtype), device=gy.device, memory_format=torch.channels_last)
     if _dma_ok(gy, Cout, Cin, precision):
         gy = _to_bf16(gy)
-        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _lib.GC_F32, precision, _lib.GC_BF16)
-    else:
-        d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gy), precision)
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gx), precision, _dtype_code(gy))
     wp = _packed(d, w, _lib.GC_PASS_DGRAD, wkey)
     ep, keep = _epilogue(bias, act, slope, gx if (act != 0 and gx.dtype == torch.float32) else None)
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
@@ -312,8 +330,8 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
 
 
 @conv_dgrad.register_fake
-def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0):
-    return gy.new_empty((gy.shape[0], w.shape[1], H, W))
+def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1):
+    return gy.new_empty((gy.shape[0], w.shape[1], H, W), dtype=_out_dtype(gy, out_dtype))
 
 
 @torch.library.custom_op("ganconv::conv_wgrad", mutates_args=())
@@ -324,9 +342,10 @@ def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: in
     N2, Cout, Ho, Wo = gy.shape
     if N2 != N or (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
         raise RuntimeError("ganconv: x and gy shapes are inconsistent with the convolution geometry")
-    if x.dtype != gy.dtype:
-        gy = gy.to(x.dtype)
     x, gy = _nhwc(x), _nhwc(gy)
+    if x.dtype != gy.dtype:      # mixed storage (e.g. an fp32 image feeding bf16 activations): the operands are bf16 anyway
+        x = x if x.dtype == torch.bfloat16 else _to_bf16(x)
+        gy = gy if gy.dtype == torch.bfloat16 else _to_bf16(gy)
     # bf16 copies only where the LDS-DMA weight-gradient kernel can use them; the other kernels convert fp32 operands
     # in registers (narrow layers are bound by reading these tensors once, a copy would only add traffic)
     if (precision == _lib.GC_PREC_BF16 and x.dtype == torch.float32 and Cin % 8 == 0 and Cout % 8 == 0 and Cin > 32
@@ -352,7 +371,7 @@ def _(x, gy, kh, kw, stride, padding, precision):
 
 # ---- autograd: each formula uses only the three ops above -------------------------------------------------------
 def _fprop_setup(ctx, inputs, output):
-    x, w, bias, stride, padding, precision, wkey, act, slope = inputs
+    x, w, bias, stride, padding, precision, wkey, act, slope, _ = inputs
     if act != 0:
         ctx.save_for_backward(x, w, output)
     else:
@@ -371,24 +390,24 @@ def _fprop_backward(ctx, gy):
     if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and gy.is_cuda:
         with _SideLaunch(gy.device) as side:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision)
-        gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey)
+        gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype))
         side.join()
         gw = gw.to(w.dtype)
     else:
         if ctx.needs_input_grad[0]:
-            gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey)
+            gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype))
         if ctx.needs_input_grad[1]:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
-        gb = gy.sum((0, 2, 3))
-    return gx, gw, gb, None, None, None, None, None, None
+        gb = gy.sum((0, 2, 3), dtype=torch.float32)
+    return gx, gw, gb, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_fprop", _fprop_backward, setup_context=_fprop_setup)
 
 
 def _dgrad_setup(ctx, inputs, output):
-    gy, w, bias, H, W, stride, padding, precision, wkey, act, slope = inputs
+    gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, _ = inputs
     if act != 0:
         ctx.save_for_backward(gy, w, output)
     else:
@@ -407,17 +426,17 @@ def _dgrad_backward(ctx, u):
     if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and u.is_cuda:
         with _SideLaunch(u.device) as side:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision)
-        g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey)
+        g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype))
         side.join()
         g_w = g_w.to(w.dtype)
     else:
         if ctx.needs_input_grad[0]:
-            g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey)
+            g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype))
         if ctx.needs_input_grad[1]:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
-        g_b = u.sum((0, 2, 3))
-    return g_gy, g_w, g_b, None, None, None, None, None, None, None, None
+        g_b = u.sum((0, 2, 3), dtype=torch.float32)
+    return g_gy, g_w, g_b, None, None, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_dgrad", _dgrad_backward, setup_context=_dgrad_setup)
@@ -434,9 +453,9 @@ def _wgrad_backward(ctx, v):
     stride, padding, precision = ctx.cfg
     g_x = g_gy = None
     if ctx.needs_input_grad[0]:
-        g_x = conv_dgrad(gy, v, None, x.shape[2], x.shape[3], stride, padding, precision, 0)
+        g_x = conv_dgrad(gy, v, None, x.shape[2], x.shape[3], stride, padding, precision, 0, 0, 0.0, _code_of(x.dtype))
     if ctx.needs_input_grad[1]:
-        g_gy = conv_fprop(x, v, None, stride, padding, precision, 0)
+        g_gy = conv_fprop(x, v, None, stride, padding, precision, 0, 0, 0.0, _code_of(gy.dtype))
     return g_x, g_gy, None, None, None, None, None
 
 
@@ -465,11 +484,13 @@ torch.library.register_autograd("ganconv::blur3x3", lambda ctx, g: blur3x3(g), s
 
 
 # ---- InstanceNorm (+ LeakyReLU), with explicit first- and second-order backward kernels --------------------------
-def _in_args(x):
-    if x.dtype != torch.float32:
-        raise RuntimeError("ganconv: instance norm kernels take float32 tensors")
+def _in_args(x, *same):
+    """(N, H*W, C, dtype code) of an NHWC fp32 / bf16 tensor; the other tensors must share its dtype."""
+    for t in same:
+        if t.dtype != x.dtype:
+            raise RuntimeError(f"ganconv: norm kernels take tensors of one dtype (got {x.dtype} and {t.dtype})")
     N, C, H, W = x.shape
-    return N, H * W, C
+    return N, H * W, C, _dtype_code(x)
 
 
 def _ptr(t):
@@ -481,9 +502,10 @@ def instnorm_act(x: Tensor, eps: float, act: int, slope: float) -> Tensor:
     """act((x - mean) * rsqrt(var + eps)) per (sample, channel); act = GC_ACT_NONE or GC_ACT_LRELU."""
     _check_cuda(x)
     x = _nhwc(x)
-    N, HW, C = _in_args(x)
+    N, HW, C, dt = _in_args(x)
     z = torch.empty_like(x, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().gc_instnorm_act_fwd(_ptr(x), _ptr(z), _optr(_bf16_twin(z)), N, HW, C, eps, act, slope, _stream()), "gc_instnorm_act_fwd")
+    _lib.check(_lib.lib().gc_instnorm_act_fwd(_ptr(x), _ptr(z), _optr(_bf16_twin(z)), N, HW, C, dt, eps, act, slope, _stream()),
+               "gc_instnorm_act_fwd")
     return z
 
 
@@ -496,9 +518,9 @@ def _(x, eps, act, slope):
 def instnorm_act_bwd(x: Tensor, gz: Tensor, eps: float, act: int, slope: float) -> Tensor:
     _check_cuda(x, gz)
     x, gz = _nhwc(x), _nhwc(gz)
-    N, HW, C = _in_args(x)
+    N, HW, C, dt = _in_args(x, gz)
     gx = torch.empty_like(x, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().gc_instnorm_act_bwd(_ptr(x), _ptr(gz), _ptr(gx), _optr(_bf16_twin(gx)), N, HW, C, eps, act, slope, _stream()),
+    _lib.check(_lib.lib().gc_instnorm_act_bwd(_ptr(x), _ptr(gz), _ptr(gx), _optr(_bf16_twin(gx)), N, HW, C, dt, eps, act, slope, _stream()),
                "gc_instnorm_act_bwd")
     return gx
 
@@ -512,11 +534,11 @@ def _(x, gz, eps, act, slope):
 def instnorm_act_bwd_bwd(x: Tensor, gz: Tensor, u: Tensor, eps: float, act: int, slope: float) -> tuple[Tensor, Tensor]:
     _check_cuda(x, gz, u)
     x, gz, u = _nhwc(x), _nhwc(gz), _nhwc(u)
-    N, HW, C = _in_args(x)
+    N, HW, C, dt = _in_args(x, gz, u)
     g_x = torch.empty_like(x, memory_format=torch.channels_last)
     g_gz = torch.empty_like(x, memory_format=torch.channels_last)
     _lib.check(_lib.lib().gc_instnorm_act_bwd_bwd(_ptr(x), _ptr(gz), _ptr(u), _ptr(g_x), _ptr(g_gz), _optr(_bf16_twin(g_x)),
-                                                  _optr(_bf16_twin(g_gz)), N, HW, C, eps, act, slope, _stream()),
+                                                  _optr(_bf16_twin(g_gz)), N, HW, C, dt, eps, act, slope, _stream()),
                "gc_instnorm_act_bwd_bwd")
     return g_x, g_gz
 
@@ -563,18 +585,17 @@ def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], r
     ones (read only).  Returns (y, mean, rstd, unbiased variance); the caller folds the last two into its running
     statistics with batchnorm_update_running_."""
     _check_cuda(x, weight, bias, running_mean, running_var)
-    if x.dtype != torch.float32:
-        raise RuntimeError("ganconv: batch norm kernels take float32 tensors")
     x = _nhwc(x)
     N, C, H, W = x.shape
     P = N * H * W
+    dt = _dtype_code(x)
     y = torch.empty_like(x, memory_format=torch.channels_last)
     mean, rstd, var = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(3))
     L = _lib.lib()
     ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
     rm, rv = (None, None) if training else (running_mean, running_var)
     _lib.check(L.gc_batchnorm_act_fwd(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _optr(rm), _optr(rv), None,
-                                      _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), P, C, eps, 0.0, act, slope,
+                                      _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), P, C, dt, eps, 0.0, act, slope,
                                       1 if training else 0, _stream()), "gc_batchnorm_act_fwd")
     return y, mean, rstd, var
 
@@ -582,7 +603,8 @@ def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], r
 @batchnorm_act.register_fake
 def _(x, weight, bias, running_mean, running_var, training, eps, act, slope):
     C = x.shape[1]
-    return torch.empty_like(x), x.new_empty(C), x.new_empty(C), x.new_empty(C)
+    f = dict(dtype=torch.float32)
+    return torch.empty_like(x), x.new_empty(C, **f), x.new_empty(C, **f), x.new_empty(C, **f)
 
 
 @torch.library.custom_op("ganconv::batchnorm_update_running_", mutates_args=("running_mean", "running_var", "num_batches_tracked"))
@@ -600,15 +622,18 @@ def batchnorm_act_bwd(x: Tensor, gy: Tensor, weight: Optional[Tensor], bias: Opt
     """(gx, gweight, gbias) of a training-mode batchnorm_act."""
     _check_cuda(x, gy)
     x, gy = _nhwc(x), _nhwc(gy)
+    if gy.dtype != x.dtype:
+        raise RuntimeError(f"ganconv: norm kernels take tensors of one dtype (got {x.dtype} and {gy.dtype})")
     N, C, H, W = x.shape
     P = N * H * W
+    dt = _dtype_code(x)
     gx = torch.empty_like(x, memory_format=torch.channels_last)
     gw = torch.empty(C, dtype=torch.float32, device=x.device)
     gb = torch.empty(C, dtype=torch.float32, device=x.device)
     L = _lib.lib()
     ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
     _lib.check(L.gc_batchnorm_act_bwd(_ptr(x), _ptr(gy), _optr(weight), _optr(bias), _ptr(mean), _ptr(rstd), _ptr(gx),
-                                      _optr(_bf16_twin(gx)), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), P, C, act, slope, _stream()),
+                                      _optr(_bf16_twin(gx)), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), P, C, dt, act, slope, _stream()),
                "gc_batchnorm_act_bwd")
     return gx, gw, gb
 
@@ -616,7 +641,7 @@ def batchnorm_act_bwd(x: Tensor, gy: Tensor, weight: Optional[Tensor], bias: Opt
 @batchnorm_act_bwd.register_fake
 def _(x, gy, weight, bias, mean, rstd, act, slope):
     C = x.shape[1]
-    return torch.empty_like(x), x.new_empty(C), x.new_empty(C)
+    return torch.empty_like(x), x.new_empty(C, dtype=torch.float32), x.new_empty(C, dtype=torch.float32)
 
 
 def _bn_setup(ctx, inputs, output):

@@ -134,7 +134,8 @@ int gc_conv2d_wgrad(const gc_conv_desc* desc, const void* x, const void* gy, flo
 int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 
 /* InstanceNorm2d (affine = false, no running statistics, biased variance, eps inside the square root) fused with
- * an optional LeakyReLU, NHWC fp32, C a multiple of 4; HW = H*W.  Replaces aten::instance_norm + aten::leaky_relu
+ * an optional LeakyReLU, NHWC, all tensors of one gc_dtype, `dtype` ( arithmetic and statistics in fp32), C a multiple of
+ * 4; HW = H*W.  Replaces aten::instance_norm + aten::leaky_relu
  * and their first- and second-order backward at
  *   torch.nn.InstanceNorm2d(out_dim), torch.nn.LeakyReLU(0.2)   BasicGANs/models.py:79-80 (the WGAN-GP critic)
  *   torch.nn.InstanceNorm2d(channels) inside AdaIN               StyleGAN/model.py:195 (act = GC_ACT_NONE)
@@ -142,16 +143,17 @@ int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_
  * bwd:      gx = d(loss)/dx given gz = d(loss)/dz              (statistics are recomputed from x)
  * bwd_bwd:  given u = d(loss2)/d(gx):  g_x = d(loss2)/dx through gx,  g_gz = d(loss2)/d(gz)
  * The second-order kernel is what the gradient penalty's .backward() needs (BasicGANs/loss_functions.py:21-28).
- * Every *_bf16 argument may be NULL; otherwise the kernel also writes a bf16 (round-to-nearest-even) copy of that
+ * Every *_bf16 argument may be NULL (and must be with dtype = GC_BF16); otherwise the kernel also writes a bf16 (round-to-nearest-even) copy of that
  * output there, same layout, for the convolution that reads it next in GC_PREC_BF16 mode. */
-int gc_instnorm_act_fwd(const float* x, float* z, void* z_bf16, int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope,
-                        void* stream);
-int gc_instnorm_act_bwd(const float* x, const float* gz, float* gx, void* gx_bf16, int32_t N, int32_t HW, int32_t C, float eps,
-                        int32_t act, float slope, void* stream);
-int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, float* g_x, float* g_gz, void* g_x_bf16, void* g_gz_bf16,
-                            int32_t N, int32_t HW, int32_t C, float eps, int32_t act, float slope, void* stream);
+int gc_instnorm_act_fwd(const void* x, void* z, void* z_bf16, int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, int32_t act,
+                        float slope, void* stream);
+int gc_instnorm_act_bwd(const void* x, const void* gz, void* gx, void* gx_bf16, int32_t N, int32_t HW, int32_t C, int32_t dtype,
+                        float eps, int32_t act, float slope, void* stream);
+int gc_instnorm_act_bwd_bwd(const void* x, const void* gz, const void* u, void* g_x, void* g_gz, void* g_x_bf16, void* g_gz_bf16,
+                            int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, int32_t act, float slope, void* stream);
 
-/* BatchNorm2d fused with an optional ReLU / LeakyReLU, NHWC fp32, C a multiple of 4, P = N*H*W pixels.  Replaces
+/* BatchNorm2d fused with an optional ReLU / LeakyReLU, NHWC, x / y / gy / gx of one gc_dtype, `dtype` ( parameters,
+ * statistics and arithmetic fp32), C a multiple of 4, P = N*H*W pixels.  Replaces
  * aten::batch_norm (+ its backward) followed by aten::relu / aten::leaky_relu at
  *   torch.nn.BatchNorm2d(out_dim), torch.nn.ReLU(True)          BasicGANs/models.py:37, BasicGANs/DCGAN.py:49
  *   norm_op(out_dim), torch.nn.LeakyReLU(0.2) with BatchNorm2d  BasicGANs/models.py:79-80 (the DCGAN critic)
@@ -165,13 +167,13 @@ int gc_instnorm_act_bwd_bwd(const float* x, const float* gz, const float* u, flo
  * counter + 1) instead of handing the running buffers to the forward call.  The backward call assumes a training-mode forward (statistics depend on x).
  * workspace: gc_batchnorm_workspace_bytes(P, C) bytes, 16-byte aligned.  *_bf16: optional bf16 copy as above. */
 size_t gc_batchnorm_workspace_bytes(int64_t P, int32_t C);
-int gc_batchnorm_act_fwd(const float* x, float* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
-                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, float eps, float momentum, int32_t act,
-                         float slope, int32_t training, void* stream);
-int gc_batchnorm_act_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
-                         const float* save_rstd, float* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
-                         size_t workspace_bytes, int64_t P, int32_t C, int32_t act, float slope, void* stream);
+                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, float eps, float momentum,
+                         int32_t act, float slope, int32_t training, void* stream);
+int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
+                         size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
 
 int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,
                                 const float* var_unbiased, int32_t C, float momentum, void* stream);
@@ -183,6 +185,15 @@ int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t
  * a HIP graph.  Same operation order as torch's single-tensor Adam. */
 int gc_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const int64_t* numel, float* step, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* Split reductions.  A convolution whose output grid cannot fill the chip (few output pixels x channels, long
+ * reduction) is split over several workgroups that add fp32 partial tiles into the zeroed output with atomics; the
+ * order of those adds, and so the last bit of the result, varies from run to run.  gc_set_split_reduction(0) turns
+ * the split off for the whole process (every output element is then produced by one workgroup in a fixed order);
+ * the default is on.  Returns the previous setting.  No counterpart in the reference, whose cuDNN algorithms are
+ * chosen by torch.backends.cudnn flags; per-channel bias gradients and fused channel statistics are summed with
+ * atomics in either setting. */
+int gc_set_split_reduction(int on);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around every launch while enabled.
  * gc_profile_collect synchronises on the recorded events, returns the number of kernel families written to
