@@ -8,14 +8,40 @@ BigGAN/train.py:108-127,187-226 (orthogonal init / regularisation, step order).
 
 Every Conv2d (3x3, 1x1, incl. the attention projections) runs on the gan_amd kernels through
 gan_amd.functional.conv2d with the spectrally normalised weight W / sigma, as the reference calls F.conv2d.  The
-power iteration, the SN Linear layers, conditional-BN statistics, attention bmm/softmax, embeddings, pooling and
+power iteration, the SN Linear layers, conditional-BN statistics, the attention product, embeddings, pooling and
 nearest upsampling stay on stock torch ops.  Reference quirks kept: sigma is not differentiated; the conditional
 BN gain has no +1; the projection term broadcasts `output` ([B,1]) against the class embedding.
+
+Two storage / arithmetic options, both off by default (set_activation_dtype, set_fused_attention):
+  * activations between layers stored in bf16 (convolutions accumulate in fp32, the normalisation statistics, the
+    Linear layers, the losses and the images stay fp32);
+  * in the bf16 precision mode, softmax(K Q) V of the attention blocks as ONE torch fused-attention call on bf16
+    operands, which never materialises the [B, 4096, 4096] weights the reference's bmm + softmax + bmm writes and
+    re-reads (17 GB at batch 256).
 """
 import torch
 
 from .. import functional as GF
 from .. import nn as gnn
+from .. import ops
+
+_act_dtype = None          # None: every layer follows its input (fp32 images -> fp32 activations)
+_fused_attention = False
+
+
+def set_activation_dtype(dtype):
+    """torch.bfloat16: convolutions store bf16 outputs; None or torch.float32: fp32 storage (the reference's)."""
+    global _act_dtype
+    _act_dtype = None if dtype in (None, torch.float32) else dtype
+
+
+def set_fused_attention(on):
+    global _fused_attention
+    _fused_attention = bool(on)
+
+
+def _like(t, ref):
+    return t if t.dtype == ref.dtype else t.to(ref.dtype)
 
 
 class SpectralNorm(object):
@@ -55,9 +81,10 @@ class Conv2d(SpectralNorm, gnn.Conv2d):
                             dilation=dilation, groups=groups, bias=bias)
         SpectralNorm.__init__(self, output_channels, n_iterations=n_iterations, norm=norm)
 
-    def forward(self, x):
+    def forward(self, x, activation=None, out_dtype=None):
         return GF.conv2d(x, self.compute_weight(), bias=self.bias, stride=self.stride, padding=self.padding,
-                         dilation=self.dilation, groups=self.groups)
+                         dilation=self.dilation, groups=self.groups, activation=activation,
+                         out_dtype=out_dtype if out_dtype is not None else _act_dtype)
 
 
 class BatchNorm(torch.nn.Module):
@@ -67,7 +94,7 @@ class BatchNorm(torch.nn.Module):
         self.linear = Linear(y_dim, channels * 2)
 
     def forward(self, x, y):
-        gamma, beta = self.linear(y).chunk(2, dim=1)
+        gamma, beta = _like(self.linear(y), x).chunk(2, dim=1)
         return gamma.unsqueeze(2).unsqueeze(2) * self.batch_norm(x) + beta.unsqueeze(2).unsqueeze(2)
 
 
@@ -82,12 +109,27 @@ class SelfAttentionBlock(torch.nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
-        key = self.f_layer(x).reshape(b, -1, h * w).permute(0, 2, 1)
-        query = self.g_layer(x).reshape(b, -1, h * w)
-        attention_weights = self.softmax(torch.bmm(key, query))
-        value = self.h_layer(x).reshape(b, -1, h * w)
-        output = torch.bmm(attention_weights, value.permute(0, 2, 1)).view(b, -1, h, w)
-        return self.gamma * output + x
+        key = self.f_layer(x).reshape(b, -1, h * w).permute(0, 2, 1)      # [b, positions, c / k]
+        query = self.g_layer(x).reshape(b, -1, h * w)                      # [b, c / k, positions]
+        value = self.h_layer(x).reshape(b, -1, h * w)                      # [b, c, positions]
+        if _fused_attention and ops.get_precision() == ops._lib.GC_PREC_BF16:
+            output = self._fused(key, query.permute(0, 2, 1), value.permute(0, 2, 1), x.dtype)
+        else:
+            attention_weights = self.softmax(torch.bmm(key, query))
+            output = torch.bmm(attention_weights, value.permute(0, 2, 1))
+        # the reference reinterprets the [b, positions, c] product as [b, c, h, w] without a transpose
+        output = output.reshape(b, -1, h, w)
+        return _like(self.gamma, output) * output + x
+
+    @staticmethod
+    def _fused(q, k, v, out_dtype):
+        """softmax(q k^T) v with unit scale; q, k: [b, positions, d], v: [b, positions, c]; d is zero-padded to c
+        because the fused kernels want one width for all three operands."""
+        pad = v.shape[2] - q.shape[2]
+        q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+        q, k = torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(k, (0, pad))
+        o = torch.nn.functional.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None], scale=1.0)[:, 0]
+        return o.to(out_dtype)
 
 
 class GeneratorBlock(torch.nn.Module):
@@ -124,6 +166,8 @@ class Generator(torch.nn.Module):
         latent_vectors = torch.split(latent_vector, 20, dim=1)
         y_embedding = self.linear_y(y)
         output = self.linear_z(latent_vectors[0]).view(latent_vector.shape[0], -1, 4, 4)
+        if _act_dtype is not None:
+            output = output.to(_act_dtype)
         index = 1
         for layer in self.main_sequence:
             if isinstance(layer, GeneratorBlock):
@@ -131,7 +175,7 @@ class Generator(torch.nn.Module):
                 index += 1
             else:
                 output = layer(output)
-        return self.tanh(self.to_RGB_layer(torch.nn.functional.relu(self.bn(output))))
+        return self.tanh(self.to_RGB_layer(torch.nn.functional.relu(self.bn(output)), out_dtype=torch.float32))
 
 
 class DiscriminatorBlock(torch.nn.Module):
@@ -145,7 +189,7 @@ class DiscriminatorBlock(torch.nn.Module):
         self.residual_conv = Conv2d(input_channels, output_channels, kernel_size=1, stride=1)
 
     def forward(self, x):
-        output = self.downsample(self.conv_2(self.relu_2(self.conv_1(self.relu_1(x)))))
+        output = self.downsample(self.conv_2(self.conv_1(self.relu_1(x), activation="relu")))    # relu_2 in conv_1's epilogue
         return output + self.downsample(self.residual_conv(x))
 
 
@@ -161,7 +205,7 @@ class Discriminator(torch.nn.Module):
         self.projection_layer = Linear(16 * ch, 1)
 
     def forward(self, x, y):
-        h = torch.sum(self.relu(self.main_sequence(x)), dim=[2, 3])
+        h = torch.sum(self.relu(self.main_sequence(x)).float(), dim=[2, 3])
         output = self.projection_layer(h)
         y_embedding = self.embedding_layer(y)
         return output + torch.sum(y_embedding * output, dim=1).unsqueeze(1)

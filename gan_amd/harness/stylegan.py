@@ -10,8 +10,12 @@ Wasserstein-GP loss of BasicGANs/loss_functions.py:4-38.
 What runs where: every Conv2d goes through gan_amd.nn.Conv2d (the EqualizedLR pre-hook's scaled, non-leaf weight is
 read at call time), FusedUpsample through gan_amd.functional.conv_transpose2d, the depthwise blur through
 gan_amd.functional.blur3x3 (self-adjoint, so it needs no custom backward Function), the InstanceNorm inside AdaIN
-through the fused instance-norm kernel.  The mapping MLP, the style affine, noise injection, LeakyReLU, minibatch
-standard deviation and the fade-in blends stay on stock torch ops.
+through the fused instance-norm kernel; the LeakyReLU that follows a discriminator convolution runs in that
+convolution's epilogue (same arithmetic as the separate module).  The mapping MLP, the style affine, noise injection,
+the generator's LeakyReLU, minibatch standard deviation and the fade-in blends stay on stock torch ops.
+
+set_activation_dtype(torch.bfloat16) makes every convolution store bf16 outputs (fp32 accumulation; images, styles,
+the minibatch statistic, the final projection and the losses stay fp32); the default keeps fp32 storage.
 
 Randomness the reference draws inside forward (per-block noise images, style-mixing crossover) can be passed in so
 that a step is repeatable across devices.  Reference quirks kept: the same noise image is used for both injections
@@ -24,6 +28,17 @@ import torch
 
 from .. import functional as GF
 from .. import nn as gnn
+
+_act_dtype = None          # None: every layer follows its input (fp32 storage)
+
+
+def set_activation_dtype(dtype):
+    global _act_dtype
+    _act_dtype = None if dtype in (None, torch.float32) else dtype
+
+
+def _like(t, ref):
+    return t if t.dtype == ref.dtype else t.to(ref.dtype)
 
 
 class EqualizedLR:
@@ -65,14 +80,20 @@ class EqualizedLinearLayer(torch.nn.Module):
 
 
 class EqualizedConv2d(torch.nn.Module):
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, out_dtype=None, **kwargs):
         super().__init__()
         conv2d = gnn.Conv2d(*args, **kwargs)
         conv2d.weight.data.normal_(mean=0, std=1)
         conv2d.bias.data.zero_()
         self.conv2d = equalized_lr(conv2d)
+        self.out_dtype = out_dtype        # a fixed storage type for this layer's output (image layers: fp32)
 
-    def forward(self, x):
+    def fuse_leaky_relu(self, negative_slope):
+        self.conv2d.activation, self.conv2d.negative_slope = "leaky_relu", negative_slope
+        return self
+
+    def forward(self, x, out_dtype=None):
+        self.conv2d.out_dtype = out_dtype or self.out_dtype or _act_dtype
         return self.conv2d(x)
 
 
@@ -105,7 +126,8 @@ class ConstantInput(torch.nn.Module):
         self.constant_input = torch.nn.Parameter(torch.randn(1, n_channels, size, size))
 
     def forward(self, x):
-        return self.constant_input.repeat(x.shape[0], 1, 1, 1)
+        c = self.constant_input if _act_dtype is None else self.constant_input.to(_act_dtype)
+        return c.repeat(x.shape[0], 1, 1, 1)
 
 
 class NoiseInput(torch.nn.Module):
@@ -114,7 +136,7 @@ class NoiseInput(torch.nn.Module):
         self.scaling_factor = torch.nn.Parameter(torch.zeros(1, n_channels, 1, 1))
 
     def forward(self, x, noise):
-        return x + self.scaling_factor * noise
+        return torch.addcmul(x, _like(self.scaling_factor, x), _like(noise, x))     # x + scaling_factor * noise, one pass
 
 
 class AdaptiveInstanceNormalization(torch.nn.Module):
@@ -126,9 +148,9 @@ class AdaptiveInstanceNormalization(torch.nn.Module):
         self.affine_transformation_layer.linear_layer.bias.data[input_ch:] = 0
 
     def forward(self, x, style):
-        styles = self.affine_transformation_layer(style)
+        styles = _like(self.affine_transformation_layer(style), x)
         y_s, y_b = torch.chunk(styles, 2, dim=1)
-        return y_s.unsqueeze(2).unsqueeze(3) * self.instance_normalization(x) + y_b.unsqueeze(2).unsqueeze(3)
+        return torch.addcmul(y_b.unsqueeze(2).unsqueeze(3), y_s.unsqueeze(2).unsqueeze(3), self.instance_normalization(x))
 
 
 class FusedUpsample(torch.nn.Module):
@@ -144,7 +166,7 @@ class FusedUpsample(torch.nn.Module):
     def forward(self, input):
         weight = torch.nn.functional.pad(self.weight * self.multiplier, [1, 1, 1, 1])
         weight = (weight[:, :, 1:, 1:] + weight[:, :, :-1, 1:] + weight[:, :, 1:, :-1] + weight[:, :, :-1, :-1]) / 4
-        return GF.conv_transpose2d(input, weight, self.bias, stride=2, padding=self.pad)
+        return GF.conv_transpose2d(input, weight, self.bias, stride=2, padding=self.pad, out_dtype=_act_dtype)
 
 
 class SynthesisNetworkBlock(torch.nn.Module):
@@ -202,7 +224,7 @@ class SynthesisNetwork(torch.nn.Module):
             SynthesisNetworkBlock(512, 512), SynthesisNetworkBlock(512, 256), SynthesisNetworkBlock(256, 128, fused=fused),
             SynthesisNetworkBlock(128, 64, fused=fused), SynthesisNetworkBlock(64, 32, fused=fused),
             SynthesisNetworkBlock(32, 16, fused=fused))
-        self.to_RGB_layers = torch.nn.Sequential(*[EqualizedConv2d(c, image_dim, kernel_size=1, stride=1, padding=0)
+        self.to_RGB_layers = torch.nn.Sequential(*[EqualizedConv2d(c, image_dim, kernel_size=1, stride=1, padding=0, out_dtype=torch.float32)
                                                    for c in (512, 512, 512, 512, 256, 128, 64, 32, 16)])
 
     def forward(self, w_vectors, pg_step=8, alpha=1, noises=None, crossover_point=None):
@@ -264,9 +286,21 @@ class DownsampleBlock(torch.nn.Module):
         else:
             self.convolution_2 = EqualizedConv2d(output_channels, output_channels, kernel_size=kernel_size_2, padding=padding_2)
         self.activation_2 = torch.nn.LeakyReLU(0.2)
+        # LeakyReLU in the epilogue of the convolution it follows (not after the AvgPool2d of the unfused downsample)
+        self.convolution_1[0].fuse_leaky_relu(0.2)
+        self._fused_2 = not (downsample and not fused)
+        if self._fused_2:
+            (self.convolution_2[-1] if downsample else self.convolution_2).fuse_leaky_relu(0.2)
 
-    def forward(self, x):
-        return self.activation_2(self.convolution_2(self.activation_1(self.convolution_1(x))))
+    def forward(self, x, out_dtype=None):
+        """`out_dtype`: storage type of this block's result (None: the harness's activation type)."""
+        output = self.convolution_1(x)
+        if isinstance(self.convolution_2, torch.nn.Sequential):
+            for layer in self.convolution_2:
+                output = layer(output, out_dtype) if isinstance(layer, EqualizedConv2d) else layer(output)
+        else:
+            output = self.convolution_2(output, out_dtype)
+        return output if self._fused_2 else self.activation_2(output)
 
 
 class Discriminator(torch.nn.Module):
@@ -291,16 +325,19 @@ class Discriminator(torch.nn.Module):
         for index in range(progressive_growing_phase + 1):
             cur_idx = -progressive_growing_phase - 1 + index
             cur_layer = self.downsampling_blocks[cur_idx]
+            # The minibatch standard deviation divides by a per-position spread over the batch, which bf16 rounding can
+            # collapse to exactly zero: the features it is taken of are produced and kept in fp32.
+            feeds_std = index == progressive_growing_phase - 1
             if index == 0:
                 cur_idx_rgb = cur_idx if not self.use_activations else cur_idx * 2
-                output = self.from_RGB_layers[cur_idx_rgb](output)
+                output = self.from_RGB_layers[cur_idx_rgb](output, torch.float32 if progressive_growing_phase == 0 else None)
                 if self.use_activations:
                     output = self.from_RGB_layers[cur_idx_rgb + 1](output)
             if index == progressive_growing_phase:
                 averaged_std = output.std(dim=0, unbiased=False).mean()
                 averaged_std = averaged_std.expand(output.shape[0], 1, output.shape[2], output.shape[3])
                 output = torch.cat([output, averaged_std], dim=1)
-            output = cur_layer(output)
+            output = cur_layer(output, torch.float32 if feeds_std else None)
             if 0 <= alpha < 1 and index == 0 and cur_idx != -1:
                 x = torch.nn.functional.avg_pool2d(x, 2)
                 cur_idx_rgb = cur_idx if not self.use_activations else cur_idx * 2
@@ -308,7 +345,7 @@ class Discriminator(torch.nn.Module):
                 if self.use_activations:
                     x = self.from_RGB_layers[cur_idx_rgb + 1](output)
                 output = (1 - alpha) * x + alpha * output
-        return self.final_projection(output.squeeze(2).squeeze(2))
+        return self.final_projection(output.squeeze(2).squeeze(2).float())
 
 
 def requires_grad(model, flag=True):

@@ -570,13 +570,18 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
         gan.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec,tol,coarse", [("fp32x3", 5e-4, 5e-2), ("bf16", 5e-2, 3e-1)])
-def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse):
+# (bf16: the gradients of the noise scaling factors and of the biases are sums of signed terms that largely cancel; the
+#  rounding of the summands leaves 0.2-0.3 of the small remainder, in either storage type)
+@pytest.mark.parametrize("prec,tol,coarse,bf16_storage", [("fp32x3", 5e-4, 5e-2, False), ("bf16", 5e-2, 4e-1, False), ("bf16", 5e-2, 4e-1, True)],
+                         ids=["fp32x3", "bf16", "bf16_storage"])
+def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse, bf16_storage):
     """StyleGAN-v1 at 128x128 (pg step 5, fused blocks, style mixing, minibatch stddev, 513-channel conv): critic phase
     with gradient penalty, generator phase and a fade-in forward pass against the reference trace."""
     from gan_amd.harness import stylegan as S
     from test_oracle_golden import check_grads, stylegan_setup
     gan.set_precision(prec)
+    gan.set_split_reduction(False)      # run-to-run reproducible sums
+    S.set_activation_dtype(torch.bfloat16 if bf16_storage else None)
     try:
         z, rec, G, D, real, zs, noises = stylegan_setup(golden_dir, lambda: S.StyleBasedGenerator(fused=True),
                                                         lambda: S.Discriminator(fused=True, use_activations=True))
@@ -601,15 +606,21 @@ def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coa
         assert check_grads(G.named_parameters(), z, "gen.gradG", coarse) > 40
     finally:
         gan.set_precision("bf16")
+        gan.set_split_reduction(True)
+        S.set_activation_dtype(None)
 
 
-@pytest.mark.parametrize("prec,tol,coarse", [("fp32x3", 5e-4, 5e-2), ("bf16", 5e-2, 3e-1)])
-def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse):
+@pytest.mark.parametrize("prec,tol,coarse,fast", [("fp32x3", 5e-4, 5e-2, False), ("bf16", 5e-2, 3e-1, False), ("bf16", 5e-2, 3e-1, True)],
+                         ids=["fp32x3", "bf16", "bf16_storage_fused_attention"])
+def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse, fast):
     """BigGAN 128x128 (spectral-norm 3x3 / 1x1 convs incl. the attention projections, conditional BN, nearest
-    upsampling, projection discriminator): hinge phases with orthogonal regularisation against the reference trace."""
+    upsampling, projection discriminator): hinge phases with orthogonal regularisation against the reference trace.
+    `fast`: activations stored in bf16 and the attention product as one fused call (the harness's speed options)."""
     from gan_amd.harness import biggan as Bg
     from test_oracle_golden import biggan_setup, check_grads
     gan.set_precision(prec)
+    Bg.set_activation_dtype(torch.bfloat16 if fast else None)
+    Bg.set_fused_attention(fast)
     try:
         z, rec, G, D, real, z1, z2, labels = biggan_setup(golden_dir, Bg)
         G.cuda(); D.cuda()
@@ -626,6 +637,8 @@ def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coars
         assert rel(img[:, :, 32:96, 32:96], z["image_crop"]) < 20 * tol
     finally:
         gan.set_precision("bf16")
+        Bg.set_activation_dtype(None)
+        Bg.set_fused_attention(False)
 
 
 @pytest.mark.parametrize("fused_adam", [False, True], ids=["torch_adam", "fused_adam"])

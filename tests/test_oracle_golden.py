@@ -222,7 +222,9 @@ def check_grads(named_params, z, prefix, tol, report=None):
         g = p.grad.detach().cpu().numpy()
         want_norm = z[prefix + "_norm." + k][0]
         if want_norm < 1e-6 * biggest:
-            assert np.linalg.norm(g) < 1e-4 * biggest, k
+            # analytically zero gradients (a bias in front of a normalisation): rounding residue only, which scales
+            # with the comparison's tolerance (bf16-stored activations leave about 2e-4 of the largest gradient)
+            assert np.linalg.norm(g) < max(1e-4, 2e-3 * tol) * biggest, k
             continue
         gs = g if g.size <= 20000 else g.ravel()[::max(1, g.size // 4096)][:4096]
         err = rel_err(gs, z[key])

@@ -1,6 +1,10 @@
 """Developer tool: one training step (discriminator phase + generator phase, gradients only) of each of the
 reference's model families on the GPU harnesses, against the CPU restatement of the reference (oracle/) on the host
-cores, at the reference's default widths.  Prints a table; run on the GPU box:  python tools/family_bench.py"""
+cores, at the reference's default widths.  Prints a table; run on the GPU box:
+    python tools/family_bench.py            reduced sizes (seconds)
+    python tools/family_bench.py --full     per-GPU sizes of the reference's configurations (Pix2Pix 256x256 batch 8,
+                                            StyleGAN 256x256 batch 32, BigGAN 128x128 ch 64 batch 256); the CPU side
+                                            runs batch 4 and its rate is taken as independent of the batch"""
 import sys
 import time
 
@@ -14,6 +18,15 @@ from oracle import ref_biggan, ref_models, ref_stylegan
 
 torch.manual_seed(0)
 dev = "cuda:0"
+FULL = "--full" in sys.argv
+CPU_B = 4
+ONLY = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]     # --only=biggan etc.
+NO_CPU = "--no-cpu" in sys.argv
+FAST = "--fast" in sys.argv      # bf16 activation storage and the other speed options of the harnesses
+
+
+def want(name):
+    return not ONLY or name in ONLY
 
 
 def gpu_time(step, n=5):
@@ -45,9 +58,15 @@ def kernel_table(step, title):
 
 
 def cpu_time(step):
+    if NO_CPU:
+        return float("nan")
     t0 = time.perf_counter()
     step()
     return time.perf_counter() - t0
+
+
+def note(msg):
+    print(msg, flush=True)
 
 
 def zero(*nets):
@@ -58,82 +77,94 @@ def zero(*nets):
 
 rows = []
 
-# ---- Pix2Pix: U-Net (ch 64) + PatchGAN on 256x256, batch 4
-B = 4
-real, label = torch.rand(B, 3, 256, 256) * 2 - 1, torch.rand(B, 3, 256, 256)
-G, D = pix2pix.Generator(ch=64).to(dev), pix2pix.Discriminator(ch=64).to(dev)
-Gr, Dr = ref_models.P2PGenerator(ch=64), ref_models.P2PDiscriminator(ch=64)
-rg, lg = real.to(dev), label.to(dev)
+if want("pix2pix"):
+    # ---- Pix2Pix: U-Net (ch 64) + PatchGAN on 256x256, batch 4
+    B = 8 if FULL else 4
+    real, label = torch.rand(B, 3, 256, 256) * 2 - 1, torch.rand(B, 3, 256, 256)
+    G, D = pix2pix.Generator(ch=64).to(dev), pix2pix.Discriminator(ch=64).to(dev)
+    Gr, Dr = ref_models.P2PGenerator(ch=64), ref_models.P2PDiscriminator(ch=64)
+    rg, lg = real.to(dev), label.to(dev)
 
 
-def p2p_gpu():
-    zero(G, D)
-    pix2pix.discriminator_phase(G, D, rg, lg)
-    pix2pix.generator_phase(G, D, rg, lg)
+    def p2p_gpu():
+        zero(G, D)
+        pix2pix.discriminator_phase(G, D, rg, lg)
+        pix2pix.generator_phase(G, D, rg, lg)
 
 
-def p2p_cpu():
-    zero(Gr, Dr)
-    ref_models.pix2pix_discriminator_phase(Gr, Dr, real, label)
-    ref_models.pix2pix_generator_phase(Gr, Dr, real, label)
+    def p2p_cpu():
+        zero(Gr, Dr)
+        ref_models.pix2pix_discriminator_phase(Gr, Dr, real[:CPU_B], label[:CPU_B])
+        ref_models.pix2pix_generator_phase(Gr, Dr, real[:CPU_B], label[:CPU_B])
 
 
-rows.append(("Pix2Pix U-Net + PatchGAN, 256x256, batch 4", B, gpu_time(p2p_gpu), cpu_time(p2p_cpu)))
-kernel_table(p2p_gpu, "Pix2Pix")
-del G, D, Gr, Dr
+    rows.append((f"Pix2Pix U-Net + PatchGAN, 256x256, batch {B}", B, gpu_time(p2p_gpu), cpu_time(p2p_cpu)))
+    note("pix2pix done")
+    kernel_table(p2p_gpu, "Pix2Pix")
+    del G, D, Gr, Dr
 
-# ---- StyleGAN-v1 at progressive step 5 (128x128), batch 16, style mixing, gradient penalty
-B, pg = 16, 5
-real = torch.rand(B, 3, 128, 128) * 2 - 1
-zs = torch.randn(4, B, 512)
-eps = torch.rand(B, 1, 1, 1)
-G, D = stylegan.StyleBasedGenerator().to(dev), stylegan.Discriminator().to(dev)
-Gr, Dr = ref_stylegan.StyleBasedGenerator(), ref_stylegan.Discriminator()
-rg, zg, eg = real.to(dev), zs.to(dev), eps.to(dev)
-
-
-def sg_gpu():
-    zero(G, D)
-    stylegan.critic_phase(G, D, rg, [zg[0], zg[1]], eg, pg, crossover_point=3)
-    stylegan.generator_phase(G, D, [zg[2], zg[3]], pg, crossover_point=3)
+if want("stylegan"):
+    # ---- StyleGAN-v1 at progressive step 5 (128x128), batch 16, style mixing, gradient penalty
+    if FAST:
+        stylegan.set_activation_dtype(torch.bfloat16)
+    B, pg = (32, 6) if FULL else (16, 5)
+    real = torch.rand(B, 3, 4 * 2 ** pg, 4 * 2 ** pg) * 2 - 1
+    zs = torch.randn(4, B, 512)
+    eps = torch.rand(B, 1, 1, 1)
+    G, D = stylegan.StyleBasedGenerator().to(dev), stylegan.Discriminator().to(dev)
+    Gr, Dr = ref_stylegan.StyleBasedGenerator(), ref_stylegan.Discriminator()
+    rg, zg, eg = real.to(dev), zs.to(dev), eps.to(dev)
 
 
-def sg_cpu():
-    zero(Gr, Dr)
-    ref_stylegan.critic_phase(Gr, Dr, real, [zs[0], zs[1]], eps, pg, crossover_point=3)
-    ref_stylegan.generator_phase(Gr, Dr, [zs[2], zs[3]], pg, crossover_point=3)
+    def sg_gpu():
+        zero(G, D)
+        stylegan.critic_phase(G, D, rg, [zg[0], zg[1]], eg, pg, crossover_point=3)
+        stylegan.generator_phase(G, D, [zg[2], zg[3]], pg, crossover_point=3)
 
 
-rows.append(("StyleGAN-v1, progressive step 5 (128x128), batch 16", B, gpu_time(sg_gpu), cpu_time(sg_cpu)))
-kernel_table(sg_gpu, "StyleGAN")
-del G, D, Gr, Dr
-
-# ---- BigGAN 128x128 (G ch 96, D ch 64), 10 classes, batch 16
-B, ncls = 16, 10
-real = torch.rand(B, 3, 128, 128) * 2 - 1
-z1, z2 = torch.rand(B, 120), torch.rand(B, 120)
-lab = torch.randint(0, ncls, (3, B))
-G, D = biggan.Generator(n_classes=ncls, ch=96).to(dev), biggan.Discriminator(n_classes=ncls, ch=64).to(dev)
-Gr, Dr = ref_biggan.Generator(n_classes=ncls, ch=96), ref_biggan.Discriminator(n_classes=ncls, ch=64)
-rg, z1g, z2g, labg = real.to(dev), z1.to(dev), z2.to(dev), lab.to(dev)
+    def sg_cpu():
+        zero(Gr, Dr)
+        ref_stylegan.critic_phase(Gr, Dr, real[:CPU_B], [zs[0, :CPU_B], zs[1, :CPU_B]], eps[:CPU_B], pg, crossover_point=3)
+        ref_stylegan.generator_phase(Gr, Dr, [zs[2, :CPU_B], zs[3, :CPU_B]], pg, crossover_point=3)
 
 
-def bg_gpu():
-    zero(G, D)
-    biggan.discriminator_phase(G, D, rg, labg[0], z1g, labg[1])
-    biggan.generator_phase(G, D, z2g, labg[2])
+    rows.append((f"StyleGAN-v1, progressive step {pg} ({4 * 2 ** pg}x{4 * 2 ** pg}), batch {B}", B, gpu_time(sg_gpu, 3), cpu_time(sg_cpu)))
+    note("stylegan done")
+    kernel_table(sg_gpu, "StyleGAN")
+    del G, D, Gr, Dr
+
+if want("biggan"):
+    # ---- BigGAN 128x128 (G ch 96, D ch 64), 10 classes, batch 16
+    if FAST:
+        biggan.set_activation_dtype(torch.bfloat16)
+        biggan.set_fused_attention(True)
+    B, ncls = (256 if FULL else 16), 10
+    gch = 64 if FULL else 96
+    real = torch.rand(B, 3, 128, 128) * 2 - 1
+    z1, z2 = torch.rand(B, 120), torch.rand(B, 120)
+    lab = torch.randint(0, ncls, (3, B))
+    G, D = biggan.Generator(n_classes=ncls, ch=gch).to(dev), biggan.Discriminator(n_classes=ncls, ch=64).to(dev)
+    Gr, Dr = ref_biggan.Generator(n_classes=ncls, ch=gch), ref_biggan.Discriminator(n_classes=ncls, ch=64)
+    rg, z1g, z2g, labg = real.to(dev), z1.to(dev), z2.to(dev), lab.to(dev)
 
 
-def bg_cpu():
-    zero(Gr, Dr)
-    ref_biggan.discriminator_phase(Gr, Dr, real, lab[0], z1, lab[1])
-    ref_biggan.generator_phase(Gr, Dr, z2, lab[2])
+    def bg_gpu():
+        zero(G, D)
+        biggan.discriminator_phase(G, D, rg, labg[0], z1g, labg[1])
+        biggan.generator_phase(G, D, z2g, labg[2])
 
 
-rows.append(("BigGAN 128x128 (G ch 96, D ch 64), batch 16", B, gpu_time(bg_gpu), cpu_time(bg_cpu)))
-kernel_table(bg_gpu, "BigGAN")
+    def bg_cpu():
+        zero(Gr, Dr)
+        ref_biggan.discriminator_phase(Gr, Dr, real[:CPU_B], lab[0, :CPU_B], z1[:CPU_B], lab[1, :CPU_B])
+        ref_biggan.generator_phase(Gr, Dr, z2[:CPU_B], lab[2, :CPU_B])
+
+
+    rows.append((f"BigGAN 128x128 (G ch {gch}, D ch 64), batch {B}", B, gpu_time(bg_gpu, 3), cpu_time(bg_cpu)))
+    kernel_table(bg_gpu, "BigGAN")
 
 print(f"{'family (D phase + G phase, gradients only, eager launches)':62s} {'GPU ms':>9s} {'GPU img/s':>10s} {'CPU s':>8s} {'CPU img/s':>10s} {'ratio':>7s}")
 for name, b, tg, tc in rows:
-    print(f"{name:62s} {1e3 * tg:9.2f} {b / tg:10.1f} {tc:8.2f} {b / tc:10.2f} {tc / tg:7.1f}")
-print(f"(torch CPU threads: {torch.get_num_threads()}; bf16 MFMA precision mode on the GPU)")
+    print(f"{name:62s} {1e3 * tg:9.2f} {b / tg:10.1f} {tc:8.2f} {CPU_B / tc:10.2f} {(b / tg) / (CPU_B / tc):7.1f}")
+print("harness speed options (bf16 activation storage, fused attention):", "on" if FAST else "off")
+print(f"(CPU steps run at batch {CPU_B}; torch CPU threads: {torch.get_num_threads()}; bf16 MFMA precision mode on the GPU)")
