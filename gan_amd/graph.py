@@ -1,0 +1,39 @@
+"""Recording a whole training step into one HIP graph.
+
+A step of the reference's models is hundreds of launches (per-layer kernels, normalisation, elementwise glue, the
+optimizer); at small per-GPU batches (Pix2Pix: 8 images) the host cannot issue them as fast as the GPU retires them.
+GraphedStep runs the step a few times on a side stream, records it once and afterwards replays the recording with one
+host call per step.
+
+What the step function may do: anything that only enqueues GPU work on tensors whose storage outlives the recording
+(parameters, optimizer state, preallocated inputs that the caller refreshes with copy_()).  What it may not do: read
+values back to the host (.item(), prints), rebind a buffer to a new tensor (write into it instead), branch on data, or
+draw host-side random numbers that should differ between steps (device-side generators are recorded correctly).
+"""
+import torch
+
+from . import ops
+
+
+class GraphedStep:
+    def __init__(self, step, warmup=2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # Packed weight images and bf16 operand copies made during the warm-up must not be found by the recording: their
+        # producer kernels would be missing from the graph and replays would keep reading the values of this moment.
+        ops.clear_weight_cache()
+        ops.clear_cast_cache()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step()
+        ops.clear_cast_cache()
+
+    def __call__(self):
+        """Replays the step; returns the tensors the recorded call returned (same storage every time)."""
+        self.graph.replay()
+        return self.out

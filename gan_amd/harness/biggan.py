@@ -61,7 +61,8 @@ class SpectralNorm(object):
             V_vector = torch.nn.functional.normalize(torch.matmul(self.U_vector, W_matrix), p=self.norm)
             U_vector = torch.nn.functional.normalize(torch.matmul(V_vector, W_matrix.T), p=self.norm)
             spectral_norm = torch.matmul(torch.matmul(U_vector, W_matrix), V_vector.T).squeeze()
-            self.U_vector.data = U_vector
+            self.U_vector.copy_(U_vector)     # written in place (the reference rebinds .data): same values, and the
+            #                                   buffer keeps its storage, which a recorded step relies on
             return spectral_norm, U_vector
 
 

@@ -680,6 +680,56 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     assert not torch.allclose(ref[2], ref[4], rtol=1e-3)      # the losses do change from cycle to cycle
 
 
+def test_graphed_step_matches_eager_steps(gan):
+    """gan_amd.GraphedStep on a full Pix2Pix step (both phases, both fused-Adam updates; U-Net and PatchGAN at width 8):
+    three replays with fresh inputs copied into the static tensors must give the losses of three eager steps."""
+    from gan_amd.harness import pix2pix as P
+    B, ch = 2, 8
+    gen = torch.Generator().manual_seed(11)
+    batches = [(torch.rand(B, 3, 256, 256, generator=gen) * 2 - 1, torch.rand(B, 3, 256, 256, generator=gen)) for _ in range(5)]
+    masks = [(torch.rand(B, ch * 8, r, r, generator=gen) < 0.5).float().cuda() * 2 for r in (2, 4, 8)]
+
+    def make():
+        torch.manual_seed(12)
+        G, D = P.Generator(ch=ch).cuda(), P.Discriminator(ch=ch).cuda()
+        oG = gan.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999)); oD = gan.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        real, label = torch.empty(B, 3, 256, 256, device="cuda"), torch.empty(B, 3, 256, 256, device="cuda")
+
+        def step():
+            oD.zero_grad(set_to_none=False); oG.zero_grad(set_to_none=False)
+            d = P.discriminator_phase(G, D, real, label, masks)
+            oD.step()
+            g, _ = P.generator_phase(G, D, real, label, 100.0, masks)
+            oG.step()
+            return torch.stack([d, g])
+
+        def feed(i):
+            real.copy_(batches[i][0]); label.copy_(batches[i][1])
+        return step, feed
+
+    gan.set_split_reduction(False)
+    try:
+        step, feed = make()
+        ref = []
+        for i in range(5):
+            feed(i); ref.append(step().cpu())
+        step, feed = make()
+        feed(0)
+        graphed = gan.GraphedStep(step, warmup=2)        # two warm-up steps on batch 0 (recording executes nothing) ...
+        step_e, feed_e = make()
+        feed_e(0)
+        for _ in range(2):
+            step_e()                                      # ... so the eager twin takes two steps on batch 0 as well
+        for i in range(1, 4):
+            feed(i); out = graphed().cpu()
+            feed_e(i); want = step_e().cpu()
+            assert torch.isfinite(out).all()
+            assert torch.allclose(out, want, rtol=2e-3, atol=1e-5), (i, out, want)
+    finally:
+        gan.set_split_reduction(True)
+    assert not torch.allclose(ref[1], ref[3], rtol=1e-3)
+
+
 @pytest.mark.parametrize("betas", [(0.0, 0.9), (0.5, 0.999)])
 def test_fused_adam_matches_torch_adam(gan, betas):
     """gan_amd.optim.Adam against torch.optim.Adam on the same parameters and gradients over several steps

@@ -22,6 +22,7 @@ FULL = "--full" in sys.argv
 CPU_B = 4
 ONLY = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]     # --only=biggan etc.
 NO_CPU = "--no-cpu" in sys.argv
+GRAPH = "--graph" in sys.argv    # also time the step recorded into one HIP graph
 FAST = "--fast" in sys.argv      # bf16 activation storage and the other speed options of the harnesses
 
 
@@ -40,6 +41,20 @@ def gpu_time(step, n=5):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     return sorted(ts)[len(ts) // 2]
+
+
+def graph_time(step, n=5):
+    if not GRAPH:
+        return float("nan")
+    g = gan_amd.GraphedStep(lambda: (step(), ops.clear_cast_cache()) and None)
+    for _ in range(2):
+        g()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
 
 
 def kernel_table(step, title):
@@ -98,7 +113,7 @@ if want("pix2pix"):
         ref_models.pix2pix_generator_phase(Gr, Dr, real[:CPU_B], label[:CPU_B])
 
 
-    rows.append((f"Pix2Pix U-Net + PatchGAN, 256x256, batch {B}", B, gpu_time(p2p_gpu), cpu_time(p2p_cpu)))
+    rows.append((f"Pix2Pix U-Net + PatchGAN, 256x256, batch {B}", B, gpu_time(p2p_gpu), cpu_time(p2p_cpu), graph_time(p2p_gpu)))
     note("pix2pix done")
     kernel_table(p2p_gpu, "Pix2Pix")
     del G, D, Gr, Dr
@@ -128,7 +143,7 @@ if want("stylegan"):
         ref_stylegan.generator_phase(Gr, Dr, [zs[2, :CPU_B], zs[3, :CPU_B]], pg, crossover_point=3)
 
 
-    rows.append((f"StyleGAN-v1, progressive step {pg} ({4 * 2 ** pg}x{4 * 2 ** pg}), batch {B}", B, gpu_time(sg_gpu, 3), cpu_time(sg_cpu)))
+    rows.append((f"StyleGAN-v1, progressive step {pg} ({4 * 2 ** pg}x{4 * 2 ** pg}), batch {B}", B, gpu_time(sg_gpu, 3), cpu_time(sg_cpu), graph_time(sg_gpu, 3)))
     note("stylegan done")
     kernel_table(sg_gpu, "StyleGAN")
     del G, D, Gr, Dr
@@ -160,11 +175,12 @@ if want("biggan"):
         ref_biggan.generator_phase(Gr, Dr, z2[:CPU_B], lab[2, :CPU_B])
 
 
-    rows.append((f"BigGAN 128x128 (G ch {gch}, D ch 64), batch {B}", B, gpu_time(bg_gpu, 3), cpu_time(bg_cpu)))
+    rows.append((f"BigGAN 128x128 (G ch {gch}, D ch 64), batch {B}", B, gpu_time(bg_gpu, 3), cpu_time(bg_cpu), graph_time(bg_gpu, 3)))
     kernel_table(bg_gpu, "BigGAN")
 
 print(f"{'family (D phase + G phase, gradients only, eager launches)':62s} {'GPU ms':>9s} {'GPU img/s':>10s} {'CPU s':>8s} {'CPU img/s':>10s} {'ratio':>7s}")
-for name, b, tg, tc in rows:
-    print(f"{name:62s} {1e3 * tg:9.2f} {b / tg:10.1f} {tc:8.2f} {CPU_B / tc:10.2f} {(b / tg) / (CPU_B / tc):7.1f}")
+for name, b, tg, tc, tgr in rows:
+    print(f"{name:62s} {1e3 * tg:9.2f} {b / tg:10.1f} {tc:8.2f} {CPU_B / tc:10.2f} {(b / tg) / (CPU_B / tc):7.1f}" +
+          (f"   as one HIP graph: {1e3 * tgr:8.2f} ms {b / tgr:9.1f} img/s" if GRAPH else ""))
 print("harness speed options (bf16 activation storage, fused attention):", "on" if FAST else "off")
 print(f"(CPU steps run at batch {CPU_B}; torch CPU threads: {torch.get_num_threads()}; bf16 MFMA precision mode on the GPU)")
