@@ -15,9 +15,9 @@ BN gain has no +1; the projection term broadcasts `output` ([B,1]) against the c
 Two storage / arithmetic options, both off by default (set_activation_dtype, set_fused_attention):
   * activations between layers stored in bf16 (convolutions accumulate in fp32, the normalisation statistics, the
     Linear layers, the losses and the images stay fp32);
-  * in the bf16 precision mode, softmax(K Q) V of the attention blocks as ONE torch fused-attention call on bf16
-    operands, which never materialises the [B, 4096, 4096] weights the reference's bmm + softmax + bmm writes and
-    re-reads (17 GB at batch 256).
+  * in the bf16 precision mode, softmax(K Q) V of the attention blocks on gan_amd.ops.attention (bf16 operands, fp32
+    accumulation), which never materialises the [B, 4096, 4096] weights the reference's bmm + softmax + bmm writes
+    and re-reads (17 GB at batch 256).
 """
 import torch
 
@@ -113,7 +113,7 @@ class SelfAttentionBlock(torch.nn.Module):
         key = self.f_layer(x).reshape(b, -1, h * w).permute(0, 2, 1)      # [b, positions, c / k]
         query = self.g_layer(x).reshape(b, -1, h * w)                      # [b, c / k, positions]
         value = self.h_layer(x).reshape(b, -1, h * w)                      # [b, c, positions]
-        if _fused_attention and ops.get_precision() == ops._lib.GC_PREC_BF16:
+        if _fused_attention and ops.get_precision() == ops._lib.GC_PREC_BF16 and (h * w) % 128 == 0 and c in (64, 128):
             output = self._fused(key, query.permute(0, 2, 1), value.permute(0, 2, 1), x.dtype)
         else:
             attention_weights = self.softmax(torch.bmm(key, query))
@@ -123,13 +123,10 @@ class SelfAttentionBlock(torch.nn.Module):
         return _like(self.gamma, output) * output + x
 
     @staticmethod
-    def _fused(q, k, v, out_dtype):
-        """softmax(q k^T) v with unit scale; q, k: [b, positions, d], v: [b, positions, c]; d is zero-padded to c
-        because the fused kernels want one width for all three operands."""
-        pad = v.shape[2] - q.shape[2]
-        q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
-        q, k = torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(k, (0, pad))
-        o = torch.nn.functional.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None], scale=1.0)[:, 0]
+    def _fused(key, query, value, out_dtype):
+        """softmax(key query^T) value on the fused kernel; key, query: [b, positions, c / k], value: [b, positions, c].
+        With bf16 channels-last storage the three operands are views of the projections' outputs (no copies)."""
+        o, _ = ops.attention(key.to(torch.bfloat16), query.to(torch.bfloat16), value.to(torch.bfloat16))
         return o.to(out_dtype)
 
 

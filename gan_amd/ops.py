@@ -663,3 +663,62 @@ def _bn_backward(ctx, gy, g_mean, g_rstd, g_var):
 
 
 torch.library.register_autograd("ganconv::batchnorm_act", _bn_backward, setup_context=_bn_setup)
+
+
+# ---- self-attention over image positions (BigGAN/model.py:97-103) -----------------------------------------------
+def _attn_args(k, q, v):
+    _check_cuda(k, q, v)
+    if k.dim() != 3 or q.shape != k.shape or v.dim() != 3 or v.shape[:2] != k.shape[:2]:
+        raise RuntimeError(f"ganconv: attention takes k, q [B, N, d] and v [B, N, C] (got {tuple(k.shape)}, {tuple(q.shape)}, {tuple(v.shape)})")
+    for t in (k, q, v):
+        if t.dtype != torch.bfloat16:
+            raise RuntimeError("ganconv: attention operands are bf16")
+    return k.shape[0], k.shape[1], k.shape[2], v.shape[2]
+
+
+@torch.library.custom_op("ganconv::attention", mutates_args=())
+def attention(k: Tensor, q: Tensor, v: Tensor) -> tuple[Tensor, Tensor]:
+    """softmax(k q^T) v per sample (softmax over the last index, unit scale) without the [N, N] weights in memory.
+    k, q: [B, N, d] bf16 (d 8 or 16); v: [B, N, C] bf16 (C 64 or 128); N a multiple of 128.  Returns the [B, N, C] bf16
+    product and the fp32 log-sum-exp of every row, which the backward pass reads."""
+    B, N, d, C = _attn_args(k, q, v)
+    k, q, v = k.contiguous(), q.contiguous(), v.contiguous()
+    out = torch.empty_like(v)
+    lse = torch.empty(B, N, dtype=torch.float32, device=v.device)
+    _lib.check(_lib.lib().gc_attention_fwd(_ptr(k), _ptr(q), _ptr(v), _ptr(out), _ptr(lse), B, N, d, C, _stream()), "gc_attention_fwd")
+    return out, lse
+
+
+@attention.register_fake
+def _(k, q, v):
+    return torch.empty_like(v), v.new_empty(v.shape[0], v.shape[1], dtype=torch.float32)
+
+
+@torch.library.custom_op("ganconv::attention_bwd", mutates_args=())
+def attention_bwd(k: Tensor, q: Tensor, v: Tensor, out: Tensor, dout: Tensor, lse: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    B, N, d, C = _attn_args(k, q, v)
+    k, q, v, out, dout = k.contiguous(), q.contiguous(), v.contiguous(), out.contiguous(), dout.to(torch.bfloat16).contiguous()
+    dk, dq, dv = torch.empty_like(k), torch.empty_like(q), torch.empty_like(v)
+    delta = torch.empty(B, N, dtype=torch.float32, device=v.device)
+    _lib.check(_lib.lib().gc_attention_bwd(_ptr(k), _ptr(q), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dk), _ptr(dq), _ptr(dv),
+                                           _ptr(delta), B, N, d, C, _stream()), "gc_attention_bwd")
+    return dk, dq, dv
+
+
+@attention_bwd.register_fake
+def _(k, q, v, out, dout, lse):
+    return torch.empty_like(k), torch.empty_like(q), torch.empty_like(v)
+
+
+def _attn_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs, *output)
+
+
+def _attn_backward(ctx, g_out, g_lse):
+    k, q, v, out, lse = ctx.saved_tensors
+    if g_out.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("ganconv: attention has no second-order backward")
+    return attention_bwd(k, q, v, out, g_out, lse)
+
+
+torch.library.register_autograd("ganconv::attention", _attn_backward, setup_context=_attn_setup)

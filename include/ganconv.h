@@ -186,6 +186,19 @@ int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t
 int gc_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const int64_t* numel, float* step, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* Self-attention over image positions without the [N, N] weight matrix in memory: out = softmax(k q^T) v per sample,
+ * softmax over the last index, unit scale.  Replaces the bmm + Softmax + bmm of SelfAttentionBlock.forward
+ * (BigGAN/model.py:97-103; the reference calls the [B, N, C / 8] operand of the first bmm "key" and the other
+ * "query": k indexes the softmax rows, q the softmax columns).  All tensors bf16, contiguous, 16-byte aligned:
+ * k, q [B, N, d], v / out / dout / dv [B, N, C], dk, dq [B, N, d]; lse and delta fp32 [B, N] (lse is written by the
+ * forward pass and read by the backward pass, delta is scratch of the backward pass).  Supported: N a multiple of 128,
+ * d 8 or 16, C 64 or 128 (the reference's blocks at ch = 64: 64 channels in the discriminator, 128 in the generator).
+ * Accumulation and the softmax statistics are fp32; the backward pass uses no atomics. */
+int gc_attention_fwd(const void* k, const void* q, const void* v, void* out, float* lse, int32_t B, int32_t N, int32_t d, int32_t C,
+                     void* stream);
+int gc_attention_bwd(const void* k, const void* q, const void* v, const void* out, const void* dout, const float* lse, void* dk,
+                     void* dq, void* dv, float* delta, int32_t B, int32_t N, int32_t d, int32_t C, void* stream);
+
 /* Split reductions.  A convolution whose output grid cannot fill the chip (few output pixels x channels, long
  * reduction) is split over several workgroups that add fp32 partial tiles into the zeroed output with atomics; the
  * order of those adds, and so the last bit of the result, varies from run to run.  gc_set_split_reduction(0) turns

@@ -680,6 +680,29 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     assert not torch.allclose(ref[2], ref[4], rtol=1e-3)      # the losses do change from cycle to cycle
 
 
+@pytest.mark.parametrize("B,N,d,C", [(2, 256, 8, 64), (3, 384, 16, 128), (1, 4096, 16, 128), (2, 4096, 8, 64)])
+def test_attention_against_unfused_product(gan, B, N, d, C):
+    """gan_amd.ops.attention (forward and the three operand gradients) against bmm + softmax + bmm in fp32 on the same
+    bf16-rounded operands (reference BigGAN/model.py:97-103).  Tolerance: the kernel rounds the probabilities and dS to
+    bf16 before the second products (relative 2^-9 per element, fp32 accumulation) and stores bf16 results."""
+    g = torch.Generator().manual_seed(7)
+    k = (torch.randn(B, N, d, generator=g) * 0.7).cuda().to(torch.bfloat16).requires_grad_(True)
+    q = (torch.randn(B, N, d, generator=g) * 0.7).cuda().to(torch.bfloat16).requires_grad_(True)
+    v = torch.randn(B, N, C, generator=g).cuda().to(torch.bfloat16).requires_grad_(True)
+    go = torch.randn(B, N, C, generator=g).cuda().to(torch.bfloat16)
+    out, lse = gan.ops.attention(k, q, v)
+    dk, dq, dv = torch.autograd.grad(out, (k, q, v), go)
+    kr, qr, vr = (t.detach().float().requires_grad_(True) for t in (k, q, v))
+    sr = torch.bmm(kr, qr.transpose(1, 2))
+    outr = torch.bmm(torch.softmax(sr, dim=-1), vr)
+    dkr, dqr, dvr = torch.autograd.grad(outr, (kr, qr, vr), go.float())
+    assert rel(lse, torch.logsumexp(sr, dim=-1)) < 1e-5
+    assert rel(out.float(), outr) < 6e-3
+    assert rel(dv.float(), dvr) < 6e-3
+    assert rel(dk.float(), dkr) < 1.5e-2
+    assert rel(dq.float(), dqr) < 1.5e-2
+
+
 def test_graphed_step_matches_eager_steps(gan):
     """gan_amd.GraphedStep on a full Pix2Pix step (both phases, both fused-Adam updates; U-Net and PatchGAN at width 8):
     three replays with fresh inputs copied into the static tensors must give the losses of three eager steps."""
