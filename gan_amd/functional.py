@@ -87,3 +87,18 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
 
 def blur3x3(input):
     return ops.blur3x3(input)
+
+
+def avg_pool2x2(input):
+    """torch.nn.functional.avg_pool2d(input, 2) for even extents; channel counts that are not a multiple of 8 (images)
+    take the torch operator."""
+    if input.shape[1] % 8 or input.shape[2] % 2 or input.shape[3] % 2:
+        return torch.nn.functional.avg_pool2d(input, 2)
+    return ops.pool2x2(input, 0.25)
+
+
+def upsample_nearest2x(input):
+    """torch.nn.functional.interpolate(input, scale_factor=2, mode="nearest")."""
+    if input.shape[1] % 8:
+        return torch.nn.functional.interpolate(input, scale_factor=2, mode="nearest")
+    return ops.replicate2x(input, 1.0)

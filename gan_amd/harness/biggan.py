@@ -137,7 +137,7 @@ class GeneratorBlock(torch.nn.Module):
         self.conv_2 = Conv2d(output_channels, output_channels, kernel_size=kernel_size, stride=stride, padding=padding)
         self.relu_1 = torch.nn.ReLU()
         self.relu_2 = torch.nn.ReLU()
-        self.upsample = torch.nn.Upsample(scale_factor=2, mode="nearest")
+        self.upsample = gnn.UpsampleNearest2x()
         self.batch_norm_1 = BatchNorm(input_channels, y_dim=y_dim)
         self.batch_norm_2 = BatchNorm(output_channels, y_dim=y_dim)
         self.residual_conv = Conv2d(input_channels, output_channels, kernel_size=1, stride=1, padding=0)
@@ -183,12 +183,13 @@ class DiscriminatorBlock(torch.nn.Module):
         self.conv_2 = Conv2d(output_channels, output_channels, kernel_size=kernel_size, stride=stride, padding=padding)
         self.relu_1 = torch.nn.ReLU()
         self.relu_2 = torch.nn.ReLU()
-        self.downsample = torch.nn.AvgPool2d(2) if downsample else torch.nn.Identity()
+        self.downsample = gnn.AvgPool2x2() if downsample else torch.nn.Identity()
         self.residual_conv = Conv2d(input_channels, output_channels, kernel_size=1, stride=1)
 
     def forward(self, x):
         output = self.downsample(self.conv_2(self.conv_1(self.relu_1(x), activation="relu")))    # relu_2 in conv_1's epilogue
-        return output + self.downsample(self.residual_conv(x))
+        return output + self.residual_conv(self.downsample(x))     # = downsample(residual_conv(x)): both are linear, the
+        #                                                            1x1 convolution then runs on a quarter of the pixels
 
 
 class Discriminator(torch.nn.Module):

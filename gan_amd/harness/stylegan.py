@@ -183,7 +183,7 @@ class SynthesisNetworkBlock(torch.nn.Module):
                     FusedUpsample(input_channels, output_channels, kernel_size=3, padding=1), BlurLayer(output_channels))
             else:
                 self.convolution_1 = torch.nn.Sequential(
-                    torch.nn.Upsample(scale_factor=2, mode="nearest"),
+                    gnn.UpsampleNearest2x(),
                     EqualizedConv2d(input_channels, output_channels, kernel_size=kernel_size, padding=padding),
                     BlurLayer(output_channels))
             self.convolution_2 = EqualizedConv2d(output_channels, output_channels, kernel_size=kernel_size, padding=padding)
@@ -282,7 +282,7 @@ class DownsampleBlock(torch.nn.Module):
                 self.convolution_2 = torch.nn.Sequential(
                     BlurLayer(output_channels),
                     EqualizedConv2d(output_channels, output_channels, kernel_size=kernel_size_2, padding=padding_2),
-                    torch.nn.AvgPool2d(2))
+                    gnn.AvgPool2x2())
         else:
             self.convolution_2 = EqualizedConv2d(output_channels, output_channels, kernel_size=kernel_size_2, padding=padding_2)
         self.activation_2 = torch.nn.LeakyReLU(0.2)

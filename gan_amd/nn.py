@@ -85,6 +85,21 @@ class BlurLayer(torch.nn.Module):
         return F.blur3x3(input)
 
 
+class AvgPool2x2(torch.nn.Module):
+    """torch.nn.AvgPool2d(2) on the NHWC pooling kernel (reference BigGAN/model.py:188, StyleGAN/model.py:440)."""
+
+    def forward(self, input):
+        return F.avg_pool2x2(input)
+
+
+class UpsampleNearest2x(torch.nn.Module):
+    """torch.nn.Upsample(scale_factor=2, mode="nearest") on the NHWC replication kernel (reference BigGAN/model.py:117,
+    StyleGAN/model.py:247)."""
+
+    def forward(self, input):
+        return F.upsample_nearest2x(input)
+
+
 class InstanceNormAct2d(torch.nn.Module):
     """InstanceNorm2d(affine=False, track_running_stats=False) followed by LeakyReLU(negative_slope), or by nothing
     when negative_slope is None, as ONE kernel with hand-written backward and double-backward kernels.  Holds no

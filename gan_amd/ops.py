@@ -722,3 +722,49 @@ def _attn_backward(ctx, g_out, g_lse):
 
 
 torch.library.register_autograd("ganconv::attention", _attn_backward, setup_context=_attn_setup)
+
+
+# ---- 2x2 pooling / 2x nearest replication (an adjoint pair; each is the other's backward) -------------------------
+def _resample(fn_name, x, scale, H, W, shape):
+    _check_cuda(x)
+    x = _nhwc(x)
+    N, C = x.shape[0], x.shape[1]
+    y = torch.empty(shape, dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    _lib.check(getattr(_lib.lib(), fn_name)(_ptr(x), _ptr(y), N, H, W, C, _dtype_code(x), scale, _stream()), fn_name)
+    return y
+
+
+@torch.library.custom_op("ganconv::pool2x2", mutates_args=())
+def pool2x2(x: Tensor, scale: float) -> Tensor:
+    """scale * (sum over 2x2 blocks); H and W even, C a multiple of 8.  scale 0.25: AvgPool2d(2)."""
+    N, C, H, W = x.shape
+    if H % 2 or W % 2:
+        raise RuntimeError("ganconv: pool2x2 needs even extents")
+    return _resample("gc_pool2x2", x, scale, H // 2, W // 2, (N, C, H // 2, W // 2))
+
+
+@pool2x2.register_fake
+def _(x, scale):
+    N, C, H, W = x.shape
+    return x.new_empty(N, C, H // 2, W // 2)
+
+
+@torch.library.custom_op("ganconv::replicate2x", mutates_args=())
+def replicate2x(x: Tensor, scale: float) -> Tensor:
+    """scale * (every pixel repeated 2x2); C a multiple of 8.  scale 1: nearest Upsample(scale_factor=2)."""
+    N, C, H, W = x.shape
+    return _resample("gc_replicate2x", x, scale, H, W, (N, C, 2 * H, 2 * W))
+
+
+@replicate2x.register_fake
+def _(x, scale):
+    N, C, H, W = x.shape
+    return x.new_empty(N, C, 2 * H, 2 * W)
+
+
+def _scale_ctx(ctx, inputs, output):
+    ctx.scale = inputs[1]
+
+
+torch.library.register_autograd("ganconv::pool2x2", lambda ctx, g: (replicate2x(g, ctx.scale), None), setup_context=_scale_ctx)
+torch.library.register_autograd("ganconv::replicate2x", lambda ctx, g: (pool2x2(g, ctx.scale), None), setup_context=_scale_ctx)

@@ -186,6 +186,15 @@ int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t
 int gc_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const int64_t* numel, float* step, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* 2x2 sum-pooling and 2x nearest replication, NHWC, fp32 or bf16 (`dtype`), C a multiple of 8, 16-byte aligned:
+ *   gc_pool2x2     : y[n,h,w,c] = scale * (x[n,2h,2w,c] + x[n,2h,2w+1,c] + x[n,2h+1,2w,c] + x[n,2h+1,2w+1,c]),  x is [N,2Ho,2Wo,C]
+ *   gc_replicate2x : y[n,2h+a,2w+b,c] = scale * x[n,h,w,c] (a, b in {0,1}),  x is [N,H,W,C], y [N,2H,2W,C]
+ * The two are adjoint: AvgPool2d(2) is pool with scale 1/4 and its gradient replicate with 1/4; nearest
+ * Upsample(scale_factor=2) is replicate with 1 and its gradient pool with 1.  Replace aten::avg_pool2d(_backward) and
+ * aten::upsample_nearest2d(_backward) at BigGAN/model.py:117,188 and StyleGAN/model.py:247,440. */
+int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream);
+int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream);
+
 /* Self-attention over image positions without the [N, N] weight matrix in memory: out = softmax(k q^T) v per sample,
  * softmax over the last index, unit scale.  Replaces the bmm + Softmax + bmm of SelfAttentionBlock.forward
  * (BigGAN/model.py:97-103; the reference calls the [B, N, C / 8] operand of the first bmm "key" and the other

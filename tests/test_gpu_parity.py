@@ -703,6 +703,25 @@ def test_attention_against_unfused_product(gan, B, N, d, C):
     assert rel(dq.float(), dqr) < 1.5e-2
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 16, 8, 12), (2, 64, 34, 6), (1, 8, 2, 2)])
+def test_pool_and_replicate_against_torch(gan, shape, dt):
+    """AvgPool2d(2) and nearest 2x upsampling kernels, forward and gradient, against the torch operators."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g).cuda().to(dt).requires_grad_(True)
+    tol = 1e-6 if dt == torch.float32 else 4e-3
+    for fn, ref in ((gan.functional.avg_pool2x2, lambda t: torch.nn.functional.avg_pool2d(t, 2)),
+                    (gan.functional.upsample_nearest2x, lambda t: torch.nn.functional.interpolate(t, scale_factor=2, mode="nearest"))):
+        y = fn(x)
+        xr = x.detach().float().requires_grad_(True)
+        yr = ref(xr)
+        assert y.shape == yr.shape and y.dtype == dt
+        gy = torch.randn(*y.shape, generator=g).cuda().to(dt)
+        gx, = torch.autograd.grad(y, x, gy)
+        gxr, = torch.autograd.grad(yr, xr, gy.float())
+        assert rel(y.float(), yr) < tol and rel(gx.float(), gxr) < tol
+
+
 def test_graphed_step_matches_eager_steps(gan):
     """gan_amd.GraphedStep on a full Pix2Pix step (both phases, both fused-Adam updates; U-Net and PatchGAN at width 8):
     three replays with fresh inputs copied into the static tensors must give the losses of three eager steps."""
