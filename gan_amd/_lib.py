@@ -21,6 +21,7 @@ EXPORTS = (
     "gc_wgrad_workspace_bytes", "gc_conv2d_wgrad", "gc_dwblur3x3", "gc_profile_enable", "gc_profile_collect",
     "gc_instnorm_act_fwd", "gc_instnorm_act_bwd", "gc_instnorm_act_bwd_bwd",
     "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_adam_step", "gc_set_split_reduction", "gc_attention_fwd", "gc_attention_bwd", "gc_pool2x2", "gc_replicate2x",
+    "gc_cond_batchnorm_workspace_bytes", "gc_cond_batchnorm_act_fwd", "gc_cond_batchnorm_act_bwd",
 )
 
 
@@ -72,6 +73,10 @@ def lib():
     L.gc_batchnorm_workspace_bytes.restype = sz
     L.gc_batchnorm_workspace_bytes.argtypes = [i64, i32]
     L.gc_batchnorm_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, f32, f32, i32, f32, i32, vp]
+    L.gc_cond_batchnorm_workspace_bytes.restype = sz
+    L.gc_cond_batchnorm_workspace_bytes.argtypes = [i32, i32, i32]
+    L.gc_cond_batchnorm_act_fwd.argtypes = [vp] * 11 + [sz, i32, i32, i32, i32, f32, f32, i32, f32, i32, vp]
+    L.gc_cond_batchnorm_act_bwd.argtypes = [vp] * 10 + [sz, i32, i32, i32, i32, i32, f32, vp]
     L.gc_batchnorm_update_running.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp]
     L.gc_batchnorm_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, i32, f32, vp]
     L.gc_adam_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp]

@@ -13,6 +13,11 @@
 //   2. finalize: one workgroup per 64 channels merges the slabs in a fixed order (Chan's parallel-variance update
 //      in the forward pass), derives a / b (or the two backward means) and updates the running statistics;
 //   3. apply: same geometry as 1, elementwise, optionally writing a bf16 copy for the convolution that reads it next.
+//
+// Conditional mode (reference BigGAN/model.py:61-77: gamma[n, c] * BatchNorm(x) + beta[n, c] with per-sample gain and
+// bias from a Linear layer): gamma / beta are [N, C]; slabs never cross a sample, so a slab has one gain per channel.
+// Backward: with g = gy * act', ggamma[n, c] = sum_hw g * xh and gbeta[n, c] = sum_hw g per sample, and
+//   gx = r * (gamma[n, c] * g - A / P - xh * B / P),  A = sum_n gamma[n, c] * gbeta[n, c],  B = sum_n gamma[n, c] * ggamma[n, c].
 #include "common.h"
 
 namespace gc {
@@ -37,7 +42,23 @@ struct BnParams {          // x / gy / out are fp32 or bf16 (template parameter)
   int32_t P, C, slabs, slab_pix;
   float eps, momentum, slope;
   int32_t act, training;
+  const float* cgamma;   // conditional mode: [N][C] gain and bias (gamma / beta above are then null)
+  const float* cbeta;
+  int32_t HW, sps, nsamp;   // pixels per sample, slabs per sample (0 = unconditional), samples
 };
+
+// pixel range [p0, p1) of a slab; in conditional mode also its sample
+__device__ __forceinline__ void slab_range(const BnParams& p, int slab, int& p0, int& p1, int& n) {
+  if (p.sps > 0) {
+    n = slab / p.sps;
+    p0 = n * p.HW + (slab - n * p.sps) * p.slab_pix;
+    p1 = min((n + 1) * p.HW, p0 + p.slab_pix);
+  } else {
+    n = 0;
+    p0 = slab * p.slab_pix;
+    p1 = min(p.P, p0 + p.slab_pix);
+  }
+}
 
 constexpr int kQB = 16, kPL = 16;   // channel quads x pixel lanes of a workgroup
 
@@ -71,7 +92,8 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(const BnParams p) 
   const int slab = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const int c = (chunk * kQB + tq) * 4;
   const bool cok = c < p.C;
-  const int p0 = slab * p.slab_pix, p1 = min(p.P, p0 + p.slab_pix);
+  int p0, p1, n;
+  slab_range(p, slab, p0, p1, n);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   auto ld = [&](const void* ptr, int pix) -> f32x4 { return load4<T>(ptr, (size_t)pix * p.C + c); };
   if (MODE == 0) {
@@ -97,6 +119,10 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(const BnParams p) 
       f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = zero;
       if (p.gamma != nullptr) ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
       if (p.beta != nullptr) be = *reinterpret_cast<const f32x4*>(p.beta + c);
+      if (p.sps > 0) {
+        ga = *reinterpret_cast<const f32x4*>(p.cgamma + (size_t)n * p.C + c);
+        be = *reinterpret_cast<const f32x4*>(p.cbeta + (size_t)n * p.C + c);
+      }
       for (int pix = p0 + tl; pix < p1; pix += kPL) {
         const f32x4 xh = (ld(p.x, pix) - mu) * r;
         const f32x4 g = ld(p.gy, pix) * act_mask(ga * xh + be, p.act, p.slope);
@@ -123,11 +149,28 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
   const int c = blockIdx.x * kFinCh + tc;
   const bool cok = c < p.C;
   float n = 0.f, a = 0.f, b = 0.f;   // forward: count, mean, M2;  backward: -, sum g, sum g*xh
-  if (cok)
+  if (MODE == 1 && p.sps > 0) {      // conditional: per-sample sums are outputs, their gain-weighted totals feed gx
+    if (cok)
+      for (int smp = lane; smp < p.nsamp; smp += kFinLanes) {
+        float sg = 0.f, sgx = 0.f;
+        for (int s = 0; s < p.sps; s++) {
+          const float2 v = *reinterpret_cast<const float2*>(p.part + ((size_t)(smp * p.sps + s) * p.C + c) * 2);
+          sg += v.x;
+          sgx += v.y;
+        }
+        p.gbeta[(size_t)smp * p.C + c] = sg;
+        p.ggamma[(size_t)smp * p.C + c] = sgx;
+        const float ga = p.cgamma[(size_t)smp * p.C + c];
+        a += ga * sg;
+        b += ga * sgx;
+      }
+  } else if (cok)
     for (int s = lane; s < p.slabs; s += kFinLanes) {
       const float2 v = *reinterpret_cast<const float2*>(p.part + ((size_t)s * p.C + c) * 2);
       if (MODE == 0) {
-        const float nb = (float)(min(p.P, (s + 1) * p.slab_pix) - s * p.slab_pix);
+        int q0, q1, smp;
+        slab_range(p, s, q0, q1, smp);
+        const float nb = (float)(q1 - q0);
         const float tot = n + nb, delta = v.x - a;
         a += delta * (nb / tot);
         b += v.y + delta * delta * (n * nb / tot);
@@ -170,8 +213,10 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
     }
     if (p.num_batches != nullptr && c == 0) p.num_batches[0] += 1;
   } else {
-    p.gbeta[c] = a;
-    p.ggamma[c] = b;
+    if (p.sps == 0) {
+      p.gbeta[c] = a;
+      p.ggamma[c] = b;
+    }
     p.coef[c] = a / (float)p.P;
     p.coef[p.C + c] = b / (float)p.P;
   }
@@ -206,7 +251,8 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
   const int slab = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const int c = (chunk * kQB + tq) * 4;
   if (c >= p.C) return;
-  const int p0 = slab * p.slab_pix, p1 = min(p.P, p0 + p.slab_pix);
+  int p0, p1, n;
+  slab_range(p, slab, p0, p1, n);
   const f32x4 k0 = *reinterpret_cast<const f32x4*>(p.coef + c), k1 = *reinterpret_cast<const f32x4*>(p.coef + p.C + c);
   f32x4 mu = {0.f, 0.f, 0.f, 0.f}, r = mu, ga = {1.f, 1.f, 1.f, 1.f}, be = mu;
   if (MODE == 1) {
@@ -215,18 +261,24 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
     if (p.gamma != nullptr) ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
     if (p.beta != nullptr) be = *reinterpret_cast<const f32x4*>(p.beta + c);
   }
+  const bool cond = p.sps > 0;
+  if (cond) {
+    ga = *reinterpret_cast<const f32x4*>(p.cgamma + (size_t)n * p.C + c);
+    be = *reinterpret_cast<const f32x4*>(p.cbeta + (size_t)n * p.C + c);
+  }
   for (int pix = p0 + tl; pix < p1; pix += kPL) {
     const size_t o = (size_t)pix * p.C + c;
     const f32x4 xv = load4<T>(p.x, o);
     f32x4 res;
     if (MODE == 0) {
-      const f32x4 pre = k0 * xv + k1;
+      f32x4 pre = k0 * xv + k1;
+      if (cond) pre = ga * pre + be;      // k0, k1 normalise only in conditional mode
       const f32x4 m = act_mask(pre, p.act, p.slope);
       res = pre * m;
     } else {
       const f32x4 xh = (xv - mu) * r;
       const f32x4 g = load4<T>(p.gy, o) * act_mask(ga * xh + be, p.act, p.slope);
-      res = ga * r * (g - k0 - xh * k1);
+      res = cond ? r * (ga * g - k0 - xh * k1) : ga * r * (g - k0 - xh * k1);
     }
     store4<T>(p.out, o, res);
     if (p.out_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out_bf16 + o) = cvt_bf16x4(res);
@@ -234,6 +286,15 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
 }
 
 static void bn_geometry(BnParams& p) {
+  if (p.nsamp > 0) {   // conditional: slabs inside samples, about 2048 in all, at least 256 pixels each
+    long sps = 2048 / p.nsamp;
+    if (sps > p.HW / 256) sps = p.HW / 256;
+    if (sps < 1) sps = 1;
+    p.slab_pix = (int)((p.HW + sps - 1) / sps);
+    p.sps = (p.HW + p.slab_pix - 1) / p.slab_pix;
+    p.slabs = p.nsamp * p.sps;
+    return;
+  }
   const int chunks = (p.C / 4 + kQB - 1) / kQB;
   long slabs = (p.P + 255) / 256;              // at least 256 pixels per slab
   const long cap = chunks >= 4 ? 128 : 512 / chunks;
@@ -251,18 +312,25 @@ using namespace gc;
 
 extern "C" {
 
-size_t gc_batchnorm_workspace_bytes(int64_t P, int32_t C) {
+static size_t bn_workspace(int64_t P, int32_t C, int32_t nsamp) {
   if (P <= 0 || C <= 0 || P >= (1ll << 31)) return 0;
   BnParams p{};
-  p.P = (int32_t)P; p.C = C;
+  p.P = (int32_t)P; p.C = C; p.nsamp = nsamp; p.HW = nsamp > 0 ? (int32_t)(P / nsamp) : 0;
   bn_geometry(p);
   return ((size_t)p.slabs * C * 2 + 2 * (size_t)C) * sizeof(float);
 }
 
-int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
-                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, float eps, float momentum,
-                         int32_t act, float slope, int32_t training, void* stream) {
+size_t gc_batchnorm_workspace_bytes(int64_t P, int32_t C) { return bn_workspace(P, C, 0); }
+
+size_t gc_cond_batchnorm_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+  if (N <= 0 || HW <= 0) return 0;
+  return bn_workspace((int64_t)N * HW, C, N);
+}
+
+static int bn_forward(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                      void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, float eps, float momentum,
+                      int32_t act, float slope, int32_t training, void* stream, int32_t nsamp) {
   if (dtype != GC_F32 && dtype != GC_BF16) { set_error("batchnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
   if (dtype == GC_BF16 && y_bf16 != nullptr) { set_error("batchnorm: bf16 tensors need no bf16 copy"); return GC_BAD_ARGUMENT; }
   if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
@@ -277,10 +345,13 @@ int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamm
       misaligned(beta, 15) || misaligned(save_mean, 15) || misaligned(save_rstd, 15)) {
     set_error("batchnorm: misaligned pointer"); return GC_BAD_ARGUMENT;
   }
-  const size_t need = gc_batchnorm_workspace_bytes(P, C);
+  if (nsamp > 0 && (gamma == nullptr || beta == nullptr)) { set_error("batchnorm: conditional mode needs gain and bias"); return GC_BAD_ARGUMENT; }
+  const size_t need = bn_workspace(P, C, nsamp);
   if (workspace_bytes < need) { set_error("batchnorm: workspace of %zu bytes given, %zu needed", workspace_bytes, need); return GC_WORKSPACE_TOO_SMALL; }
   BnParams p{};
-  p.x = x; p.out = y; p.out_bf16 = (uint16_t*)y_bf16; p.gamma = gamma; p.beta = beta;
+  p.x = x; p.out = y; p.out_bf16 = (uint16_t*)y_bf16;
+  if (nsamp > 0) { p.cgamma = gamma; p.cbeta = beta; p.nsamp = nsamp; p.HW = (int32_t)(P / nsamp); }
+  else { p.gamma = gamma; p.beta = beta; }
   p.running_mean = running_mean; p.running_var = running_var; p.num_batches = num_batches_tracked;
   p.save_mean = save_mean; p.save_rstd = save_rstd; p.save_var = save_var;
   p.P = (int32_t)P; p.C = C; p.eps = eps; p.momentum = momentum; p.slope = slope; p.act = act; p.training = training;
@@ -309,9 +380,26 @@ int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamm
   return check_hip(hipGetLastError(), "batchnorm forward launch");
 }
 
-int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
-                         const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
-                         size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream) {
+int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                         void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, float eps, float momentum,
+                         int32_t act, float slope, int32_t training, void* stream) {
+  return bn_forward(x, y, y_bf16, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, save_var, workspace,
+                    workspace_bytes, P, C, dtype, eps, momentum, act, slope, training, stream, 0);
+}
+
+int gc_cond_batchnorm_act_fwd(const void* x, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var, void* workspace,
+                              size_t workspace_bytes, int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, float momentum,
+                              int32_t act, float slope, int32_t training, void* stream) {
+  if (N <= 0 || HW <= 0) { set_error("batchnorm: conditional mode needs N > 0 and HW > 0"); return GC_BAD_ARGUMENT; }
+  return bn_forward(x, y, nullptr, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, save_var, workspace,
+                    workspace_bytes, (int64_t)N * HW, C, dtype, eps, momentum, act, slope, training, stream, N);
+}
+
+static int bn_backward(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
+                       size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream, int32_t nsamp) {
   if (dtype != GC_F32 && dtype != GC_BF16) { set_error("batchnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
   if (dtype == GC_BF16 && gx_bf16 != nullptr) { set_error("batchnorm: bf16 tensors need no bf16 copy"); return GC_BAD_ARGUMENT; }
   if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
@@ -329,10 +417,13 @@ int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, cons
     if (zero_fill(ggamma, sizeof(float) * C, s) != GC_OK) return GC_HIP_ERROR;
     return zero_fill(gbeta, sizeof(float) * C, s);
   }
-  const size_t need = gc_batchnorm_workspace_bytes(P, C);
+  if (nsamp > 0 && (gamma == nullptr || beta == nullptr)) { set_error("batchnorm: conditional mode needs gain and bias"); return GC_BAD_ARGUMENT; }
+  const size_t need = bn_workspace(P, C, nsamp);
   if (workspace_bytes < need) { set_error("batchnorm: workspace of %zu bytes given, %zu needed", workspace_bytes, need); return GC_WORKSPACE_TOO_SMALL; }
   BnParams p{};
-  p.x = x; p.gy = gy; p.out = gx; p.out_bf16 = (uint16_t*)gx_bf16; p.gamma = gamma; p.beta = beta;
+  p.x = x; p.gy = gy; p.out = gx; p.out_bf16 = (uint16_t*)gx_bf16;
+  if (nsamp > 0) { p.cgamma = gamma; p.cbeta = beta; p.nsamp = nsamp; p.HW = (int32_t)(P / nsamp); }
+  else { p.gamma = gamma; p.beta = beta; }
   p.save_mean = const_cast<float*>(save_mean); p.save_rstd = const_cast<float*>(save_rstd);
   p.ggamma = ggamma; p.gbeta = gbeta;
   p.P = (int32_t)P; p.C = C; p.slope = slope; p.act = act;
@@ -353,6 +444,21 @@ int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, cons
     else hipLaunchKernelGGL((bn_apply_kernel<1, uint16_t>), grid, block, 0, s, p);
   }
   return check_hip(hipGetLastError(), "batchnorm backward launch");
+}
+
+int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
+                         size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream) {
+  return bn_backward(x, gy, gamma, beta, save_mean, save_rstd, gx, gx_bf16, ggamma, gbeta, workspace, workspace_bytes, P, C, dtype, act,
+                     slope, stream, 0);
+}
+
+int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                              const float* save_rstd, void* gx, float* ggamma, float* gbeta, void* workspace, size_t workspace_bytes,
+                              int32_t N, int32_t HW, int32_t C, int32_t dtype, int32_t act, float slope, void* stream) {
+  if (N <= 0 || HW <= 0) { set_error("batchnorm: conditional mode needs N > 0 and HW > 0"); return GC_BAD_ARGUMENT; }
+  return bn_backward(x, gy, gamma, beta, save_mean, save_rstd, gx, nullptr, ggamma, gbeta, workspace, workspace_bytes, (int64_t)N * HW, C,
+                     dtype, act, slope, stream, N);
 }
 
 int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,

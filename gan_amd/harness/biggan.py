@@ -8,8 +8,9 @@ BigGAN/train.py:108-127,187-226 (orthogonal init / regularisation, step order).
 
 Every Conv2d (3x3, 1x1, incl. the attention projections) runs on the gan_amd kernels through
 gan_amd.functional.conv2d with the spectrally normalised weight W / sigma, as the reference calls F.conv2d.  The
-power iteration, the SN Linear layers, conditional-BN statistics, the attention product, embeddings, pooling and
-nearest upsampling stay on stock torch ops.  Reference quirks kept: sigma is not differentiated; the conditional
+conditional BatchNorm + ReLU runs on the fused normalisation kernels, pooling / nearest upsampling on the resampling
+kernels; the power iteration, the SN Linear layers, the attention product (unless switched to the fused kernel, below)
+and the embeddings stay on stock torch ops.  Reference quirks kept: sigma is not differentiated; the conditional
 BN gain has no +1; the projection term broadcasts `output` ([B,1]) against the class embedding.
 
 Two storage / arithmetic options, both off by default (set_activation_dtype, set_fused_attention):
@@ -42,6 +43,26 @@ def set_fused_attention(on):
 
 def _like(t, ref):
     return t if t.dtype == ref.dtype else t.to(ref.dtype)
+
+
+_fused_norm = True
+
+
+def set_fused_norm(on):
+    """Training-mode (conditional) BatchNorm + ReLU on the fused normalisation kernels (default) or on torch ops."""
+    global _fused_norm
+    _fused_norm = bool(on)
+
+
+def _fused_bn(bn, x, weight, bias, activation):
+    """bn: a torch.nn.BatchNorm2d in training mode (its running statistics are updated as torch does); weight / bias:
+    its own [C] parameters or per-sample [N, C] gains and biases."""
+    y, mean, _, var = ops.batchnorm_act(x, weight, bias, bn.running_mean, bn.running_var, True, float(bn.eps),
+                                        1 if activation == "relu" else 0, 0.0)
+    if bn.track_running_stats:
+        with torch.no_grad():
+            ops.batchnorm_update_running_(bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, var, float(bn.momentum))
+    return y
 
 
 class SpectralNorm(object):
@@ -94,9 +115,16 @@ class BatchNorm(torch.nn.Module):
         self.batch_norm = torch.nn.BatchNorm2d(channels, affine=False)
         self.linear = Linear(y_dim, channels * 2)
 
-    def forward(self, x, y):
-        gamma, beta = _like(self.linear(y), x).chunk(2, dim=1)
-        return gamma.unsqueeze(2).unsqueeze(2) * self.batch_norm(x) + beta.unsqueeze(2).unsqueeze(2)
+    def forward(self, x, y, activation=None):
+        """gamma(y) * BatchNorm(x) + beta(y), then the optional ReLU, as one fused normalisation (statistics, finalize,
+        apply) in training mode; the unfused torch composition otherwise."""
+        gamma, beta = self.linear(y).chunk(2, dim=1)
+        bn = self.batch_norm
+        if _fused_norm and bn.training and x.shape[1] % 4 == 0:
+            return _fused_bn(bn, x, gamma, beta, activation)
+        gamma, beta = _like(gamma, x), _like(beta, x)
+        out = gamma.unsqueeze(2).unsqueeze(2) * bn(x) + beta.unsqueeze(2).unsqueeze(2)
+        return torch.relu(out) if activation == "relu" else out
 
 
 class SelfAttentionBlock(torch.nn.Module):
@@ -143,8 +171,8 @@ class GeneratorBlock(torch.nn.Module):
         self.residual_conv = Conv2d(input_channels, output_channels, kernel_size=1, stride=1, padding=0)
 
     def forward(self, x, y):
-        output = self.conv_1(self.upsample(self.relu_1(self.batch_norm_1(x, y))))
-        output = self.conv_2(self.relu_2(self.batch_norm_2(output, y)))
+        output = self.conv_1(self.upsample(self.batch_norm_1(x, y, activation="relu")))     # relu_1 / relu_2 inside the norm
+        output = self.conv_2(self.batch_norm_2(output, y, activation="relu"))
         return output + self.residual_conv(self.upsample(x))
 
 
@@ -173,7 +201,11 @@ class Generator(torch.nn.Module):
                 index += 1
             else:
                 output = layer(output)
-        return self.tanh(self.to_RGB_layer(torch.nn.functional.relu(self.bn(output)), out_dtype=torch.float32))
+        if _fused_norm and self.bn.training and output.shape[1] % 4 == 0:
+            output = _fused_bn(self.bn, output, self.bn.weight, self.bn.bias, "relu")
+        else:
+            output = torch.nn.functional.relu(self.bn(output))
+        return self.tanh(self.to_RGB_layer(output, out_dtype=torch.float32))
 
 
 class DiscriminatorBlock(torch.nn.Module):

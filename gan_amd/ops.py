@@ -578,6 +578,12 @@ torch.library.register_autograd("ganconv::instnorm_act_bwd", _in_bwd_backward, s
 
 
 # ---- BatchNorm (+ ReLU / LeakyReLU), first-order backward --------------------------------------------------------
+def _cond_affine(weight, bias, N, C):
+    if bias is None or tuple(weight.shape) != (N, C) or tuple(bias.shape) != (N, C):
+        raise RuntimeError(f"ganconv: conditional batchnorm takes gain and bias of shape [N, C] = [{N}, {C}]")
+    return weight.float().contiguous(), bias.float().contiguous()
+
+
 @torch.library.custom_op("ganconv::batchnorm_act", mutates_args=())
 def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
                   running_var: Optional[Tensor], training: bool, eps: float, act: int, slope: float) -> tuple[Tensor, Tensor, Tensor, Tensor]:
@@ -592,8 +598,15 @@ def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], r
     y = torch.empty_like(x, memory_format=torch.channels_last)
     mean, rstd, var = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(3))
     L = _lib.lib()
-    ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
     rm, rv = (None, None) if training else (running_mean, running_var)
+    if weight is not None and weight.dim() == 2:     # conditional: gain and bias per sample and channel
+        weight, bias = _cond_affine(weight, bias, N, C)
+        ws = torch.empty(max(L.gc_cond_batchnorm_workspace_bytes(N, H * W, C), 16), dtype=torch.uint8, device=x.device)
+        _lib.check(L.gc_cond_batchnorm_act_fwd(_ptr(x), _ptr(y), _ptr(weight), _ptr(bias), _optr(rm), _optr(rv), None, _ptr(mean),
+                                               _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), N, H * W, C, dt, eps, 0.0, act, slope,
+                                               1 if training else 0, _stream()), "gc_cond_batchnorm_act_fwd")
+        return y, mean, rstd, var
+    ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
     _lib.check(L.gc_batchnorm_act_fwd(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _optr(rm), _optr(rv), None,
                                       _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), P, C, dt, eps, 0.0, act, slope,
                                       1 if training else 0, _stream()), "gc_batchnorm_act_fwd")
@@ -628,9 +641,17 @@ def batchnorm_act_bwd(x: Tensor, gy: Tensor, weight: Optional[Tensor], bias: Opt
     P = N * H * W
     dt = _dtype_code(x)
     gx = torch.empty_like(x, memory_format=torch.channels_last)
+    L = _lib.lib()
+    if weight is not None and weight.dim() == 2:
+        weight, bias = _cond_affine(weight, bias, N, C)
+        gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+        ws = torch.empty(max(L.gc_cond_batchnorm_workspace_bytes(N, H * W, C), 16), dtype=torch.uint8, device=x.device)
+        _lib.check(L.gc_cond_batchnorm_act_bwd(_ptr(x), _ptr(gy), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(gw),
+                                               _ptr(gb), _ptr(ws), ws.numel(), N, H * W, C, dt, act, slope, _stream()),
+                   "gc_cond_batchnorm_act_bwd")
+        return gx, gw, gb
     gw = torch.empty(C, dtype=torch.float32, device=x.device)
     gb = torch.empty(C, dtype=torch.float32, device=x.device)
-    L = _lib.lib()
     ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
     _lib.check(L.gc_batchnorm_act_bwd(_ptr(x), _ptr(gy), _optr(weight), _optr(bias), _ptr(mean), _ptr(rstd), _ptr(gx),
                                       _optr(_bf16_twin(gx)), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), P, C, dt, act, slope, _stream()),
@@ -640,8 +661,8 @@ def batchnorm_act_bwd(x: Tensor, gy: Tensor, weight: Optional[Tensor], bias: Opt
 
 @batchnorm_act_bwd.register_fake
 def _(x, gy, weight, bias, mean, rstd, act, slope):
-    C = x.shape[1]
-    return torch.empty_like(x), x.new_empty(C, dtype=torch.float32), x.new_empty(C, dtype=torch.float32)
+    shape = (x.shape[0], x.shape[1]) if weight is not None and weight.dim() == 2 else (x.shape[1],)
+    return torch.empty_like(x), x.new_empty(shape, dtype=torch.float32), x.new_empty(shape, dtype=torch.float32)
 
 
 def _bn_setup(ctx, inputs, output):
@@ -729,7 +750,7 @@ def _resample(fn_name, x, scale, H, W, shape):
     _check_cuda(x)
     x = _nhwc(x)
     N, C = x.shape[0], x.shape[1]
-    y = torch.empty(shape, dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    y = torch.empty(shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     _lib.check(getattr(_lib.lib(), fn_name)(_ptr(x), _ptr(y), N, H, W, C, _dtype_code(x), scale, _stream()), fn_name)
     return y
 

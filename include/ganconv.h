@@ -175,6 +175,20 @@ int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, cons
                          const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
                          size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
 
+/* Conditional BatchNorm fused with an optional ReLU / LeakyReLU: y = act(gamma[n,c] * xh + beta[n,c]) with xh the
+ * batch-normalised input (statistics over all N * HW pixels as above, no affine parameters of its own) and a gain and
+ * bias per SAMPLE and channel, float [N, C] each.  Replaces BatchNorm.forward of BigGAN/model.py:61-77 (BatchNorm2d
+ * (affine=False), then gamma * . + beta from a Linear layer) together with the ReLU that follows it (:129,133).  The
+ * backward pass returns ggamma / gbeta as [N, C] and gx; everything else as in gc_batchnorm_act_fwd / _bwd. */
+size_t gc_cond_batchnorm_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int gc_cond_batchnorm_act_fwd(const void* x, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var, void* workspace,
+                              size_t workspace_bytes, int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, float momentum,
+                              int32_t act, float slope, int32_t training, void* stream);
+int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                              const float* save_rstd, void* gx, float* ggamma, float* gbeta, void* workspace, size_t workspace_bytes,
+                              int32_t N, int32_t HW, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
+
 int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,
                                 const float* var_unbiased, int32_t C, float momentum, void* stream);
 

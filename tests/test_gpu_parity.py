@@ -704,6 +704,33 @@ def test_attention_against_unfused_product(gan, B, N, d, C):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,act", [((4, 32, 8, 8), 1), ((3, 64, 40, 24), 1), ((2, 8, 32, 32), 0), ((5, 128, 4, 4), 1)])
+def test_conditional_batchnorm_against_torch(gan, shape, act, dt):
+    """gamma[n, c] * BatchNorm2d(affine=False)(x) + beta[n, c], then ReLU (reference BigGAN/model.py:61-77,129): output,
+    the batch statistics and the gradients of x, gamma and beta against the torch composition in fp32."""
+    g = torch.Generator().manual_seed(13)
+    N, C, H, W = shape
+    x = (torch.randn(*shape, generator=g) * 1.5 + 0.3).cuda().to(dt).requires_grad_(True)
+    gamma = (torch.randn(N, C, generator=g) * 0.5 + 1).cuda().requires_grad_(True)
+    beta = (torch.randn(N, C, generator=g) * 0.3).cuda().requires_grad_(True)
+    y, mean, rstd, var = gan.ops.batchnorm_act(x, gamma, beta, None, None, True, 1e-5, act, 0.0)
+    gy = torch.randn(*shape, generator=g).cuda().to(dt)
+    gx, gg, gb = torch.autograd.grad(y, (x, gamma, beta), gy)
+    xr, gr, br = x.detach().float().requires_grad_(True), gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    yr = gr[:, :, None, None] * torch.nn.functional.batch_norm(xr, None, None, training=True, eps=1e-5) + br[:, :, None, None]
+    if act:
+        yr = torch.relu(yr)
+    if dt == torch.bfloat16:     # the gradient mask follows the stored (rounded) output's sign in both implementations
+        yr = yr + (y.float() - yr).detach() * 0
+    gxr, ggr, gbr = torch.autograd.grad(yr, (xr, gr, br), gy.float())
+    tol = 2e-5 if dt == torch.float32 else 8e-3
+    assert y.dtype == dt and rel(y.float(), yr) < tol
+    assert rel(mean, xr.mean(dim=(0, 2, 3))) < 1e-5 and rel(var, xr.var(dim=(0, 2, 3), unbiased=True)) < 1e-4
+    assert rel(gx.float(), gxr) < (2e-4 if dt == torch.float32 else 2e-2)
+    assert rel(gg, ggr) < (1e-4 if dt == torch.float32 else 1e-2) and rel(gb, gbr) < (1e-4 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 16, 8, 12), (2, 64, 34, 6), (1, 8, 2, 2)])
 def test_pool_and_replicate_against_torch(gan, shape, dt):
     """AvgPool2d(2) and nearest 2x upsampling kernels, forward and gradient, against the torch operators."""
