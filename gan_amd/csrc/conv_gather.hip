@@ -393,6 +393,11 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
     long pix = 0;
     for (int c = 0; c < p.tt.n_classes; c++) pix += (long)p.N * p.tt.cls_oh[c] * p.tt.cls_ow[c];
     if ((pix / 256) * p.n_oc_tiles >= 1024) l.tp = 256;
+    // largest problems: 256 x 256 per workgroup (two-deep ring fills the LDS) halves the bytes moved into LDS per FLOP
+    if (l.tp == 256 && p.OC % 256 == 0 && (pix / 256) * (p.OC / 256) >= 512) {
+      l.to = 256;
+      p.n_oc_tiles = p.OC / 256;
+    }
   }
   int tiles = 0, min_steps = 1 << 30;
   for (int c = 0; c < p.tt.n_classes; c++) {

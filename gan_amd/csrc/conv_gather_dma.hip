@@ -295,6 +295,7 @@ static int launch_dma_one(const GatherParams& p, double flops, hipStream_t strea
 
 int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t s) {
   if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
+  if (l.to == 256 && l.tp == 256) return out_f32 ? launch_dma_one<float, 256, 256, 2, 8>(p, l.flops, s) : launch_dma_one<uint16_t, 256, 256, 2, 8>(p, l.flops, s);
   if (l.to == 128 && l.tp == 256) return out_f32 ? launch_dma_one<float, 128, 256, 3, 8>(p, l.flops, s) : launch_dma_one<uint16_t, 128, 256, 3, 8>(p, l.flops, s);
   // At most one workgroup per CU: nothing else hides the load latency, so spend the idle LDS on a deeper ring.
   const bool deep = (long)p.n_pix_tiles * p.n_oc_tiles <= 256;

@@ -319,6 +319,9 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
     } else {
       p.n_ci_tiles = (p.Cin + 127) / 128;
     }
+    // 256 output channels per tile (fewer bytes into LDS per FLOP) where that does not multiply the partial sums:
+    // long reductions, or weights with enough tiles to fill the chip anyway
+    if (p.Cout % 256 == 0 && (p.K >= 65536 || (long)(p.Cout / 256) * p.n_ci_tiles * p.n_tap_groups >= 256)) l.to = 256;
   } else if (p.thin) {
     p.ICp = 4;
     while (p.ICp < p.Cin) p.ICp *= 2;

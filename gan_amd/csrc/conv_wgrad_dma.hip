@@ -24,7 +24,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 template <int ROWB>
 __device__ __forceinline__ int seg_swz(int k) {
-  return ROWB == 256 ? ((k & 3) | (((k >> 3) & 1) << 2)) : (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+  return ROWB >= 256 ? ((k & 3) | (((k >> 3) & 1) << 2)) : (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
 }
 
 template <int N>
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
   constexpr int YJ = kStepPix / RPIY / 4, XJ = kStepPix / RPIX / 4;   // wave-instructions per wave per step
   constexpr int LOADS = YJ + XJ;
   constexpr int FO = TO / 32, FC = kTC / 32;
-  static_assert(FC == 4 && (FO == 4 || FO == 2), "the fragment wait lists its registers explicitly");
+  static_assert(FC == 4 && (FO == 8 || FO == 4 || FO == 2), "the fragment wait lists its registers explicitly");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -157,7 +157,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
       asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[j]) : "v"(sb + xa[j]), "n"(4 * ROWBX) : "memory");
     }
     // the wait names every destination so that no use can be scheduled ahead of it
-    if constexpr (FO == 4)
+    if constexpr (FO == 8)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ylo[0]), "+v"(yhi[0]), "+v"(ylo[1]), "+v"(yhi[1]), "+v"(ylo[2]), "+v"(yhi[2]), "+v"(ylo[3]), "+v"(yhi[3]),
+                     "+v"(ylo[4]), "+v"(yhi[4]), "+v"(ylo[5]), "+v"(yhi[5]), "+v"(ylo[6]), "+v"(yhi[6]), "+v"(ylo[7]), "+v"(yhi[7]),
+                     "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1]), "+v"(xlo[2]), "+v"(xhi[2]), "+v"(xlo[3]), "+v"(xhi[3]));
+    else if constexpr (FO == 4)
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(ylo[0]), "+v"(yhi[0]), "+v"(ylo[1]), "+v"(yhi[1]), "+v"(ylo[2]), "+v"(yhi[2]), "+v"(ylo[3]), "+v"(yhi[3]),
                      "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1]), "+v"(xlo[2]), "+v"(xhi[2]), "+v"(xlo[3]), "+v"(xhi[3]));
@@ -252,6 +257,7 @@ static int launch_dma_one(const WgradParams& p, double flops, hipStream_t stream
 
 int launch_wgrad_dma(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
   if (p.K <= 0 || p.Cout <= 0 || p.Cin <= 0) return GC_OK;
+  if (l.to == 256) return launch_dma_one<256, 3>(p, l.flops, s);
   if (l.to == 64) return launch_dma_one<64, 4>(p, l.flops, s);
   return launch_dma_one<128, 4>(p, l.flops, s);
 }

@@ -186,7 +186,7 @@ static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t 
   }
   p.a_bias = (int32_t)(-min_off);
   const int64_t limit = (1ll << 31) - (1 << 20);
-  const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 128 || l.to == 64) &&
+  const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 256 || l.to == 128 || l.to == 64) &&
                    p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
   if (dma) return launch_gather_dma(p, l, out_dt == GC_F32, stream);
   return launch_gather(p, l, stream);

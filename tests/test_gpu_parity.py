@@ -749,6 +749,23 @@ def test_pool_and_replicate_against_torch(gan, shape, dt):
         assert rel(y.float(), yr) < tol and rel(gx.float(), gxr) < tol
 
 
+@pytest.mark.parametrize("cin,cout,hw,k,s,p", [(256, 256, 128, 3, 1, 1), (128, 512, 96, 4, 2, 1)])
+def test_largest_tiles_against_torch(gan, cin, cout, hw, k, s, p):
+    """Problems big enough for the 256-channel x 256-pixel tiles (and their data gradients), too big for the C oracle:
+    compared with torch's fp32 convolution of the same bf16-rounded operands on the GPU."""
+    g = torch.Generator().manual_seed(21)
+    B = 8
+    x = torch.randn(B, cin, hw, hw, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.03).cuda().requires_grad_(True)
+    y = gan.functional.conv2d(x, w, None, stride=s, padding=p)
+    gy = torch.randn(*y.shape, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    xr, wr = x.detach().float().requires_grad_(True), w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, stride=s, padding=p)
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.float())
+    assert rel(y.float(), yr) < 4e-3 and rel(gx.float(), gxr) < 4e-3 and rel(gw, gwr) < 2e-3
+
+
 def test_graphed_step_matches_eager_steps(gan):
     """gan_amd.GraphedStep on a full Pix2Pix step (both phases, both fused-Adam updates; U-Net and PatchGAN at width 8):
     three replays with fresh inputs copied into the static tensors must give the losses of three eager steps."""

@@ -17,7 +17,8 @@ SETS = {
     "wgan": [(3, 64, 64, 4, 2, 1), (64, 32, 128, 4, 2, 1), (128, 16, 256, 4, 2, 1), (256, 8, 512, 4, 2, 1), (512, 4, 1, 4, 1, 0), (512, 4, 100, 4, 1, 0)],
     "ksweep": [(64, 32, 128, 4, 2, 1), (128, 32, 128, 4, 2, 1), (256, 32, 128, 4, 2, 1), (512, 32, 128, 4, 2, 1), (1024, 32, 128, 4, 2, 1),
                (64, 32, 128, 3, 1, 1), (64, 32, 128, 1, 1, 0), (128, 32, 128, 1, 1, 0), (512, 32, 128, 1, 1, 0)],
-    "big": [(256, 32, 512, 4, 2, 1), (512, 64, 512, 3, 1, 1), (128, 128, 128, 3, 1, 1), (512, 16, 512, 4, 2, 1)],
+    "big": [(256, 32, 512, 4, 2, 1), (512, 64, 512, 3, 1, 1), (128, 128, 128, 3, 1, 1), (512, 16, 512, 4, 2, 1),
+            (512, 32, 512, 3, 1, 1), (256, 64, 256, 3, 1, 1), (1024, 16, 1024, 3, 1, 1)],
 }
 B = a.batch
 
