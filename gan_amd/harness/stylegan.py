@@ -11,8 +11,9 @@ What runs where: every Conv2d goes through gan_amd.nn.Conv2d (the EqualizedLR pr
 read at call time), FusedUpsample through gan_amd.functional.conv_transpose2d, the depthwise blur through
 gan_amd.functional.blur3x3 (self-adjoint, so it needs no custom backward Function), the InstanceNorm inside AdaIN
 through the fused instance-norm kernel; the LeakyReLU that follows a discriminator convolution runs in that
-convolution's epilogue (same arithmetic as the separate module).  The mapping MLP, the style affine, noise injection,
-the generator's LeakyReLU, minibatch standard deviation and the fade-in blends stay on stock torch ops.
+convolution's epilogue (same arithmetic as the separate module); the generator's noise injection -> LeakyReLU ->
+InstanceNorm -> style chain is one kernel per direction (gan_amd.ops.noise_lrelu_adain).  The mapping MLP, the style
+affine layers, minibatch standard deviation and the fade-in blends stay on stock torch ops.
 
 set_activation_dtype(torch.bfloat16) makes every convolution store bf16 outputs (fp32 accumulation; images, styles,
 the minibatch statistic, the final projection and the losses stay fp32); the default keeps fp32 storage.
@@ -28,6 +29,7 @@ import torch
 
 from .. import functional as GF
 from .. import nn as gnn
+from .. import ops
 
 _act_dtype = None          # None: every layer follows its input (fp32 storage)
 
@@ -39,6 +41,15 @@ def set_activation_dtype(dtype):
 
 def _like(t, ref):
     return t if t.dtype == ref.dtype else t.to(ref.dtype)
+
+
+_fused_chain = True
+
+
+def set_fused_chain(on):
+    """The generator's noise -> LeakyReLU -> InstanceNorm -> style chain on the fused kernel (default) or as modules."""
+    global _fused_chain
+    _fused_chain = bool(on)
 
 
 class EqualizedLR:
@@ -197,10 +208,22 @@ class SynthesisNetworkBlock(torch.nn.Module):
         if noise is None:
             b, _, w, h = output.shape
             noise = torch.randn(b, 1, w, h, device=output.device)
-        output = self.adaIN_1(self.leaky_relu_1(self.noise_injection_1(output, noise)), style)
+        output = self._styled(output, noise, style, self.noise_injection_1, self.leaky_relu_1, self.adaIN_1)
         output = self.convolution_2(output)
-        output = self.adaIN_2(self.leaky_relu_2(self.noise_injection_2(output, noise)), style)
+        output = self._styled(output, noise, style, self.noise_injection_2, self.leaky_relu_2, self.adaIN_2)
         return output
+
+    @staticmethod
+    def _styled(x, noise, style, injection, activation, adain):
+        """noise injection -> LeakyReLU -> AdaIN: one fused kernel per direction when it applies (GPU tensor, channels a
+        multiple of 4, no second-order graph being built), else the three modules as the reference chains them."""
+        if _fused_chain and x.is_cuda and x.shape[1] % 4 == 0:
+            w = injection.scaling_factor_orig                      # EqualizedLR: the scaled factor the pre-hook would set
+            sf = w * math.sqrt(2 / (w.shape[1] * w[0][0].numel()))
+            y_s, y_b = torch.chunk(adain.affine_transformation_layer(style), 2, dim=1)
+            return ops.noise_lrelu_adain(x, noise, sf, y_s, y_b, float(adain.instance_normalization.eps),
+                                         float(activation.negative_slope))[0]
+        return adain(activation(injection(x, noise)), style)
 
 
 class MappingNetwork(torch.nn.Module):

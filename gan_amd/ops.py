@@ -789,3 +789,71 @@ def _scale_ctx(ctx, inputs, output):
 
 torch.library.register_autograd("ganconv::pool2x2", lambda ctx, g: (replicate2x(g, ctx.scale), None), setup_context=_scale_ctx)
 torch.library.register_autograd("ganconv::replicate2x", lambda ctx, g: (pool2x2(g, ctx.scale), None), setup_context=_scale_ctx)
+
+
+# ---- StyleGAN: noise injection -> LeakyReLU -> InstanceNorm -> style affine as one op (first-order backward) -----
+def _adain_args(x, noise, sf, ys, yb):
+    _check_cuda(x, noise, sf, ys, yb)
+    N, C, H, W = x.shape
+    if noise.numel() != N * H * W or sf.numel() != C or tuple(ys.shape) != (N, C) or tuple(yb.shape) != (N, C):
+        raise RuntimeError("ganconv: noise_lrelu_adain takes noise [N,1,H,W], a scale per channel and styles [N,C]")
+    f = lambda t: t.float().contiguous()
+    return N, C, H * W, f(noise), f(sf).reshape(-1), f(ys), f(yb)
+
+
+@torch.library.custom_op("ganconv::noise_lrelu_adain", mutates_args=())
+def noise_lrelu_adain(x: Tensor, noise: Tensor, sf: Tensor, ys: Tensor, yb: Tensor, eps: float, slope: float) -> tuple[Tensor, Tensor, Tensor]:
+    """ys * InstanceNorm(leaky_relu(x + sf * noise)) + yb (reference StyleGAN/model.py:249-261).  Returns (out, mean,
+    rstd); the last two are [N, C] statistics kept for the backward pass."""
+    x = _nhwc(x)
+    N, C, HW, noise, sf, ys, yb = _adain_args(x, noise, sf, ys, yb)
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    mu, r = (torch.empty(N, C, dtype=torch.float32, device=x.device) for _ in range(2))
+    _lib.check(_lib.lib().gc_noise_lrelu_adain_fwd(_ptr(x), _ptr(noise), _ptr(sf), _ptr(ys), _ptr(yb), _ptr(out), _ptr(mu), _ptr(r), N, HW, C,
+                                                   _dtype_code(x), eps, slope, _stream()), "gc_noise_lrelu_adain_fwd")
+    return out, mu, r
+
+
+@noise_lrelu_adain.register_fake
+def _(x, noise, sf, ys, yb, eps, slope):
+    f = dict(dtype=torch.float32)
+    return torch.empty_like(x), x.new_empty(x.shape[0], x.shape[1], **f), x.new_empty(x.shape[0], x.shape[1], **f)
+
+
+@torch.library.custom_op("ganconv::noise_lrelu_adain_bwd", mutates_args=())
+def noise_lrelu_adain_bwd(x: Tensor, noise: Tensor, sf: Tensor, ys: Tensor, yb: Tensor, mu: Tensor, r: Tensor, gout: Tensor,
+                          slope: float) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    x, gout = _nhwc(x), _nhwc(gout)
+    if gout.dtype != x.dtype:
+        gout = gout.to(x.dtype)
+    N, C, HW, noise, sf, ys, yb = _adain_args(x, noise, sf, ys, yb)
+    gx = torch.empty_like(x, memory_format=torch.channels_last)
+    g_sf, g_ys, g_yb = (torch.empty(N, C, dtype=torch.float32, device=x.device) for _ in range(3))
+    _lib.check(_lib.lib().gc_noise_lrelu_adain_bwd(_ptr(x), _ptr(noise), _ptr(sf), _ptr(ys), _ptr(yb), _ptr(mu), _ptr(r), _ptr(gout), _ptr(gx),
+                                                   _ptr(g_sf), _ptr(g_ys), _ptr(g_yb), N, HW, C, _dtype_code(x), slope, _stream()),
+               "gc_noise_lrelu_adain_bwd")
+    return gx, g_sf, g_ys, g_yb
+
+
+@noise_lrelu_adain_bwd.register_fake
+def _(x, noise, sf, ys, yb, mu, r, gout, slope):
+    f = dict(dtype=torch.float32)
+    N, C = x.shape[0], x.shape[1]
+    return torch.empty_like(x), x.new_empty(N, C, **f), x.new_empty(N, C, **f), x.new_empty(N, C, **f)
+
+
+def _adain_setup(ctx, inputs, output):
+    x, noise, sf, ys, yb, _, slope = inputs
+    ctx.save_for_backward(x, noise, sf, ys, yb, output[1], output[2])
+    ctx.slope = slope
+
+
+def _adain_backward(ctx, gout, g_mu, g_r):
+    x, noise, sf, ys, yb, mu, r = ctx.saved_tensors
+    if gout.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("ganconv: noise_lrelu_adain has no second-order backward")
+    gx, g_sf, g_ys, g_yb = noise_lrelu_adain_bwd(x, noise, sf, ys, yb, mu, r, gout, ctx.slope)
+    return gx, None, g_sf.sum(dim=0).reshape(sf.shape).to(sf.dtype), g_ys.to(ys.dtype), g_yb.to(yb.dtype), None, None
+
+
+torch.library.register_autograd("ganconv::noise_lrelu_adain", _adain_backward, setup_context=_adain_setup)

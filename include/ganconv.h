@@ -200,6 +200,19 @@ int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t
 int gc_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const int64_t* numel, float* step, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* StyleGAN's chain behind every synthesis convolution as one kernel per direction (StyleGAN/model.py:179-208,249-261:
+ * NoiseInput, LeakyReLU(0.2), InstanceNorm2d, style affine):
+ *   out = ys[n,c] * IN(lrelu(x + sf[c] * noise[n,hw])) + yb[n,c]
+ * x / out / gout / gx NHWC fp32 or bf16 (`dtype`), C a multiple of 4; noise float [N, HW]; sf float [C]; ys, yb float
+ * [N, C].  The forward pass writes the per-(n, c) mean and rsqrt(var + eps) of the activated tensor to mu / r
+ * (float [N, C]) for the backward pass, which returns gx, g_ys / g_yb [N, C] and g_sf per sample [N, C] (sum over n
+ * for the parameter's gradient).  First order only; the noise gets no gradient. */
+int gc_noise_lrelu_adain_fwd(const void* x, const float* noise, const float* sf, const float* ys, const float* yb, void* out, float* mu,
+                             float* r, int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, float slope, void* stream);
+int gc_noise_lrelu_adain_bwd(const void* x, const float* noise, const float* sf, const float* ys, const float* yb, const float* mu,
+                             const float* r, const void* gout, void* gx, float* g_sf, float* g_ys, float* g_yb, int32_t N, int32_t HW,
+                             int32_t C, int32_t dtype, float slope, void* stream);
+
 /* 2x2 sum-pooling and 2x nearest replication, NHWC, fp32 or bf16 (`dtype`), C a multiple of 8, 16-byte aligned:
  *   gc_pool2x2     : y[n,h,w,c] = scale * (x[n,2h,2w,c] + x[n,2h,2w+1,c] + x[n,2h+1,2w,c] + x[n,2h+1,2w+1,c]),  x is [N,2Ho,2Wo,C]
  *   gc_replicate2x : y[n,2h+a,2w+b,c] = scale * x[n,h,w,c] (a, b in {0,1}),  x is [N,H,W,C], y [N,2H,2W,C]

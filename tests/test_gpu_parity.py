@@ -704,6 +704,32 @@ def test_attention_against_unfused_product(gan, B, N, d, C):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 32, 8, 8), (2, 64, 40, 24), (4, 8, 4, 4), (1, 512, 16, 16)])
+def test_noise_lrelu_adain_against_torch(gan, shape, dt):
+    """ys * InstanceNorm2d(leaky_relu(x + sf * noise)) + yb (reference StyleGAN/model.py:249-261) and the gradients of x,
+    the noise scale and the two styles against the torch composition in fp32."""
+    g = torch.Generator().manual_seed(17)
+    N, C, H, W = shape
+    x = (torch.randn(*shape, generator=g) * 1.3).cuda().to(dt).requires_grad_(True)
+    noise = torch.randn(N, 1, H, W, generator=g).cuda()
+    sf = (torch.randn(1, C, 1, 1, generator=g) * 0.4).cuda().requires_grad_(True)
+    ys = (torch.randn(N, C, generator=g) * 0.5 + 1).cuda().requires_grad_(True)
+    yb = (torch.randn(N, C, generator=g) * 0.3).cuda().requires_grad_(True)
+    out, mu, r = gan.ops.noise_lrelu_adain(x, noise, sf, ys, yb, 1e-5, 0.2)
+    go = torch.randn(*shape, generator=g).cuda().to(dt)
+    gx, gsf, gys, gyb = torch.autograd.grad(out, (x, sf, ys, yb), go)
+    xr, sfr, ysr, ybr = (t.detach().float().requires_grad_(True) for t in (x, sf, ys, yb))
+    tr = torch.nn.functional.leaky_relu(xr + sfr * noise, 0.2)
+    outr = ysr[:, :, None, None] * torch.nn.functional.instance_norm(tr, eps=1e-5) + ybr[:, :, None, None]
+    gxr, gsfr, gysr, gybr = torch.autograd.grad(outr, (xr, sfr, ysr, ybr), go.float())
+    tol, gtol = (2e-5, 2e-4) if dt == torch.float32 else (6e-3, 1.5e-2)
+    assert out.dtype == dt and rel(out.float(), outr) < tol
+    assert rel(mu, tr.mean(dim=(2, 3))) < 1e-5
+    assert rel(gx.float(), gxr) < gtol and rel(gys, gysr) < gtol and rel(gyb, gybr) < gtol
+    assert gsf.shape == sf.shape and rel(gsf, gsfr) < 3 * gtol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape,act", [((4, 32, 8, 8), 1), ((3, 64, 40, 24), 1), ((2, 8, 32, 32), 0), ((5, 128, 4, 4), 1)])
 def test_conditional_batchnorm_against_torch(gan, shape, act, dt):
     """gamma[n, c] * BatchNorm2d(affine=False)(x) + beta[n, c], then ReLU (reference BigGAN/model.py:61-77,129): output,
