@@ -18,7 +18,7 @@ cycles = prof["warmup"] + prof["steps"] + 2 + 2      # replays (warm-up + timed)
 rows = list(csv.DictReader(open(os.path.join(d, "bench_kernel_stats.csv"))))
 tot = sum(float(x["TotalDurationNs"]) for x in rows) / 1e6 / cycles
 lib = sum(float(x["TotalDurationNs"]) for x in rows if x["Name"].removeprefix("void ").startswith("gc::")) / 1e6 / cycles
-print(f"# Round 1, state {tag[-1]}: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']}` on one MI355X\n")
+print(f"# Measurement set {tag}: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']}` on one MI355X\n")
 cb = line.get("cpu_baseline", {})
 print(f"Unprofiled default run (`python bench.py`, `{tag}_bench_line.json`): **{line['value']:.0f} img/s, {line['ms_per_step']:.2f} ms per cycle**; "
       f"dominant conv kernel `{r['kernel']}`: {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of the dense bf16 peak, average launch "
