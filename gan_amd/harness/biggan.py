@@ -148,7 +148,8 @@ class SelfAttentionBlock(torch.nn.Module):
             output = torch.bmm(attention_weights, value.permute(0, 2, 1))
         # the reference reinterprets the [b, positions, c] product as [b, c, h, w] without a transpose
         output = output.reshape(b, -1, h, w)
-        return _like(self.gamma, output) * output + x
+        # gamma * output + x in one pass whose result takes x's (channels-last) layout
+        return torch.addcmul(x, output, _like(self.gamma, output))
 
     @staticmethod
     def _fused(key, query, value, out_dtype):
