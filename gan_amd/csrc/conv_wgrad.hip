@@ -274,6 +274,59 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const WgradReduc
   }
 }
 
+// The same reduction for the common case of a dense [Cout][Cin][kh][kw] gradient with at most 16 taps.  A workgroup
+// owns 64 consecutive (co, ci) pairs for all taps; each of its SW waves takes every SW-th slab and reads, per
+// instruction, four taps x 256 contiguous bytes (lane = (tap % 4, pair quad)).  Waves 1.. hand their sums to wave 0
+// through LDS, which adds them in a fixed order, transposes [tap][pair] -> [pair][tap] through LDS and writes the
+// workgroup's 64 * T results as one contiguous run (the generic kernel above writes 4-byte pieces 4 T bytes apart).
+template <int SW>
+__global__ __launch_bounds__(SW * 64) void wgrad_reduce_dense_kernel(const WgradReduceParams p) {
+  __shared__ f32x4 red[(SW > 2 ? SW - 1 : 2) * 64 * 4];   // [wave - 1][j][lane]; reused as the [pair][tap] tile (4352 bytes)
+  const int T = p.kh * p.kw;
+  const size_t pairs = (size_t)p.Cout * p.Cin;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quad = lane & 15, tl = lane >> 4;
+  const size_t pair0 = (size_t)blockIdx.x * 64;
+  const bool ok = pair0 + quad * 4 < pairs;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ok)
+    for (int sp = wave; sp < p.splits; sp += SW) {
+      const float* src = p.part + (size_t)sp * T * pairs + pair0 + quad * 4;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (tl + 4 * j < T) acc[j] += *reinterpret_cast<const f32x4*>(src + (size_t)(tl + 4 * j) * pairs);
+    }
+  if (SW > 1) {
+    if (wave > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) red[((wave - 1) * 4 + j) * 64 + lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 0; w < SW - 1; w++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] += red[(w * 4 + j) * 64 + lane];
+  }
+  // from here on one wave works alone; the LDS unit serves its instructions in order, so the tile needs no barrier
+  float* tile = reinterpret_cast<float*>(red);   // [64 pairs][17]: the odd pitch keeps the column writes off one bank
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) tile[(quad * 4 + e) * 17 + tl + 4 * j] = acc[j][e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // lane t of the run: element (pair0 * T + t), i.e. pair t / T, tap t % T -- contiguous in the gradient
+  const int n_out = (int)((pairs - pair0 < 64 ? pairs - pair0 : 64) * T);
+  float* dst = p.gw + pair0 * T;
+  for (int t = lane; t < n_out; t += 64) {
+    const float v = p.alpha * tile[(t / T) * 17 + t % T];
+    dst[t] = p.accumulate ? dst[t] + v : v;
+  }
+}
+
 // gb[c] += sum over pixels of gy[k][c]; gb is zeroed by the launcher.  One block sums a run of pixels.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void colsum_kernel(const T* gy, float* gb, int K, int C, int cstride, int coff, int k_per_block) {
@@ -383,6 +436,17 @@ int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
   const size_t total = (size_t)p.Cout * (p.thin ? p.ICp : p.Cin) * p.kh * p.kw;
   if (total == 0) return GC_OK;
+  const int T = p.kh * p.kw;
+  if (!p.thin && T <= 16 && p.Cin % 4 == 0 && p.s_s == 1 && p.s_r == p.kw && p.s_ci == T && p.s_co == (int64_t)p.Cin * T) {
+    const size_t pairs = (size_t)p.Cout * p.Cin;
+    const dim3 grid((unsigned)((pairs + 63) / 64));
+    // enough waves to pull the slabs at full rate: more split waves per workgroup when there are few pairs
+    const size_t wgs = (pairs + 63) / 64;
+    if (p.splits >= 16 && wgs * 4 < 2048) hipLaunchKernelGGL(wgrad_reduce_dense_kernel<16>, grid, dim3(1024), 0, stream, p);
+    else if (p.splits >= 4) hipLaunchKernelGGL(wgrad_reduce_dense_kernel<4>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(wgrad_reduce_dense_kernel<1>, grid, dim3(64), 0, stream, p);
+    return check_hip(hipGetLastError(), "wgrad_reduce launch");
+  }
   if (total % 4 == 0) {   // slabs stay 16-byte aligned: 4 elements per lane
     const size_t blocks = (total / 4 + 63) / 64;
     hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
