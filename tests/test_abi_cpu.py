@@ -56,6 +56,37 @@ def test_sizes_and_descriptor_validation():
     assert L.gc_dwblur3x3(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 4, 4, 6, _lib.GC_F32, None) == -2
 
 
+def test_argument_validation_of_the_layer_kernels():
+    """Entry points around the convolutions reject bad shapes, null or misaligned pointers before touching the GPU."""
+    L = _lib.lib()
+    q = ctypes.c_void_p(256)      # an aligned non-null pointer that is never dereferenced: every call below fails validation
+    odd = ctypes.c_void_p(260)
+    # attention: N a multiple of 128, d in {8, 16}, C in {64, 128}
+    assert L.gc_attention_fwd(q, q, q, q, q, 2, 100, 8, 64, None) == -2 and b"N % 128" in L.gc_last_error()
+    assert L.gc_attention_fwd(q, q, q, q, q, 2, 256, 12, 64, None) == -2
+    assert L.gc_attention_fwd(q, q, q, q, q, 2, 256, 8, 96, None) == -2
+    assert L.gc_attention_fwd(q, q, None, q, q, 2, 256, 8, 64, None) == -5
+    assert L.gc_attention_fwd(q, odd, q, q, q, 2, 256, 8, 64, None) == -5
+    assert L.gc_attention_bwd(q, q, q, q, q, q, q, q, q, None, 2, 256, 8, 64, None) == -5
+    # pooling / replication: channels a multiple of 8
+    assert L.gc_pool2x2(q, q, 1, 4, 4, 12, _lib.GC_BF16, 0.25, None) == -2
+    assert L.gc_replicate2x(q, None, 1, 4, 4, 16, _lib.GC_BF16, 1.0, None) == -5
+    assert L.gc_pool2x2(q, q, 0, 4, 4, 16, _lib.GC_F32, 0.25, None) == 0          # empty batch
+    # conditional batchnorm: workspace size grows with the sample-aligned slabs; gain and bias are mandatory
+    ws = L.gc_cond_batchnorm_workspace_bytes(4, 1024, 64)
+    assert ws >= (4 * 64 * 2 + 2 * 64) * 4 and L.gc_cond_batchnorm_workspace_bytes(0, 1024, 64) == 0
+    assert L.gc_cond_batchnorm_act_fwd(q, q, None, None, None, None, None, q, q, q, q, ws, 4, 1024, 64, _lib.GC_F32, 1e-5, 0.1, 1, 0.0, 1, None) == -5
+    assert L.gc_cond_batchnorm_act_fwd(q, q, q, q, None, None, None, q, q, q, q, 16, 4, 1024, 64, _lib.GC_F32, 1e-5, 0.1, 1, 0.0, 1, None) == -3
+    assert L.gc_cond_batchnorm_act_fwd(q, q, q, q, None, None, None, q, q, q, q, ws, 4, 1024, 66, _lib.GC_F32, 1e-5, 0.1, 1, 0.0, 1, None) == -2
+    # noise -> LeakyReLU -> InstanceNorm -> style chain
+    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, 2, 64, 30, _lib.GC_BF16, 1e-5, 0.2, None) == -2
+    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, 2, 64, 32, _lib.GC_BF16, 1e-5, 0.0, None) == -2     # slope must be positive
+    assert L.gc_noise_lrelu_adain_fwd(q, None, q, q, q, q, q, q, 2, 64, 32, _lib.GC_BF16, 1e-5, 0.2, None) == -5
+    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, 0, 64, 32, _lib.GC_BF16, 1e-5, 0.2, None) == 0
+    # the split-reduction switch reports the previous setting
+    assert L.gc_set_split_reduction(0) == 1 and L.gc_set_split_reduction(1) == 0 and L.gc_set_split_reduction(1) == 1
+
+
 def test_python_layer_fails_loudly_without_gpu():
     import gan_amd
     conv = gan_amd.nn.Conv2d(3, 8, 4, 2, 1)
