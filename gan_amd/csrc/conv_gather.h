@@ -68,6 +68,9 @@ int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t stre
 // Few output channels (at most 64 (tap, channel) pairs), stride-1 gather: fills the patch geometry, false if unsuitable.
 bool plan_scatter(GatherParams& p, const GatherLaunch& l);
 int launch_scatter(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
+// Image layer (<= 4 fp32 input channels, 4x4 stride-2 forward): patch staged once, see conv_image.hip.
+bool plan_image(const GatherParams& p, const GatherLaunch& l);
+int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // LDS-DMA fast path: bf16 input, vector-aligned channels, 64- or 128-channel tile, no reduction split.
 int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 

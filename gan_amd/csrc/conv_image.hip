@@ -1,0 +1,115 @@
+// First layer of the DCGAN / WGAN-GP critic: Conv2d(<= 4 channels -> up to 64, kernel 4, stride 2, padding 1) on fp32
+// images (reference BasicGANs/models.py:52-56,77).  1.6 GFLOP against 90 MB of traffic at batch 512: HBM-bound, so the
+// goal is to touch every input byte once and to keep the instruction count per output pixel low.
+//
+// A workgroup owns a 4 x 32 rectangle of one sample's output.  It stages the 10 x 66 input patch into LDS as bf16
+// with the channels padded to 4 (8 bytes per pixel, zeros outside the image), so that the 4 taps x 4 channels of one
+// filter row are 32 contiguous bytes for every output pixel: the B operand of a 16x16x32 MFMA (two filter rows) is
+// one 16-byte LDS read per lane, with no address arithmetic per tap.  The packed weights ([oc][tap][4 channels],
+// 64 reduction elements per row) stay in registers as A operands.
+#include "conv_gather.h"
+
+namespace gc {
+namespace {
+
+constexpr int kTH = 4, kTW = 32;                 // output rectangle of a workgroup (a multiple of 4 rows: one or more per wave)
+constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
+
+template <typename TOut>
+__global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p) {
+  __shared__ __attribute__((aligned(16))) uint16_t patch[kPH * kPW * 4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c16 = lane & 15;
+  const int tiles_w = p.OW / kTW, tiles_h = p.OH / kTH;
+  int bid = blockIdx.x;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int n = bid / tiles_h;
+  const int oh0 = th * kTH, ow0 = tw * kTW;
+  const int ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;   // input coordinates of patch element (0, 0)
+
+  // weights: A fragments of up to four 16-channel blocks, two reduction steps (filter rows 0-1, 2-3)
+  bf16x8 wa[4][2];
+#pragma unroll
+  for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      u32x4 v = z;
+      if (ob * 16 < p.OC) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)(ob * 16 + c16) * p.row_pitch + ks * 32 + g * 8);
+      wa[ob][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+
+  // stage the patch: one thread per pixel, channels padded to 4
+  const float* img = reinterpret_cast<const float*>(p.in) + (size_t)n * p.IH * p.IW * p.IC;
+  for (int e = t; e < kPH * kPW; e += kThreads) {
+    const int pr = e / kPW, pc = e - pr * kPW;
+    const int ih = ih0 + pr, iw = iw0 + pc;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+      const float* src = img + ((size_t)ih * p.IW + iw) * p.IC;
+      v[0] = src[0];
+      if (p.IC > 1) v[1] = src[1];
+      if (p.IC > 2) v[2] = src[2];
+      if (p.IC > 3) v[3] = src[3];
+    }
+    *reinterpret_cast<u32x2*>(patch + e * 4) = cvt_bf16x4(v);
+  }
+  __syncthreads();
+
+  // wave w: output rows RW * w .. of the rectangle, each in two groups of 16 pixels
+  constexpr int RW = kTH / 4;
+#pragma unroll
+  for (int grp = 0; grp < 2 * RW; grp++) {
+    const int oh_l = RW * wave + (grp >> 1), ow_l = (grp & 1) * 16 + c16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int pr = 2 * oh_l + 2 * ks + (g >> 1), pc = 2 * ow_l + 2 * (g & 1);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(patch + (pr * kPW + pc) * 4);
+#pragma unroll
+      for (int ob = 0; ob < 4; ob++)
+        if (ob * 16 < p.OC) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
+    }
+    const size_t pix = ((size_t)n * p.OH + oh0 + oh_l) * p.OW + ow0 + ow_l;
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) {
+      const int oc = ob * 16 + 4 * g;
+      if (oc >= p.OC) continue;
+      f32x4 v = acc[ob];
+      if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + oc);
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act, p.slope);
+      const size_t o = pix * p.out_cstride + p.out_coff + oc;
+      if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+      else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v);
+    }
+  }
+}
+
+}  // namespace
+
+// Applies to: fp32 input of at most 4 dense channels, the 4x4 / stride 2 / padding 1 forward pass, up to 64 output
+// channels in multiples of 16, output extents that tile by 4 x 32, plain epilogue (bias, activation).
+bool plan_image(const GatherParams& p, const GatherLaunch& l) {
+  if (l.in_bf16 || l.x3 || l.mode != kThinInput || p.ICp != 4 || p.IC > 4 || p.in_cstride != p.IC || p.in_coff != 0) return false;
+  if (p.T != 16 || p.tt.n_classes != 1 || p.a != 2 || p.row_pitch != 64 || p.IH != 2 * p.OH || p.IW != 2 * p.OW) return false;
+  for (int e = 0; e < 16; e++)
+    if (p.tt.dh[e] != e / 4 - 1 || p.tt.dw[e] != e % 4 - 1 || p.tt.wtap[e] != e) return false;
+  if (p.OC % 16 != 0 || p.OC > 64 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
+  if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
+  if ((reinterpret_cast<uintptr_t>(p.bias) & 15u) != 0) return false;
+  return (long)p.N * (p.OH / kTH) * (p.OW / kTW) < (1l << 31);
+}
+
+int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
+  const unsigned blocks = (unsigned)((long)p.N * (p.OH / kTH) * (p.OW / kTW));
+  if (blocks == 0) return GC_OK;
+  ProfScope ps("gc::conv_image_kernel", l.flops, stream);
+  if (out_f32) hipLaunchKernelGGL(conv_image_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, p);
+  else hipLaunchKernelGGL(conv_image_kernel<uint16_t>, dim3(blocks), dim3(kThreads), 0, stream, p);
+  return check_hip(hipGetLastError(), "conv_image launch");
+}
+
+}  // namespace gc

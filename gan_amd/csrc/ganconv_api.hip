@@ -173,6 +173,7 @@ static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t 
     set_error("out_bf16 needs an fp32 output whose channel slice is a multiple of 4 channels at a multiple of 4");
     return GC_UNSUPPORTED_GEOMETRY;
   }
+  if (plan_image(p, l)) return launch_image(p, l, out_dt == GC_F32, stream);
   if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   l.big_tile_ok = true;
   plan_gather(p, l);
