@@ -93,6 +93,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
 }
 
 // Zero-fill as an ordinary kernel (a memset node recorded into a HIP graph was seen not to take effect on replay).
+bool patch_kernel_allowed();     // process-wide switch (gc_set_patch_kernel)
 bool split_reduction_allowed();   // process-wide switch (gc_set_split_reduction)
 int zero_fill(void* ptr, size_t bytes, hipStream_t stream);   // bytes a multiple of 4, ptr 4-byte aligned
 

@@ -71,6 +71,10 @@ int launch_scatter(const GatherParams& p, const GatherLaunch& l, bool out_f32, h
 // Image layer (<= 4 fp32 input channels, 4x4 stride-2 forward): patch staged once, see conv_image.hip.
 bool plan_image(const GatherParams& p, const GatherLaunch& l);
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
+// Patch-resident kernel (stride-1 gathers with >= 4 taps per class on large images, see conv_patch.hip); plan_patch
+// rewrites the tile bookkeeping in p when it accepts.
+bool plan_patch(GatherParams& p, const GatherLaunch& l);
+int launch_patch(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // LDS-DMA fast path: bf16 input, vector-aligned channels, 64- or 128-channel tile, no reduction split.
 int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 

@@ -36,6 +36,8 @@ struct ProfRec {
   double flops;
   hipEvent_t e0, e1;
 };
+static std::atomic<bool> g_patch_kernel{true};
+bool patch_kernel_allowed() { return g_patch_kernel.load(std::memory_order_relaxed); }
 static std::atomic<bool> g_split_reduction{true};
 bool split_reduction_allowed() { return g_split_reduction.load(std::memory_order_relaxed); }
 static std::mutex g_prof_mu;
@@ -189,6 +191,7 @@ static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t 
   const int64_t limit = (1ll << 31) - (1 << 20);
   const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 256 || l.to == 128 || l.to == 64) &&
                    p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
+  if (dma && patch_kernel_allowed() && plan_patch(p, l)) return launch_patch(p, l, out_dt == GC_F32, stream);
   if (dma) return launch_gather_dma(p, l, out_dt == GC_F32, stream);
   return launch_gather(p, l, stream);
 }
@@ -250,6 +253,8 @@ using namespace gc;
 extern "C" {
 
 int gc_version(void) { return GANCONV_VERSION; }
+
+int gc_set_patch_kernel(int on) { return g_patch_kernel.exchange(on != 0) ? 1 : 0; }
 
 int gc_set_split_reduction(int on) { return g_split_reduction.exchange(on != 0) ? 1 : 0; }
 

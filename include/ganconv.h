@@ -244,6 +244,11 @@ int gc_attention_bwd(const void* k, const void* q, const void* v, const void* ou
  * atomics in either setting. */
 int gc_set_split_reduction(int on);
 
+/* Kernel selection aid for measurements: gc_set_patch_kernel(0) keeps large stride-1 multi-tap convolutions on the
+ * tiled LDS-DMA kernel instead of the patch-resident one (default on; same results up to summation order).  Returns
+ * the previous setting.  No counterpart in the reference. */
+int gc_set_patch_kernel(int on);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around every launch while enabled.
  * gc_profile_collect synchronises on the recorded events, returns the number of kernel families written to
  * the caller's arrays (at most max_entries) and resets the records.  flops[] holds the algorithmic FLOPs

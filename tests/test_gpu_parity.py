@@ -775,6 +775,32 @@ def test_pool_and_replicate_against_torch(gan, shape, dt):
         assert rel(y.float(), yr) < tol and rel(gx.float(), gxr) < tol
 
 
+@pytest.mark.parametrize("cin,cout,hw,k,s,p,B", [(128, 256, 64, 3, 1, 1, 32), (96, 128, 64, 3, 1, 1, 64), (128, 256, 128, 4, 2, 1, 16),
+                                                  (64, 192, 32, 3, 1, 1, 128), (256, 128, 64, 3, 1, 1, 64)])
+def test_patch_kernel_exact_on_small_integers(gan, cin, cout, hw, k, s, p, B):
+    """Shapes that take the patch-resident kernel (forward of 3x3 stride 1; data gradient of 3x3 and of 4x4 stride 2 by
+    parity classes; channel counts that leave partial chunks and partial channel tiles): with small-integer operands
+    every product and partial sum is exact in bf16 x bf16 -> fp32, so the results must equal torch's fp32 convolution
+    bit for bit, whatever the summation order."""
+    g = torch.Generator().manual_seed(23)
+    x = torch.randint(-3, 4, (B, cin, hw, hw), generator=g).float().cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randint(-4, 5, (cout, cin, k, k), generator=g).float() / 8).cuda().requires_grad_(True)
+    y = gan.functional.conv2d(x, w, None, stride=s, padding=p, out_dtype=torch.float32)
+    gy = torch.randint(-2, 3, tuple(y.shape), generator=g).float().cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gx, = torch.autograd.grad(y, x, gy)
+    xr = x.detach().float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, w.detach(), None, stride=s, padding=p)
+    gxr, = torch.autograd.grad(yr, xr, gy.float())
+    assert torch.equal(y, yr)
+    assert torch.equal(gx, gxr.to(torch.bfloat16))     # the exact fp32 sums, rounded once to the bf16 storage type
+    prev = gan._lib.lib().gc_set_patch_kernel(0)
+    try:
+        y2 = gan.functional.conv2d(x.detach(), w.detach(), None, stride=s, padding=p, out_dtype=torch.float32)
+    finally:
+        gan._lib.lib().gc_set_patch_kernel(prev)
+    assert torch.equal(y2, yr)
+
+
 @pytest.mark.parametrize("cin,cout,hw,k,s,p", [(256, 256, 128, 3, 1, 1), (128, 512, 96, 4, 2, 1)])
 def test_largest_tiles_against_torch(gan, cin, cout, hw, k, s, p):
     """Problems big enough for the 256-channel x 256-pixel tiles (and their data gradients), too big for the C oracle:

@@ -5,7 +5,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "gc::conv" not in k and "gc::wgrad" not in k: continue
+            if "conv_" not in k and "gc::wgrad" not in k or "gc::" not in k: continue
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
             acc[k]["_dur_ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
     print("==", d)
