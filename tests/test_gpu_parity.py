@@ -776,7 +776,7 @@ def test_pool_and_replicate_against_torch(gan, shape, dt):
 
 
 @pytest.mark.parametrize("cin,cout,hw,k,s,p,B", [(128, 256, 64, 3, 1, 1, 32), (96, 128, 64, 3, 1, 1, 64), (128, 256, 128, 4, 2, 1, 16),
-                                                  (64, 192, 32, 3, 1, 1, 128), (256, 128, 64, 3, 1, 1, 64)])
+                                                  (64, 192, 32, 3, 1, 1, 128), (256, 128, 64, 3, 1, 1, 64), (128, 64, 64, 3, 1, 1, 64), (64, 128, 128, 4, 2, 1, 16)])
 def test_patch_kernel_exact_on_small_integers(gan, cin, cout, hw, k, s, p, B):
     """Shapes that take the patch-resident kernel (forward of 3x3 stride 1; data gradient of 3x3 and of 4x4 stride 2 by
     parity classes; channel counts that leave partial chunks and partial channel tiles): with small-integer operands
