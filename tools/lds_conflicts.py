@@ -48,7 +48,20 @@ def wgrad_tr_read(rowb, f):
     return res
 
 
+def patch_read(swz):
+    """conv_patch.hip: 64-byte rows (32 channels); a fragment reads 16 consecutive rows starting at any row."""
+    res = 0
+    for row0 in range(0, 48):
+        def addr(l):
+            row = row0 + (l & 15)
+            return row * 64 + (((l >> 4) ^ swz(row)) * 16)
+        res = max(res, worst(B128_GROUPS, addr, 16, 64))
+    return res
+
+
 if __name__ == "__main__":
+    print("patch kernel, 64-byte rows, chunk ^ ((row >> 2) & 3):", patch_read(lambda r: (r >> 2) & 3), "-way")
+    print("patch kernel, 64-byte rows, chunk ^ ((row >> 1) & 3):", patch_read(lambda r: (r >> 1) & 3), "-way  (used)")
     print("gather b128 read, no swizzle      :", gather_read(lambda r: 0))
     print("gather b128 read, (row>>1)&7      :", gather_read(lambda r: (r >> 1) & 7))
     print("wgrad tr read rowb=256 none       :", wgrad_tr_read(256, lambda k: 0))
