@@ -801,6 +801,64 @@ def test_patch_kernel_exact_on_small_integers(gan, cin, cout, hw, k, s, p, B):
     assert torch.equal(y2, yr)
 
 
+def _random_geometries(n, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    while len(out) < n:
+        k = rnd.choice([1, 2, 3, 3, 4, 4, 5])
+        s = rnd.choice([1, 1, 2])
+        p = rnd.choice([0, 1, 1, 2])
+        if p >= k:
+            continue
+        h, w = rnd.randint(max(k, 3), 40), rnd.randint(max(k, 3), 40)
+        if (h + 2 * p - k) < 0 or (w + 2 * p - k) < 0:
+            continue
+        out.append(dict(N=rnd.choice([1, 2, 3, 5, 9, 17]), cin=rnd.choice([3, 4, 8, 24, 64, 72, 130, 256]),
+                        cout=rnd.choice([1, 3, 16, 64, 96, 128, 200, 256]), h=h, w=w, k=k, s=s, p=p,
+                        transposed=rnd.random() < 0.35, bf16=rnd.random() < 0.5, act=rnd.choice([None, None, "relu", "leaky_relu"])))
+    return out
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32x3"])
+def test_randomized_geometries_exact_on_small_integers(gan, prec):
+    """48 seeded random layers (both convolution kinds, both storage types, odd extents, channel counts on either side of
+    every kernel's eligibility borders, fused activations) with small-integer operands: every product and partial sum is
+    exact in bf16 x bf16 -> fp32 whatever the tiling, split or summation order, so outputs, input gradients and weight
+    gradients must equal torch's fp32 results bit for bit (rounded once where the storage type is bf16)."""
+    gan.set_precision(prec)
+    try:
+        for i, c in enumerate(_random_geometries(48, 1234)):
+            g = torch.Generator().manual_seed(100 + i)
+            dt = torch.bfloat16 if c["bf16"] else torch.float32
+            x = torch.randint(-2, 3, (c["N"], c["cin"], c["h"], c["w"]), generator=g).float().cuda().to(dt).requires_grad_(True)
+            wshape = (c["cin"], c["cout"], c["k"], c["k"]) if c["transposed"] else (c["cout"], c["cin"], c["k"], c["k"])
+            w = (torch.randint(-2, 3, wshape, generator=g).float() / 4).cuda().requires_grad_(True)
+            b = (torch.randint(-4, 5, (c["cout"],), generator=g).float() / 2).cuda().requires_grad_(True)
+            conv = gan.functional.conv_transpose2d if c["transposed"] else gan.functional.conv2d
+            ref = torch.nn.functional.conv_transpose2d if c["transposed"] else torch.nn.functional.conv2d
+            y = conv(x, w, b, stride=c["s"], padding=c["p"], activation=c["act"])
+            gy = torch.randint(-2, 3, tuple(y.shape), generator=g).float().cuda().to(dt)
+            gx, gw, gb = torch.autograd.grad(y, (x, w, b), gy)
+            xr, wr, br = x.detach().float().requires_grad_(True), w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+            yr = ref(xr, wr, br, stride=c["s"], padding=c["p"])
+            if c["act"] == "relu":
+                yr = torch.relu(yr)
+            elif c["act"] == "leaky_relu":
+                yr = torch.nn.functional.leaky_relu(yr, 0.25)     # a power of two keeps the products exact
+            if c["act"] == "leaky_relu":
+                y = conv(x, w, b, stride=c["s"], padding=c["p"], activation="leaky_relu", negative_slope=0.25)
+                gx, gw, gb = torch.autograd.grad(y, (x, w, b), gy)
+            gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), gy.float())
+            tag = (i, c)
+            assert torch.equal(y.float(), yr.to(dt).float()), tag
+            assert torch.equal(gx.float(), gxr.to(dt).float()), tag
+            assert torch.equal(gw, gwr), tag
+            assert torch.equal(gb, gbr), tag
+    finally:
+        gan.set_precision("bf16")
+
+
 @pytest.mark.parametrize("cin,cout,hw,k,s,p", [(256, 256, 128, 3, 1, 1), (128, 512, 96, 4, 2, 1)])
 def test_largest_tiles_against_torch(gan, cin, cout, hw, k, s, p):
     """Problems big enough for the 256-channel x 256-pixel tiles (and their data gradients), too big for the C oracle:
