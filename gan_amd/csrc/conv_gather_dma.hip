@@ -37,8 +37,13 @@ __device__ __forceinline__ void wait_vmcnt() {   // s_waitcnt vmcnt(N) alone (ex
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr uint32_t kOutOfRange = 0x80000000u;   // beyond any buffer this kernel accepts: the load returns zeros
 
-template <typename TOut, int TO, int TP, int STAGES, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherParams p) {
+// WS ("wave specialised"): the workgroup has 2 NW waves; waves NW.. only issue the LDS-DMA loads, waves 0..NW-1 only
+// read fragments and multiply.  A wave that issues loads is held at every load instruction until the texture-address
+// path has taken the previous ones (16 cycles per 1 KiB instruction, all waves of the CU in one queue), and a held
+// wave issues no MFMA; with the roles split, that wait no longer sits in the matrix pipe's instruction stream.
+// Synchronisation stays one workgroup barrier per step, executed by both roles.
+template <typename TOut, int TO, int TP, int STAGES, int NW, bool WS = false>
+__global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel(const GatherParams p) {
   using C = DmaCfg<TO, TP, NW>;
   constexpr int W_BYTES = TO * 128, A_BYTES = TP * 128;
   constexpr int STAGE = W_BYTES + A_BYTES;
@@ -49,7 +54,10 @@ __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherPa
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63, wave_id = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = !WS || wave_id >= NW;      // issues loads
+  const bool consumer = !WS || wave_id < NW;     // multiplies and stores
+  const int wave = WS && wave_id >= NW ? wave_id - NW : wave_id;   // index within the role
   const int wo = wave / C::WP, wp_ = wave % C::WP;
 
   const uint32_t nblocks = (uint32_t)p.n_pix_tiles * (uint32_t)p.n_oc_tiles;
@@ -176,6 +184,40 @@ __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherPa
   // ---- main loop ---------------------------------------------------------------------------------------
   int issued = 0, st_i = 0, st_c = 0;
   auto next_stage = [](int s) { return s + 1 == STAGES ? 0 : s + 1; };
+  if (WS) {
+    // Both roles execute one barrier per step: at barrier `it` the loaders have seen step `it` land and the consumers
+    // have finished step it-1, whose buffer the loaders then refill.
+    if (loader) {
+      if (nsteps > 0) load_tap(tap_begin);
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; s++)
+        if (issued < nsteps) { issue(st_i); st_i = next_stage(st_i); issued++; }
+      int it = 0;
+      for (; issued < nsteps; it++, issued++) {
+        wait_vmcnt<(STAGES - 2) * LOADS>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(st_i);
+        st_i = next_stage(st_i);
+      }
+      for (; it < nsteps; it++) {
+        const int younger = nsteps - it - 1;
+        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
+        else if (STAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+    for (int it = 0; it < nsteps; it++) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      compute(st_c);
+      st_c = next_stage(st_c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   if (nsteps > 0) load_tap(tap_begin);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; s++)
@@ -204,6 +246,8 @@ __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherPa
     st_c = next_stage(st_c);
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
+  (void)consumer;
 
   // ---- epilogue ----------------------------------------------------------------------------------------
   const bool vec_ok = p.out_vec != 0;
@@ -274,10 +318,10 @@ __global__ __launch_bounds__(NW * 64) void conv_gather_dma_kernel(const GatherPa
   }
 }
 
-template <typename TOut, int TO, int TP, int STAGES, int NW>
+template <typename TOut, int TO, int TP, int STAGES, int NW, bool WS = false>
 static int launch_dma_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * (TO + TP) * 128 + kMaxTaps * 4;
-  auto kern = conv_gather_dma_kernel<TOut, TO, TP, STAGES, NW>;
+  auto kern = conv_gather_dma_kernel<TOut, TO, TP, STAGES, NW, WS>;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
     if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
@@ -287,9 +331,10 @@ static int launch_dma_one(const GatherParams& p, double flops, hipStream_t strea
   }
   const unsigned nblocks = (unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles;
   char name[96];
-  snprintf(name, sizeof(name), "gc::conv_gather_dma_kernel<%s, %d, %d, %d, %d>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, TP, STAGES, NW);
+  snprintf(name, sizeof(name), "gc::conv_gather_dma_kernel<%s, %d, %d, %d, %d%s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, TP, STAGES,
+           NW, WS ? ", true" : "");
   ProfScope ps(name, flops, stream);
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64 * (WS ? 2 : 1)), smem, stream, p);
   return check_hip(hipGetLastError(), "conv_gather_dma launch");
 }
 
@@ -302,7 +347,7 @@ int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32
   if (l.to == 128 && deep) return out_f32 ? launch_dma_one<float, 128, 128, 4, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 128, 128, 4, 4>(p, l.flops, s);
   if (l.to == 128) return out_f32 ? launch_dma_one<float, 128, 128, 2, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 128, 128, 2, 4>(p, l.flops, s);
   if (l.to == 64 && deep) return out_f32 ? launch_dma_one<float, 64, 128, 4, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 64, 128, 4, 4>(p, l.flops, s);
-  if (l.to == 64) return out_f32 ? launch_dma_one<float, 64, 128, 2, 4>(p, l.flops, s) : launch_dma_one<uint16_t, 64, 128, 2, 4>(p, l.flops, s);
+  if (l.to == 64) return out_f32 ? launch_dma_one<float, 64, 128, 3, 4, true>(p, l.flops, s) : launch_dma_one<uint16_t, 64, 128, 3, 4, true>(p, l.flops, s);
   set_error("internal: no LDS-DMA variant for this tile");
   return GC_UNSUPPORTED_GEOMETRY;
 }
