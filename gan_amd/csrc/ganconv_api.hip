@@ -82,6 +82,43 @@ __global__ __launch_bounds__(kThreads) void pack_weight_kernel(const float* w, i
   }
 }
 
+// Several weights in one launch (after an optimizer step): job j owns blocks [block0[j], block0[j + 1]).
+constexpr int kMaxPackJobs = 24;
+struct PackJob {
+  const float* w;
+  uint16_t* dst;
+  int64_t s_co, s_ci, s_r, s_s;
+  int32_t rows, cols, colp, pitch, kh, kw, transpose, planes;
+  float alpha;
+  uint32_t block0;
+};
+struct PackTable {
+  int32_t n;
+  uint32_t nblocks;
+  PackJob job[kMaxPackJobs];
+};
+__global__ __launch_bounds__(kThreads) void pack_weights_kernel(const PackTable t) {
+  int j = 0;
+  for (int i = 1; i < t.n; i++)
+    if (blockIdx.x >= t.job[i].block0) j = i;
+  const PackJob& q = t.job[j];
+  const uint32_t nb = (j + 1 < t.n ? t.job[j + 1].block0 : t.nblocks) - q.block0;
+  const size_t total = (size_t)q.rows * q.pitch;
+  for (size_t e = (size_t)(blockIdx.x - q.block0) * kThreads + threadIdx.x; e < total; e += (size_t)nb * kThreads) {
+    const int k = (int)(e % q.pitch);
+    const int row = (int)(e / q.pitch);
+    const int col = k % q.colp, tap = k / q.colp;
+    float v = 0.f;
+    if (col < q.cols && tap < q.kh * q.kw) {
+      const int co = q.transpose ? col : row, ci = q.transpose ? row : col;
+      v = q.alpha * q.w[co * q.s_co + ci * q.s_ci + (tap / q.kw) * q.s_r + (tap % q.kw) * q.s_s];
+    }
+    const uint16_t hi = float_to_bf16_bits(v);
+    q.dst[e] = hi;
+    if (q.planes == 2) q.dst[total + e] = float_to_bf16_bits(v - bf16_bits_to_float(hi));
+  }
+}
+
 // ---- depthwise 3x3 binomial blur, NHWC ----------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* x, T* y, int N, int H, int W, int C4) {
@@ -290,6 +327,49 @@ int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, w, w_strides[0], w_strides[1],
                      w_strides[2], w_strides[3], (uint16_t*)packed, rows, cols, colp, g.row_pitch, d->kh, d->kw, transpose, planes, alpha);
   return check_hip(hipGetLastError(), "pack_weight launch");
+}
+
+int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
+                    const float* alphas, void* const* packed, void* stream) {
+  if (n < 0 || (n > 0 && (descs == nullptr || passes == nullptr || ws == nullptr || w_strides == nullptr || packed == nullptr))) {
+    set_error("gc_pack_weights: null pointer"); return GC_BAD_ARGUMENT;
+  }
+  for (int base = 0; base < n; base += kMaxPackJobs) {
+    PackTable t;
+    memset(&t, 0, sizeof(t));
+    t.n = n - base < kMaxPackJobs ? n - base : kMaxPackJobs;
+    uint32_t blocks = 0;
+    for (int j = 0; j < t.n; j++) {
+      const gc_conv_desc* d = descs + base + j;
+      const int pass = passes[base + j];
+      int rc = validate(d);
+      if (rc != GC_OK) return rc;
+      if (pass != GC_PASS_FPROP && pass != GC_PASS_DGRAD) { set_error("gc_pack_weights: bad pass"); return GC_BAD_ARGUMENT; }
+      if (ws[base + j] == nullptr || packed[base + j] == nullptr || !aligned16(packed[base + j])) {
+        set_error("gc_pack_weights: null weight or null / misaligned packed buffer"); return GC_BAD_ARGUMENT;
+      }
+      const PackGeom g = geom_for(d, pass);
+      PackJob& q = t.job[j];
+      q.w = ws[base + j]; q.dst = (uint16_t*)packed[base + j];
+      const int64_t* st = w_strides + 4 * (size_t)(base + j);
+      q.s_co = st[0]; q.s_ci = st[1]; q.s_r = st[2]; q.s_s = st[3];
+      q.transpose = pass == GC_PASS_DGRAD;
+      q.rows = q.transpose ? d->Cin : d->Cout; q.cols = q.transpose ? d->Cout : d->Cin;
+      q.colp = g.icp; q.pitch = g.row_pitch; q.kh = d->kh; q.kw = d->kw;
+      q.planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
+      q.alpha = alphas != nullptr ? alphas[base + j] : 1.f;
+      q.block0 = blocks;
+      size_t nb = ((size_t)q.rows * q.pitch + kThreads - 1) / kThreads;
+      if (nb > 512) nb = 512;
+      if (nb < 1) nb = 1;
+      blocks += (uint32_t)nb;
+    }
+    t.nblocks = blocks;
+    ProfScope ps("gc::pack_weights_kernel", 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, t);
+    if (check_hip(hipGetLastError(), "pack_weights launch")) return GC_HIP_ERROR;
+  }
+  return GC_OK;
 }
 
 int gc_conv2d_fprop(const gc_conv_desc* d, const void* x, const void* packed_w, void* y, const gc_epilogue* ep, void* stream) {

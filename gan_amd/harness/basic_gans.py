@@ -178,8 +178,8 @@ class WganGpTrainer:
         self.net_G.to(self.device)
         self.net_D.to(self.device)
         if fused_adam and self.device.type == "cuda":     # one launch per step, device-side step counter (capturable)
-            self.opt_D = goptim.Adam(self.net_D.parameters(), lr=lr, betas=betas)
-            self.opt_G = goptim.Adam(self.net_G.parameters(), lr=lr, betas=betas)
+            self.opt_D = goptim.Adam(self.net_D.parameters(), lr=lr, betas=betas).repack_after_step(self.net_D)
+            self.opt_G = goptim.Adam(self.net_G.parameters(), lr=lr, betas=betas).repack_after_step(self.net_G)
         else:
             cap = capturable and self.device.type == "cuda"
             self.opt_D = torch.optim.Adam(self.net_D.parameters(), lr=lr, betas=betas, capturable=cap, foreach=True)

@@ -15,6 +15,7 @@ include/ganconv.h.  There is no fallback: on a CPU tensor, a missing library or 
 raise RuntimeError.
 """
 import ctypes
+import weakref
 from typing import Optional
 
 import torch
@@ -225,6 +226,12 @@ def _packed(desc, w, pass_, wkey):
         ent = _wcache.get(ck)
         if ent is not None and ent[0] == w.data_ptr() and ent[1] == w._version and ent[2] == tuple(w.shape):
             return ent[3]
+        if ent is not None and w.dtype == torch.float32 and ent[0] == w.data_ptr() and ent[2] == tuple(w.shape):
+            # same storage, new values: refresh the image in place (keeps repack() able to find it)
+            _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), 1.0,
+                                        ctypes.c_void_p(ent[3].data_ptr()), _stream()), "gc_pack_weight")
+            _wcache[ck] = (w.data_ptr(), w._version, tuple(w.shape), ent[3], ent[4], ent[5])
+            return ent[3]
     if w.dtype != torch.float32:
         w = w.float()
     nbytes = L.gc_packed_weight_bytes(ctypes.byref(desc), pass_)
@@ -234,8 +241,34 @@ def _packed(desc, w, pass_, wkey):
     _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), 1.0,
                                 ctypes.c_void_p(buf.data_ptr()), _stream()), "gc_pack_weight")
     if wkey:
-        _wcache[ck] = (w.data_ptr(), w._version, tuple(w.shape), buf)
+        _wcache[ck] = (w.data_ptr(), w._version, tuple(w.shape), buf, ConvDesc.from_buffer_copy(desc), weakref.ref(w))
     return buf
+
+
+def repack(wkeys):
+    """Refreshes, in ONE launch, every cached weight image of the given module keys whose parameter has changed since
+    it was packed (call right after an optimizer step: the convolutions that follow then find current images instead
+    of re-packing one weight at a time).  Images are rewritten in place."""
+    jobs = []
+    for ck, ent in _wcache.items():
+        if ck[0] not in wkeys:
+            continue
+        w = ent[5]()
+        if w is None or w.dtype != torch.float32 or w.data_ptr() != ent[0] or tuple(w.shape) != ent[2] or w._version == ent[1]:
+            continue
+        jobs.append((ck, ent, w))
+    if not jobs:
+        return 0
+    n = len(jobs)
+    descs = (ConvDesc * n)(*[e[4] for _, e, _ in jobs])
+    passes = (ctypes.c_int32 * n)(*[ck[1] for ck, _, _ in jobs])
+    ws = (ctypes.c_void_p * n)(*[w.data_ptr() for _, _, w in jobs])
+    strides = (ctypes.c_int64 * (4 * n))(*[s_ for _, _, w in jobs for s_ in w.stride()])
+    packed = (ctypes.c_void_p * n)(*[e[3].data_ptr() for _, e, _ in jobs])
+    _lib.check(_lib.lib().gc_pack_weights(n, descs, passes, ws, strides, None, packed, _stream()), "gc_pack_weights")
+    for ck, e, w in jobs:
+        _wcache[ck] = (e[0], w._version, e[2], e[3], e[4], e[5])
+    return n
 
 
 def _epilogue(bias, act=0, slope=0.0, out=None):

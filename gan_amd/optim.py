@@ -20,6 +20,13 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
+        self._nets = []
+
+    def repack_after_step(self, *nets):
+        """After every step, refresh the packed weight images of the gan_amd convolution modules of `nets` in one launch
+        (otherwise each convolution re-packs its own weight when it next runs: two small launches per layer and step)."""
+        self._nets = list(nets)
+        return self
 
     def _table(self, gi, params):
         """Host arrays of device pointers for the parameters that have a gradient; rebuilt when anything moved."""
@@ -64,4 +71,9 @@ class Adam(torch.optim.Optimizer):
                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gc_adam_step")
             for p in params:     # the kernel wrote through raw pointers: tell autograd (and every cache keyed on the
                 torch.autograd.graph.increment_version(p)      # version, e.g. packed weight images) that p changed
+        if self._nets:
+            keys = {m.__dict__["_ganconv_wkey"] for net in self._nets for m in net.modules() if "_ganconv_wkey" in m.__dict__}
+            if keys:
+                from . import ops
+                ops.repack(keys)
         return loss

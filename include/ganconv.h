@@ -100,6 +100,11 @@ size_t gc_packed_weight_bytes(const gc_conv_desc* desc, int pass);
 int gc_pack_weight(const gc_conv_desc* desc, int pass, const float* w, const int64_t w_strides[4], float alpha,
                    void* packed, void* stream);
 
+/* gc_pack_weight for n weights in one launch (what a training loop wants right after an optimizer step): descs, passes,
+ * ws, alphas (may be NULL: all 1) and packed are arrays of n entries, w_strides holds 4 element strides per entry. */
+int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
+                    const float* alphas, void* const* packed, void* stream);
+
 /* y = conv2d(x, w) [+ bias, activation, statistics].  Replaces aten::convolution (forward) behind
  *   torch.nn.Conv2d        BasicGANs/models.py:77; Pix2Pix/models.py:17,83,225-232; StyleGAN/model.py:72
  *   F.conv2d               BigGAN/model.py:56-58
