@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--ddp-eager", action="store_true",
                     help="data parallel: launch every kernel eagerly (default: forward/backward and optimizer steps are HIP "
                          "graphs, the gradient buckets are all-reduced between two replays)")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="run the independent chains of a critic iteration (real + fake pass, gradient-penalty pass, the generator's "
+                         "forward passes) one after the other instead of on streams of their own (measured: 14 %% slower)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32x3"])
     ap.add_argument("--fp32-activations", action="store_true",
                     help="store the activations between the layers in fp32 (default: bf16 storage, fp32 accumulation and statistics)")
@@ -94,7 +97,7 @@ def main():
     use_graph = not a.no_graph and not (distributed and a.ddp_eager)
     tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),
                        capturable=use_graph, batch_real_fake=True, fused_adam=True,
-                       activation_dtype=torch.float32 if a.fp32_activations else torch.bfloat16)
+                       activation_dtype=torch.float32 if a.fp32_activations else torch.bfloat16, two_streams=not a.one_stream)
     if distributed:  # replicas start from identical parameters
         for p in list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers()):
             dist.broadcast(p.data, 0)
@@ -127,7 +130,9 @@ def main():
     finite = all(x == x and abs(x) != float("inf") for x in losses)
 
     # ---- per-kernel timing of the same cycle (HIP events on the launch stream), eager, outside the timed region
+    # One stream here: a kernel's duration is that of the kernel alone on the GPU, not of a kernel sharing it with another chain.
     roofline = None
+    tr.two_streams = False
     if rank == 0:
         _lib.profile_enable(True)
     for _ in range(2):        # every rank runs the cycles: with more than one rank they contain collectives
@@ -162,7 +167,7 @@ def main():
                                    ("fp32" if a.fp32_activations else "stored in bf16 between layers (images, scores, normalisation statistics and all accumulation fp32)") +
                                    ", NHWC; conv operands bf16 on MFMA with fp32 accumulate",
                        "activation_storage": "fp32" if a.fp32_activations else "bf16",
-                       "global_batch": world * BATCH, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "global_batch": world * BATCH, "parallelism": f"dp{world}", "hip_graph": bool(use_graph), "concurrent_chains": not a.one_stream,
                        "losses_finite": finite},
             "roofline": roofline,
         }

@@ -218,30 +218,54 @@ def _dma_ok(t, ic, oc, precision):
             and t.numel() * 2 < (1 << 31) - (1 << 21))   # the kernel addresses its input with 32-bit buffer offsets
 
 
+class _Image:
+    """A cached packed weight image and what it was made from / on."""
+    __slots__ = ("ptr", "version", "shape", "buf", "desc", "wref", "stream", "event")
+
+    def mark_packed(self, w):
+        """Called right after a pack launch on the current stream."""
+        self.ptr, self.version, self.shape = w.data_ptr(), w._version, tuple(w.shape)
+        st = torch.cuda.current_stream(w.device)
+        self.stream = st.cuda_stream
+        self.event = torch.cuda.Event()
+        self.event.record(st)
+
+    def ready(self, w):
+        """Makes the current stream wait for the pack if that ran on another stream (two chains of one training phase on
+        two streams share the images)."""
+        st = torch.cuda.current_stream(w.device)
+        if st.cuda_stream != self.stream:
+            st.wait_event(self.event)
+        return self.buf
+
+
 def _packed(desc, w, pass_, wkey):
     """bf16 image of w for `pass_`; cached per registered key and refreshed when the weight's version moved."""
     L = _lib.lib()
     ck = (wkey, pass_, int(desc.precision))
     if wkey:
         ent = _wcache.get(ck)
-        if ent is not None and ent[0] == w.data_ptr() and ent[1] == w._version and ent[2] == tuple(w.shape):
-            return ent[3]
-        if ent is not None and w.dtype == torch.float32 and ent[0] == w.data_ptr() and ent[2] == tuple(w.shape):
-            # same storage, new values: refresh the image in place (keeps repack() able to find it)
-            _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), 1.0,
-                                        ctypes.c_void_p(ent[3].data_ptr()), _stream()), "gc_pack_weight")
-            _wcache[ck] = (w.data_ptr(), w._version, tuple(w.shape), ent[3], ent[4], ent[5])
-            return ent[3]
-    if w.dtype != torch.float32:
-        w = w.float()
+        if ent is not None and ent.ptr == w.data_ptr() and ent.shape == tuple(w.shape):
+            if ent.version == w._version:
+                return ent.ready(w)
+            if w.dtype == torch.float32:
+                # same storage, new values: refresh the image in place (keeps repack() able to find it)
+                _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), 1.0,
+                                            ctypes.c_void_p(ent.buf.data_ptr()), _stream()), "gc_pack_weight")
+                ent.mark_packed(w)
+                return ent.buf
+    w32 = w if w.dtype == torch.float32 else w.float()
     nbytes = L.gc_packed_weight_bytes(ctypes.byref(desc), pass_)
     if nbytes == 0:
         _lib.check(-1, "gc_packed_weight_bytes")
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), 1.0,
+    _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w32.data_ptr()), _lib.strides4(w32), 1.0,
                                 ctypes.c_void_p(buf.data_ptr()), _stream()), "gc_pack_weight")
     if wkey:
-        _wcache[ck] = (w.data_ptr(), w._version, tuple(w.shape), buf, ConvDesc.from_buffer_copy(desc), weakref.ref(w))
+        ent = _Image()
+        ent.buf, ent.desc, ent.wref = buf, ConvDesc.from_buffer_copy(desc), weakref.ref(w)
+        ent.mark_packed(w)
+        _wcache[ck] = ent
     return buf
 
 
@@ -253,21 +277,21 @@ def repack(wkeys):
     for ck, ent in _wcache.items():
         if ck[0] not in wkeys:
             continue
-        w = ent[5]()
-        if w is None or w.dtype != torch.float32 or w.data_ptr() != ent[0] or tuple(w.shape) != ent[2] or w._version == ent[1]:
+        w = ent.wref()
+        if w is None or w.dtype != torch.float32 or w.data_ptr() != ent.ptr or tuple(w.shape) != ent.shape or w._version == ent.version:
             continue
         jobs.append((ck, ent, w))
     if not jobs:
         return 0
     n = len(jobs)
-    descs = (ConvDesc * n)(*[e[4] for _, e, _ in jobs])
+    descs = (ConvDesc * n)(*[e.desc for _, e, _ in jobs])
     passes = (ctypes.c_int32 * n)(*[ck[1] for ck, _, _ in jobs])
     ws = (ctypes.c_void_p * n)(*[w.data_ptr() for _, _, w in jobs])
     strides = (ctypes.c_int64 * (4 * n))(*[s_ for _, _, w in jobs for s_ in w.stride()])
-    packed = (ctypes.c_void_p * n)(*[e[3].data_ptr() for _, e, _ in jobs])
+    packed = (ctypes.c_void_p * n)(*[e.buf.data_ptr() for _, e, _ in jobs])
     _lib.check(_lib.lib().gc_pack_weights(n, descs, passes, ws, strides, None, packed, _stream()), "gc_pack_weights")
-    for ck, e, w in jobs:
-        _wcache[ck] = (e[0], w._version, e[2], e[3], e[4], e[5])
+    for _, e, w in jobs:
+        e.mark_packed(w)
     return n
 
 

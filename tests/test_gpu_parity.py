@@ -486,18 +486,20 @@ def test_full_size_properties(gan):
         assert rel(y12, (y + 2 * y2)) < 5e-5
 
 
-@pytest.mark.parametrize("batched,fused_adam,prec,act_dtype,tol",
-                         [(False, False, "fp32x3", torch.float32, 5e-3), (True, False, "fp32x3", torch.float32, 5e-3),
-                          (True, True, "fp32x3", torch.float32, 5e-3), (True, True, "bf16", torch.float32, 1.5e-2),
-                          (True, True, "bf16", torch.bfloat16, 1.5e-2)],
+@pytest.mark.parametrize("batched,fused_adam,prec,act_dtype,tol,two_streams",
+                         [(False, False, "fp32x3", torch.float32, 5e-3, False), (True, False, "fp32x3", torch.float32, 5e-3, False),
+                          (True, True, "fp32x3", torch.float32, 5e-3, False), (True, True, "bf16", torch.float32, 1.5e-2, False),
+                          (True, True, "bf16", torch.bfloat16, 1.5e-2, False), (True, True, "fp32x3", torch.float32, 5e-3, True),
+                          (True, True, "bf16", torch.bfloat16, 1.5e-2, True), (False, True, "fp32x3", torch.float32, 5e-3, True)],
                          ids=["separate_passes", "real_fake_batched", "real_fake_batched_fused_adam", "bf16_operands",
-                              "bf16_operands_bf16_activations"])
-def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched, fused_adam, prec, act_dtype, tol):
+                              "bf16_operands_bf16_activations", "two_streams_fp32x3", "two_streams_bf16", "three_streams_fp32x3"])
+def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched, fused_adam, prec, act_dtype, tol, two_streams):
     """Full-size WGAN-GP-64 (hidden 64) at batch 64 with Adam: five critic iterations + one generator iteration
     of the reference (golden losses), fp32x3 path; weights and inputs regenerated from the recorded seeds.
     `batched` runs the real and fake critic passes as one batch of 2B; the last parameter set is the benchmark's
     setting (bf16 MFMA operands, activations stored in bf16, fused Adam): measured deviations of the critic losses from
-    the reference's are 6e-4 (fp32x3), 6.5e-3 (bf16 operands) and 5e-3 (bf16 operands and storage)."""
+    the reference's are 6e-4 (fp32x3), 6.5e-3 (bf16 operands) and 5e-3 (bf16 operands and storage).  `two_streams` runs the
+    penalty chain and the real + fake chain of each critic iteration on two streams and adds their gradients."""
     from gan_amd.harness import basic_gans as H
     rec = json.load(open(os.path.join(golden_dir, "wgangp_losses.json")))
     cfg = rec["config"]
@@ -505,7 +507,7 @@ def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched, fu
     try:
         tr = H.WganGpTrainer(cfg["B"], cfg["hidden_dim"], cfg["nz"], cfg["res"], lr=cfg["lr"], betas=tuple(cfg["betas"]),
                              seed=cfg["seed"], capturable=False, batch_real_fake=batched, fused_adam=fused_adam,
-                             activation_dtype=act_dtype)
+                             activation_dtype=act_dtype, two_streams=two_streams)
         # same init as the reference run: seed, then G init, then D init on the CPU generator
         torch.manual_seed(cfg["seed"])
         G = R.Generator(cfg["nz"], cfg["hidden_dim"], 3, resolution=cfg["res"]); G.apply(R.weights_init)
@@ -642,7 +644,7 @@ def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coars
 
 
 @pytest.mark.parametrize("fused_adam", [False, True], ids=["torch_adam", "fused_adam"])
-@pytest.mark.parametrize("overlap", [False, True], ids=["serial_backward", "wgrad_on_side_stream"])
+@pytest.mark.parametrize("overlap", [False, True, "two_streams"], ids=["serial_backward", "wgrad_on_side_stream", "two_chain_streams"])
 @pytest.mark.parametrize("with_reducer", [False, True], ids=["one_graph", "graph_per_phase"])
 def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused_adam):
     """The WGAN-GP cycle recorded into HIP graphs (the benchmark's mode; with a gradient reducer: one graph per
@@ -652,10 +654,11 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     from gan_amd.ddp import GradReducer
     from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
     B = 8
+    two_streams, overlap = overlap == "two_streams", overlap is True
 
-    def make():
+    def make(two_streams=False):
         tr = WganGpTrainer(B, 32, 100, 64, device="cuda:0", reducer_factory=GradReducer if with_reducer else None,
-                           capturable=True, batch_real_fake=True, fused_adam=fused_adam,
+                           capturable=True, batch_real_fake=True, fused_adam=fused_adam, two_streams=two_streams,
                            activation_dtype=torch.bfloat16 if fused_adam else torch.float32)   # "fused_adam" = the benchmark's set-up
         g = torch.Generator().manual_seed(5001)
         real, zs = synth_inputs(g, B, 100, 64, 6)
@@ -666,7 +669,7 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     # Adam's normalised steps amplify last-bit differences to a per cent of the losses within a cycle.
     gan.set_split_reduction(False)
     try:
-        a, b = make(), make()
+        a, b = make(), make(two_streams)       # (the eager twin always runs the plain one-stream iteration)
         ref = [a.cycle_eager().cpu() for _ in range(2 + 3)]
         gan.set_backward_overlap(overlap)     # the recorded (and its warm-up) cycles fork the weight gradients to a side stream
         b.capture(warmup=2)

@@ -1,5 +1,6 @@
 """Developer tool: A/B timing of the recorded WGAN-GP cycle inside ONE process (box-to-box spread is about 2 %, more than
-most single changes): python tools/ab_bench.py  -> ms per cycle with and without the multi-weight re-pack."""
+most single changes): python tools/ab_bench.py [--what two_streams|repack]  -> ms per cycle with and without the option."""
+import argparse
 import os
 import sys
 import time
@@ -8,15 +9,22 @@ import torch
 import gan_amd
 from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--what", default="two_streams", choices=["two_streams", "three_chains", "repack"])
+ap.add_argument("--batch", type=int, default=256)
+args = ap.parse_args()
 
-def make(repack):
-    tr = WganGpTrainer(256, 64, 100, 64, device="cuda:0", capturable=True, batch_real_fake=True, fused_adam=True, activation_dtype=torch.bfloat16)
-    if not repack:
+
+def make(on):
+    # three_chains: real, fake and penalty passes on three streams against real + fake batched beside the penalty pass
+    tr = WganGpTrainer(args.batch, 64, 100, 64, device="cuda:0", capturable=True, batch_real_fake=not (on and args.what == "three_chains"),
+                       fused_adam=True, activation_dtype=torch.bfloat16, two_streams=(on and args.what == "two_streams") or args.what == "three_chains")
+    if args.what == "repack" and not on:
         tr.opt_D.repack_after_step()
         tr.opt_G.repack_after_step()
     g = torch.Generator().manual_seed(5001)
-    real, zs = synth_inputs(g, 256, 100, 64, 6)
-    tr.set_inputs(real, zs, torch.rand(5, 256, 1, 1, 1, generator=g))
+    real, zs = synth_inputs(g, args.batch, 100, 64, 6)
+    tr.set_inputs(real, zs, torch.rand(5, args.batch, 1, 1, 1, generator=g))
     tr.capture(warmup=2)
     return tr
 
@@ -34,4 +42,6 @@ def timed(tr, n=20):
 
 a, b = make(True), make(False)
 for rnd in range(3):
-    print(f"round {rnd}: multi-weight re-pack {timed(a):.3f} ms   per-layer re-pack {timed(b):.3f} ms", flush=True)
+    print(f"round {rnd}: {args.what} on {timed(a):.3f} ms   off {timed(b):.3f} ms", flush=True)
+print("losses on :", a.static_out.cpu().numpy().round(4).tolist())
+print("losses off:", b.static_out.cpu().numpy().round(4).tolist())

@@ -18,14 +18,27 @@ cycles = prof["warmup"] + prof["steps"] + 2 + 2      # replays (warm-up + timed)
 rows = list(csv.DictReader(open(os.path.join(d, "bench_kernel_stats.csv"))))
 tot = sum(float(x["TotalDurationNs"]) for x in rows) / 1e6 / cycles
 lib = sum(float(x["TotalDurationNs"]) for x in rows if x["Name"].removeprefix("void ").startswith("gc::")) / 1e6 / cycles
-print(f"# Measurement set {tag}: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']}` on one MI355X\n")
+print(f"# Measurement set {tag}: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {prof['steps']} --warmup {prof['warmup']} --one-stream` on one MI355X\n")
 cb = line.get("cpu_baseline", {})
 print(f"Unprofiled default run (`python bench.py`, `{tag}_bench_line.json`): **{line['value']:.0f} img/s, {line['ms_per_step']:.2f} ms per cycle**; "
       f"dominant conv kernel `{r['kernel']}`: {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of the dense bf16 peak, average launch "
       f"{r['avg_launch_us']:.1f} us" + (f", {r['traffic'] / 1e6:.1f} MB HBM traffic per launch" if r.get("traffic") else "") +
       f"; CPU baseline {cb.get('value', float('nan')):.1f} img/s on {cb.get('cores')} cores.\n")
-print(f"Under the profiler: {prof['value']:.0f} img/s, {prof['ms_per_step']:.2f} ms per cycle.  {cycles} cycles were traced "
+print(f"Under the profiler with `--one-stream` (every kernel alone on the GPU: the durations below are what the roofline figure is "
+      f"about): {prof['value']:.0f} img/s, {prof['ms_per_step']:.2f} ms per cycle.  {cycles} cycles were traced "
       f"(the per-cycle columns divide by {cycles}).")
+cpath = os.path.join(d, "bench_line_under_rocprof_concurrent.json")
+if os.path.exists(cpath):
+    conc = last_json(cpath)
+    crow = {x["Name"]: x for x in csv.DictReader(open(os.path.join(d, "bench_kernel_stats_concurrent.csv")))}
+    key = next((k for k in crow if r["kernel"] in k), None)
+    one = next((x for x in rows if r["kernel"] in x["Name"]), None)
+    extra = ""
+    if key and one:
+        extra = (f"; the dominant kernel's average launch there is {float(crow[key]['TotalDurationNs']) / int(crow[key]['Calls']) / 1e3:.1f} us "
+                 f"against {float(one['TotalDurationNs']) / int(one['Calls']) / 1e3:.1f} us alone, because two kernels share the GPU")
+    print(f"The default command (independent chains of a critic iteration on concurrent streams) under the profiler: {conc['value']:.0f} img/s, "
+          f"{conc['ms_per_step']:.2f} ms per cycle (`{tag}_bench_kernel_stats_concurrent.csv`){extra}.")
 print(f"GPU kernel time per cycle {tot:.2f} ms, of which library (`gc::`) kernels {lib:.2f} ms ({100 * lib / tot:.0f} %).\n")
 print("| kernel | launches / cycle | avg µs | ms / cycle | % |\n|---|---|---|---|---|")
 for x in sorted(rows, key=lambda x: -float(x["TotalDurationNs"]))[:36]:
