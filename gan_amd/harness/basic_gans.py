@@ -126,16 +126,17 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
 
     side_chains = [penalty_chain, fake_chain] if split_real_fake else [penalty_chain]
     results = []
-    for i, chain in enumerate(side_chains):
-        st = _side_stream(real.device, i)
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            results.append(chain())
-    if split_real_fake:
-        g_main, d_real = real_chain()
-        d_fake = results[1][1]
-    else:
-        g_main, (d_real, d_fake) = both_chain()
+    with gops.suspended_backward_overlap():
+        for i, chain in enumerate(side_chains):
+            st = _side_stream(real.device, i)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                results.append(chain())
+        if split_real_fake:
+            g_main, d_real = real_chain()
+            d_fake = results[1][1]
+        else:
+            g_main, (d_real, d_fake) = both_chain()
     for i in range(len(side_chains)):      # (each fork waits for the main stream again, so a side stream does not reuse
         main.wait_stream(_side_stream(real.device, i))          # its blocks before the additions below have run)
     for j, p in enumerate(params):

@@ -99,6 +99,20 @@ def get_backward_overlap():
     return _overlap
 
 
+class suspended_backward_overlap:
+    """Context: no weight-gradient side stream inside.  For callers that already run independent chains on streams of
+    their own: a side stream forked from a forked stream inside a HIP-graph capture crashed hipStreamEndCapture
+    (ROCm 7.2), and the chains fill the GPU anyway."""
+
+    def __enter__(self):
+        global _overlap
+        self.was, _overlap = _overlap, False
+
+    def __exit__(self, *exc):
+        global _overlap
+        _overlap = self.was
+
+
 class _SideLaunch:
     """Context of one weight-gradient launch on the side stream (entered by the autograd formulas)."""
     active = None

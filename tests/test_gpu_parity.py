@@ -644,7 +644,8 @@ def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coars
 
 
 @pytest.mark.parametrize("fused_adam", [False, True], ids=["torch_adam", "fused_adam"])
-@pytest.mark.parametrize("overlap", [False, True, "two_streams"], ids=["serial_backward", "wgrad_on_side_stream", "two_chain_streams"])
+@pytest.mark.parametrize("overlap", [False, True, "two_streams", "both"],
+                         ids=["serial_backward", "wgrad_on_side_stream", "two_chain_streams", "two_chain_streams_and_wgrad_streams"])
 @pytest.mark.parametrize("with_reducer", [False, True], ids=["one_graph", "graph_per_phase"])
 def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused_adam):
     """The WGAN-GP cycle recorded into HIP graphs (the benchmark's mode; with a gradient reducer: one graph per
@@ -654,7 +655,7 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     from gan_amd.ddp import GradReducer
     from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
     B = 8
-    two_streams, overlap = overlap == "two_streams", overlap is True
+    two_streams, overlap = overlap in ("two_streams", "both"), overlap in (True, "both")
 
     def make(two_streams=False):
         tr = WganGpTrainer(B, 32, 100, 64, device="cuda:0", reducer_factory=GradReducer if with_reducer else None,
