@@ -19,7 +19,7 @@ def per_kernel(path, counter):
             k = row["Kernel_Name"]
             if k.startswith("void "):
                 k = k[5:]
-            k = k.split("(")[0]
+            k = k.replace("(anonymous namespace)::", "").split("(")[0]
             acc[k][0] += 1
             acc[k][1] += float(row["Counter_Value"]) * 1024.0
     return acc

@@ -36,14 +36,16 @@ if os.path.exists(cpath):
     extra = ""
     if key and one:
         extra = (f"; the dominant kernel's average launch there is {float(crow[key]['TotalDurationNs']) / int(crow[key]['Calls']) / 1e3:.1f} us "
-                 f"against {float(one['TotalDurationNs']) / int(one['Calls']) / 1e3:.1f} us alone, because two kernels share the GPU")
+                 f"against {float(one['TotalDurationNs']) / int(one['Calls']) / 1e3:.1f} us with one stream")
     print(f"The default command (independent chains of a critic iteration on concurrent streams) under the profiler: {conc['value']:.0f} img/s, "
-          f"{conc['ms_per_step']:.2f} ms per cycle (`{tag}_bench_kernel_stats_concurrent.csv`){extra}.")
+          f"{conc['ms_per_step']:.2f} ms per cycle (`{tag}_bench_kernel_stats_concurrent.csv`){extra}.  Kernel tracing takes the "
+          f"concurrency away (the two modes run at the same speed under the profiler and the kernel durations agree), so the gain of the "
+          f"concurrent chains shows only in unprofiled runs.")
 print(f"GPU kernel time per cycle {tot:.2f} ms, of which library (`gc::`) kernels {lib:.2f} ms ({100 * lib / tot:.0f} %).\n")
 print("| kernel | launches / cycle | avg µs | ms / cycle | % |\n|---|---|---|---|---|")
 for x in sorted(rows, key=lambda x: -float(x["TotalDurationNs"]))[:36]:
     n, t = int(x["Calls"]), float(x["TotalDurationNs"])
-    print(f"| `{x['Name'].split('(')[0][:92]}` | {n / cycles:.1f} | {t / n / 1e3:.1f} | {t / 1e6 / cycles:.3f} | {100 * t / 1e6 / cycles / tot:.2f} |")
+    print(f"| `{x['Name'].replace('(anonymous namespace)::', '').split('(')[0][:92]}` | {n / cycles:.1f} | {t / n / 1e3:.1f} | {t / 1e6 / cycles:.3f} | {100 * t / 1e6 / cycles / tot:.2f} |")
 print(f"\nFull table: `{tag}_bench_kernel_stats.csv`.  HBM traffic per launch (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of one "
       f"eager cycle, FETCH_SIZE doubled as the gfx950 counter tallies a 128-byte request as 64): `{tag}_traffic.json` (copied to "
       "`bench_traffic.json`, which `bench.py` reads).\n\n```")
