@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--one-stream", action="store_true",
                     help="run the independent chains of a critic iteration (real + fake pass, gradient-penalty pass, the generator's "
                          "forward passes) one after the other instead of on streams of their own (measured: 14 %% slower)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="data parallel: BatchNorm statistics over all ranks (the single-device result on the global batch) "
+                         "instead of per rank (what the reference's DataParallel does)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32x3"])
     ap.add_argument("--fp32-activations", action="store_true",
                     help="store the activations between the layers in fp32 (default: bf16 storage, fp32 accumulation and statistics)")
@@ -98,6 +101,10 @@ def main():
     tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),
                        capturable=use_graph, batch_real_fake=True, fused_adam=True,
                        activation_dtype=torch.float32 if a.fp32_activations else torch.bfloat16, two_streams=not a.one_stream)
+    if a.sync_bn:
+        if use_graph:
+            raise SystemExit("--sync-bn exchanges statistics inside the forward pass: run it with --ddp-eager (collectives are never captured)")
+        gan_amd.nn.convert_sync_batchnorm(tr.net_G)
     if distributed:  # replicas start from identical parameters
         for p in list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers()):
             dist.broadcast(p.data, 0)
@@ -167,7 +174,7 @@ def main():
                                    ("fp32" if a.fp32_activations else "stored in bf16 between layers (images, scores, normalisation statistics and all accumulation fp32)") +
                                    ", NHWC; conv operands bf16 on MFMA with fp32 accumulate",
                        "activation_storage": "fp32" if a.fp32_activations else "bf16",
-                       "global_batch": world * BATCH, "parallelism": f"dp{world}", "hip_graph": bool(use_graph), "concurrent_chains": not a.one_stream,
+                       "global_batch": world * BATCH, "parallelism": f"dp{world}", "hip_graph": bool(use_graph), "concurrent_chains": not a.one_stream, "batchnorm_statistics": "all ranks" if a.sync_bn else "per rank",
                        "losses_finite": finite},
             "roofline": roofline,
         }

@@ -14,6 +14,11 @@
 //      in the forward pass), derives a / b (or the two backward means) and updates the running statistics;
 //   3. apply: same geometry as 1, elementwise, optionally writing a bf16 copy for the convolution that reads it next.
 //
+// Statistics over several GPUs (one process per GPU, each holding a shard of the batch): the forward pass is split into
+// "statistics of my shard" (launches 1-2), an exchange of (mean, M2, count) done by the caller, and the evaluation-mode
+// call with the merged statistics (launch 3); the backward pass into "sums of my shard" (launches 1-2), an exchange of
+// the two sums, and the apply launch with the merged means.
+//
 // Conditional mode (reference BigGAN/model.py:61-77: gamma[n, c] * BatchNorm(x) + beta[n, c] with per-sample gain and
 // bias from a Linear layer): gamma / beta are [N, C]; slabs never cross a sample, so a slab has one gain per channel.
 // Backward: with g = gy * act', ggamma[n, c] = sum_hw g * xh and gbeta[n, c] = sum_hw g per sample, and
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
     const float mean = a, var = b / (float)p.P;
     const float r = rsqrtf(var + p.eps);
     p.save_mean[c] = mean;
-    p.save_rstd[c] = r;
+    if (p.save_rstd != nullptr) p.save_rstd[c] = r;     // (null in the statistics-only call)
     const float ga = p.gamma != nullptr ? p.gamma[c] : 1.f, be = p.beta != nullptr ? p.beta[c] : 0.f;
     p.coef[c] = ga * r;
     p.coef[p.C + c] = be - mean * ga * r;
@@ -399,26 +404,31 @@ int gc_cond_batchnorm_act_fwd(const void* x, void* y, const float* gamma, const 
 
 static int bn_backward(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
                        const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
-                       size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream, int32_t nsamp) {
+                       size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream, int32_t nsamp,
+                       int phase = 0, const float* means = nullptr) {
+  // phase 0: everything;  1: the two sums only (gx unused);  2: apply only, with `means` = [2][C] (sum g, sum g*xh) / count
   if (dtype != GC_F32 && dtype != GC_BF16) { set_error("batchnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
   if (dtype == GC_BF16 && gx_bf16 != nullptr) { set_error("batchnorm: bf16 tensors need no bf16 copy"); return GC_BAD_ARGUMENT; }
   if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
   if (act != GC_ACT_NONE && act != GC_ACT_RELU && act != GC_ACT_LRELU) { set_error("batchnorm: activation must be none, ReLU or LeakyReLU"); return GC_BAD_ARGUMENT; }
   if (C % 4 != 0) { set_error("batchnorm: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
-  if (x == nullptr || gy == nullptr || gx == nullptr || ggamma == nullptr || gbeta == nullptr || save_mean == nullptr ||
-      save_rstd == nullptr || workspace == nullptr) { set_error("batchnorm: null pointer"); return GC_BAD_ARGUMENT; }
+  if (x == nullptr || gy == nullptr || (gx == nullptr && phase != 1) || ((ggamma == nullptr || gbeta == nullptr) && phase != 2) ||
+      save_mean == nullptr || save_rstd == nullptr || (workspace == nullptr && phase != 2) || (means == nullptr && phase == 2)) {
+    set_error("batchnorm: null pointer"); return GC_BAD_ARGUMENT;
+  }
   const unsigned am = dtype == GC_F32 ? 15 : 7;
   if (misaligned(x, am) || misaligned(gy, am) || misaligned(gx, am) || misaligned(gx_bf16, 7) || misaligned(workspace, 15) ||
-      misaligned(gamma, 15) || misaligned(beta, 15) || misaligned(save_mean, 15) || misaligned(save_rstd, 15)) {
+      misaligned(gamma, 15) || misaligned(beta, 15) || misaligned(save_mean, 15) || misaligned(save_rstd, 15) || misaligned(means, 15)) {
     set_error("batchnorm: misaligned pointer"); return GC_BAD_ARGUMENT;
   }
   hipStream_t s = (hipStream_t)stream;
   if (P == 0) {
+    if (phase == 2) return GC_OK;
     if (zero_fill(ggamma, sizeof(float) * C, s) != GC_OK) return GC_HIP_ERROR;
     return zero_fill(gbeta, sizeof(float) * C, s);
   }
   if (nsamp > 0 && (gamma == nullptr || beta == nullptr)) { set_error("batchnorm: conditional mode needs gain and bias"); return GC_BAD_ARGUMENT; }
-  const size_t need = bn_workspace(P, C, nsamp);
+  const size_t need = phase == 2 ? 0 : bn_workspace(P, C, nsamp);
   if (workspace_bytes < need) { set_error("batchnorm: workspace of %zu bytes given, %zu needed", workspace_bytes, need); return GC_WORKSPACE_TOO_SMALL; }
   BnParams p{};
   p.x = x; p.gy = gy; p.out = gx; p.out_bf16 = (uint16_t*)gx_bf16;
@@ -429,16 +439,18 @@ static int bn_backward(const void* x, const void* gy, const float* gamma, const 
   p.P = (int32_t)P; p.C = C; p.slope = slope; p.act = act;
   bn_geometry(p);
   p.part = (float*)workspace;
-  p.coef = p.part + (size_t)p.slabs * C * 2;
+  p.coef = phase == 2 ? const_cast<float*>(means) : p.part + (size_t)p.slabs * C * 2;
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
-  {
-    ProfScope ps("gc::bn_partial_kernel<1>", 0.0, s);
-    if (dtype == GC_F32) hipLaunchKernelGGL((bn_partial_kernel<1, float>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((bn_partial_kernel<1, uint16_t>), grid, block, 0, s, p);
+  if (phase != 2) {
+    {
+      ProfScope ps("gc::bn_partial_kernel<1>", 0.0, s);
+      if (dtype == GC_F32) hipLaunchKernelGGL((bn_partial_kernel<1, float>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((bn_partial_kernel<1, uint16_t>), grid, block, 0, s, p);
+    }
+    { ProfScope ps("gc::bn_finalize_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, p); }
   }
-  { ProfScope ps("gc::bn_finalize_kernel<1>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, p); }
-  {
+  if (phase != 1) {
     ProfScope ps("gc::bn_apply_kernel<1>", 0.0, s);
     if (dtype == GC_F32) hipLaunchKernelGGL((bn_apply_kernel<1, float>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((bn_apply_kernel<1, uint16_t>), grid, block, 0, s, p);
@@ -459,6 +471,46 @@ int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma,
   if (N <= 0 || HW <= 0) { set_error("batchnorm: conditional mode needs N > 0 and HW > 0"); return GC_BAD_ARGUMENT; }
   return bn_backward(x, gy, gamma, beta, save_mean, save_rstd, gx, nullptr, ggamma, gbeta, workspace, workspace_bytes, (int64_t)N * HW, C,
                      dtype, act, slope, stream, N);
+}
+
+int gc_batchnorm_stats(const void* x, float* mean, float* var_unbiased, void* workspace, size_t workspace_bytes, int64_t P, int32_t C,
+                       int32_t dtype, void* stream) {
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("batchnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
+  if (P <= 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
+  if (C % 4 != 0) { set_error("batchnorm: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
+  if (x == nullptr || mean == nullptr || var_unbiased == nullptr || workspace == nullptr) { set_error("batchnorm: null pointer"); return GC_BAD_ARGUMENT; }
+  if (misaligned(x, dtype == GC_F32 ? 15 : 7) || misaligned(workspace, 15)) { set_error("batchnorm: misaligned pointer"); return GC_BAD_ARGUMENT; }
+  const size_t need = bn_workspace(P, C, 0);
+  if (workspace_bytes < need) { set_error("batchnorm: workspace of %zu bytes given, %zu needed", workspace_bytes, need); return GC_WORKSPACE_TOO_SMALL; }
+  BnParams p{};
+  p.x = x; p.save_mean = mean; p.save_var = var_unbiased;
+  p.P = (int32_t)P; p.C = C; p.eps = 1.f; p.training = 1;
+  bn_geometry(p);
+  p.part = (float*)workspace;
+  p.coef = p.part + (size_t)p.slabs * C * 2;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = (C / 4 + kQB - 1) / kQB;
+  {
+    ProfScope ps("gc::bn_partial_kernel<0>", 0.0, s);
+    if (dtype == GC_F32) hipLaunchKernelGGL((bn_partial_kernel<0, float>), dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((bn_partial_kernel<0, uint16_t>), dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
+  }
+  { ProfScope ps("gc::bn_finalize_kernel<0>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + kFinCh - 1) / kFinCh), dim3(kThreads), 0, s, p); }
+  return check_hip(hipGetLastError(), "batchnorm statistics launch");
+}
+
+int gc_batchnorm_act_bwd_sums(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                              const float* save_rstd, float* ggamma, float* gbeta, void* workspace, size_t workspace_bytes, int64_t P,
+                              int32_t C, int32_t dtype, int32_t act, float slope, void* stream) {
+  return bn_backward(x, gy, gamma, beta, save_mean, save_rstd, nullptr, nullptr, ggamma, gbeta, workspace, workspace_bytes, P, C, dtype, act,
+                     slope, stream, 0, 1);
+}
+
+int gc_batchnorm_act_bwd_apply(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_rstd, const float* means, void* gx, void* gx_bf16, int64_t P, int32_t C, int32_t dtype,
+                               int32_t act, float slope, void* stream) {
+  return bn_backward(x, gy, gamma, beta, save_mean, save_rstd, gx, gx_bf16, nullptr, nullptr, nullptr, 0, P, C, dtype, act, slope, stream, 0,
+                     2, means);
 }
 
 int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,

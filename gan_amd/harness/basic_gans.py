@@ -139,14 +139,17 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
             g_main, (d_real, d_fake) = both_chain()
     for i in range(len(side_chains)):      # (each fork waits for the main stream again, so a side stream does not reuse
         main.wait_stream(_side_stream(real.device, i))          # its blocks before the additions below have run)
-    for j, p in enumerate(params):
-        g = g_main[j]
-        for r in results:
-            g = g.add_(r[0][j])
-        if p.grad is None:
+    g_main = list(g_main)
+    for r in results:
+        torch._foreach_add_(g_main, list(r[0]))
+    if all(p.grad is None for p in params):
+        for p, g in zip(params, g_main):
             p.grad = g
-        else:
-            p.grad.add_(g)
+    else:
+        for p, g in zip(params, g_main):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        torch._foreach_add_([p.grad for p in params], g_main)
     return d_real, d_fake, results[0][1]
 
 

@@ -126,13 +126,18 @@ class BatchNormAct2d(torch.nn.Module):
     same three for the backward pass).  Parameters, buffers and their names are BatchNorm2d's (weight, bias,
     running_mean, running_var, num_batches_tracked), so it takes the place of the reference's
     `BatchNorm2d(out_dim), ReLU(True)` pair (BasicGANs/models.py:37) without changing a state_dict; the activation
-    module that follows it in the reference holds no state.  First-order gradients only; float32, channels % 4 == 0."""
+    module that follows it in the reference holds no state.  First-order gradients only; float32, channels % 4 == 0.
+
+    `sync_stats=True` (or convert_sync_batchnorm(net)): in training mode the statistics are those of the batch held by
+    all ranks of `process_group` (one process per GPU, each with a shard), i.e. the single-device result on the whole
+    batch; default: per-rank statistics, as under the reference's torch.nn.DataParallel."""
 
     _ACTS = {None: 0, "relu": 1, "leaky_relu": 2}
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, activation="relu",
-                 negative_slope=0.2):
+                 negative_slope=0.2, sync_stats=False, process_group=None):
         super().__init__()
+        self.sync_stats, self.process_group = sync_stats, process_group
         if activation not in self._ACTS:
             raise ValueError(f"activation must be one of {list(self._ACTS)}")
         if momentum is None:
@@ -169,8 +174,11 @@ class BatchNormAct2d(torch.nn.Module):
             if act == 1:
                 return torch.relu(y)
             return torch.nn.functional.leaky_relu(y, self.negative_slope) if act == 2 else y
-        y, mean, _, var = ops.batchnorm_act(input, self.weight, self.bias, self.running_mean, self.running_var, training,
-                                            float(self.eps), act, float(self.negative_slope))
+        if training and self.sync_stats:
+            y, mean, var = ops.sync_batchnorm_act(input, self.weight, self.bias, self.eps, act, self.negative_slope, self.process_group)
+        else:
+            y, mean, _, var = ops.batchnorm_act(input, self.weight, self.bias, self.running_mean, self.running_var, training,
+                                                float(self.eps), act, float(self.negative_slope))
         if training and self.track_running_stats:
             with torch.no_grad():
                 ops.batchnorm_update_running_(self.running_mean, self.running_var, self.num_batches_tracked, mean, var, float(self.momentum))
@@ -179,3 +187,12 @@ class BatchNormAct2d(torch.nn.Module):
     def extra_repr(self):
         return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine={self.affine}, "
                 f"track_running_stats={self.track_running_stats}, activation={self.activation}")
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """Switches every BatchNormAct2d of `module` to statistics over all ranks of `process_group` (the counterpart of
+    torch.nn.SyncBatchNorm.convert_sync_batchnorm for this package's fused layer).  Returns `module`."""
+    for m in module.modules():
+        if isinstance(m, BatchNormAct2d):
+            m.sync_stats, m.process_group = True, process_group
+    return module

@@ -757,6 +757,94 @@ def _bn_backward(ctx, gy, g_mean, g_rstd, g_var):
 torch.library.register_autograd("ganconv::batchnorm_act", _bn_backward, setup_context=_bn_setup)
 
 
+# ---- BatchNorm with statistics over all ranks of a process group ---------------------------------------------------
+class _SyncBatchNormAct(torch.autograd.Function):
+    """act(batch_norm(x)) where x is this rank's shard of the batch and the statistics are those of the whole batch:
+    the result (and the gradients) a single device would compute on the concatenated shards.  Two small all-reduces per
+    direction ([2C + 1] and [2C] floats).  First order only.  Returns (y, mean, unbiased variance) of the whole batch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, act, slope, group):
+        import torch.distributed as dist
+        _check_cuda(x, weight, bias)
+        x = _nhwc(x)
+        N, C, H, W = x.shape
+        P = N * H * W
+        dt = _dtype_code(x)
+        L = _lib.lib()
+        dev = x.device
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(max(P, 1), C), 16), dtype=torch.uint8, device=dev)
+        m, v = torch.zeros(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev)
+        if P > 0:
+            _lib.check(L.gc_batchnorm_stats(_ptr(x), _ptr(m), _ptr(v), _ptr(ws), ws.numel(), P, C, dt, _stream()), "gc_batchnorm_stats")
+        if world > 1:
+            # the shard means go first, so that each rank can centre its squares on the mean of the whole batch before
+            # they are added (no cancellation for channels with |mean| >> std)
+            head = torch.cat([m * P, torch.full((1,), float(P), dtype=torch.float32, device=dev)])
+            dist.all_reduce(head, group=group)
+            count = head[C]
+            mean = head[:C] / count
+            m2 = v * max(P - 1, 0) + P * (m - mean) ** 2
+            dist.all_reduce(m2, group=group)
+        else:
+            count = torch.full((), float(P), dtype=torch.float32, device=dev)
+            mean, m2 = m, v * max(P - 1, 0)
+        var_b = m2 / count
+        var_u = m2 / torch.clamp(count - 1, min=1)
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        save_mean, rstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        mean, var_b = mean.contiguous(), var_b.contiguous()
+        if P > 0:
+            _lib.check(L.gc_batchnorm_act_fwd(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _ptr(mean),
+                                              _ptr(var_b), None, _ptr(save_mean), _ptr(rstd), None, _ptr(ws), ws.numel(), P, C,
+                                              dt, eps, 0.0, act, slope, 0, _stream()), "gc_batchnorm_act_fwd")
+        else:
+            save_mean.copy_(mean)
+            rstd.copy_(torch.rsqrt(var_b + eps))
+        ctx.save_for_backward(x, weight, bias, save_mean, rstd, count)
+        ctx.cfg = (act, slope, group)
+        ctx.mark_non_differentiable(mean, var_u)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        import torch.distributed as dist
+        x, weight, bias, mean, rstd, count = ctx.saved_tensors
+        act, slope, group = ctx.cfg
+        if gy.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("ganconv: batchnorm has no second-order backward")
+        gy = _nhwc(gy)
+        if gy.dtype != x.dtype:
+            raise RuntimeError(f"ganconv: norm kernels take tensors of one dtype (got {x.dtype} and {gy.dtype})")
+        N, C, H, W = x.shape
+        P = N * H * W
+        dt = _dtype_code(x)
+        L = _lib.lib()
+        sums = torch.zeros(2, C, dtype=torch.float32, device=x.device)        # [sum g | sum g * xh]
+        if P > 0:
+            ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
+            _lib.check(L.gc_batchnorm_act_bwd_sums(_ptr(x), _ptr(gy), _optr(weight), _optr(bias), _ptr(mean), _ptr(rstd), _ptr(sums[1]),
+                                                   _ptr(sums[0]), _ptr(ws), ws.numel(), P, C, dt, act, slope, _stream()),
+                       "gc_batchnorm_act_bwd_sums")
+        gb, gw = sums[0].clone(), sums[1].clone()      # parameter gradients stay per rank: the gradient reducer averages them
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(sums, group=group)
+        means = (sums / count).contiguous()
+        gx = torch.empty_like(x, memory_format=torch.channels_last)
+        if P > 0:
+            _lib.check(L.gc_batchnorm_act_bwd_apply(_ptr(x), _ptr(gy), _optr(weight), _optr(bias), _ptr(mean), _ptr(rstd), _ptr(means),
+                                                    _ptr(gx), _optr(_bf16_twin(gx)), P, C, dt, act, slope, _stream()),
+                       "gc_batchnorm_act_bwd_apply")
+        return gx, (gw if weight is not None else None), (gb if bias is not None else None), None, None, None, None
+
+
+def sync_batchnorm_act(x, weight, bias, eps, act, slope, process_group=None):
+    """Training-mode act(batch_norm(x)) with the statistics of the batch held by all ranks of `process_group`
+    (see _SyncBatchNormAct).  Returns (y, mean, unbiased variance)."""
+    return _SyncBatchNormAct.apply(x, weight, bias, float(eps), int(act), float(slope), process_group)
+
+
 # ---- self-attention over image positions (BigGAN/model.py:97-103) -----------------------------------------------
 def _attn_args(k, q, v):
     _check_cuda(k, q, v)

@@ -4,7 +4,11 @@ Drop-in for the reference's `torch.optim.Adam(net.parameters(), lr=..., betas=..
 Pix2Pix/train.py, StyleGAN/train.py, BigGAN/train.py): same constructor arguments for the features the reference uses
 (lr, betas, eps; weight_decay / amsgrad / maximize must stay at their defaults), same arithmetic in the same order.
 The step counter lives on the device, so step() can be recorded into a HIP graph.  State per parameter: `exp_avg`,
-`exp_avg_sq`; per group: `step` (a device float tensor shared by the group's parameters)."""
+`exp_avg_sq`; per group: `step` (a device float tensor shared by the group's parameters).
+
+`Adam.average_into(averaged_net, net, weight)` folds the reference's `moving_average(averaged_G, net_G, weight)`
+(StyleGAN/train.py:71-76, called after every generator step) into the step's launch; `moving_average` below is the
+stand-alone form with the reference's signature (two multi-tensor launches)."""
 import ctypes
 
 import torch
@@ -21,6 +25,27 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
         self._nets = []
+        self._ema = {}          # id(parameter) -> its moving average (a tensor of another module)
+        self._ema_weight = 0.999
+
+    def average_into(self, averaged, net, weight=0.999):
+        """Every later step() also updates `averaged`'s parameters as weight * averaged + (1 - weight) * updated parameter
+        of `net`, matched by name (parameters of `net` that this optimizer does not step, or that got no gradient in a
+        step, are not averaged by it: use moving_average for those)."""
+        if not 0.0 <= weight <= 1.0:
+            raise ValueError("weight must lie in [0, 1]")
+        avg = dict(averaged.named_parameters())
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        for k, p in net.named_parameters():
+            if id(p) not in mine:
+                continue
+            e = avg[k]
+            if e.shape != p.shape or e.dtype != torch.float32 or e.device != p.device or not e.is_contiguous():
+                raise RuntimeError(f"gan_amd.optim.Adam.average_into: {k} of the averaged module does not match the parameter")
+            self._ema[id(p)] = e
+        self._ema_weight = float(weight)
+        self._tables.clear()
+        return self
 
     def repack_after_step(self, *nets):
         """After every step, refresh the packed weight images of the gan_amd convolution modules of `nets` in one launch
@@ -30,7 +55,8 @@ class Adam(torch.optim.Optimizer):
 
     def _table(self, gi, params):
         """Host arrays of device pointers for the parameters that have a gradient; rebuilt when anything moved."""
-        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+        ema = [self._ema.get(id(p)) for p in params]
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), 0 if e is None else e.data_ptr()) for p, e in zip(params, ema))
         ent = self._tables.get(gi)
         if ent is not None and ent[0] == sig:
             return ent[1]
@@ -39,7 +65,8 @@ class Adam(torch.optim.Optimizer):
         st = [self.state[p] for p in params]
         arrays = (n, vp(*[p.data_ptr() for p in params]), vp(*[p.grad.data_ptr() for p in params]),
                   vp(*[s["exp_avg"].data_ptr() for s in st]), vp(*[s["exp_avg_sq"].data_ptr() for s in st]),
-                  i64(*[p.numel() for p in params]))
+                  i64(*[p.numel() for p in params]),
+                  vp(*[None if e is None else e.data_ptr() for e in ema]) if any(e is not None for e in ema) else None)
         self._tables[gi] = (sig, arrays)
         return arrays
 
@@ -64,11 +91,20 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             if "step" not in group:
                 group["step"] = torch.zeros((), dtype=torch.float32, device=params[0].device)
-            n, pp, gp, mp, vp, ne = self._table(gi, params)
+            n, pp, gp, mp, vp, ne, ep = self._table(gi, params)
             b1, b2 = group["betas"]
-            _lib.check(_lib.lib().gc_adam_step(n, pp, gp, mp, vp, ne, ctypes.c_void_p(group["step"].data_ptr()), float(group["lr"]),
-                                               float(b1), float(b2), float(group["eps"]),
-                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gc_adam_step")
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if ep is None:
+                _lib.check(_lib.lib().gc_adam_step(n, pp, gp, mp, vp, ne, ctypes.c_void_p(group["step"].data_ptr()), float(group["lr"]),
+                                                   float(b1), float(b2), float(group["eps"]), stream), "gc_adam_step")
+            else:
+                _lib.check(_lib.lib().gc_adam_ema_step(n, pp, gp, mp, vp, ep, self._ema_weight, ne, ctypes.c_void_p(group["step"].data_ptr()),
+                                                       float(group["lr"]), float(b1), float(b2), float(group["eps"]), stream),
+                           "gc_adam_ema_step")
+                for p in params:
+                    e = self._ema.get(id(p))
+                    if e is not None:
+                        torch.autograd.graph.increment_version(e)
             for p in params:     # the kernel wrote through raw pointers: tell autograd (and every cache keyed on the
                 torch.autograd.graph.increment_version(p)      # version, e.g. packed weight images) that p changed
         if self._nets:
@@ -77,3 +113,15 @@ class Adam(torch.optim.Optimizer):
                 from . import ops
                 ops.repack(keys)
         return loss
+
+
+@torch.no_grad()
+def moving_average(model_1, model_2, weight=0.999):
+    """model_1's parameters <- weight * model_1's + (1 - weight) * model_2's, matched by name (StyleGAN/train.py:71-76) as
+    two multi-tensor launches instead of two per parameter."""
+    p1, p2 = dict(model_1.named_parameters()), dict(model_2.named_parameters())
+    a = [p1[k].data for k in p1]
+    b = [p2[k].data for k in p1]
+    if a:
+        torch._foreach_mul_(a, weight)
+        torch._foreach_add_(a, b, alpha=1 - weight)

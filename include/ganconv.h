@@ -194,6 +194,23 @@ int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma,
                               const float* save_rstd, void* gx, float* ggamma, float* gbeta, void* workspace, size_t workspace_bytes,
                               int32_t N, int32_t HW, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
 
+/* BatchNorm over a batch that is sharded across GPUs (one process per GPU).  The reference's torch.nn.DataParallel
+ * (StyleGAN/train.py:121-125, BigGAN/train.py:150-154) normalises each replica with its own statistics; these three
+ * calls let a data-parallel host reproduce the single-device result of BatchNorm2d (BasicGANs/models.py:37,79) instead:
+ *   forward:  gc_batchnorm_stats on the shard -> the host merges (mean, unbiased variance, count) over the ranks ->
+ *             gc_batchnorm_act_fwd with training = 0 and the merged mean / biased variance as running statistics;
+ *   backward: gc_batchnorm_act_bwd_sums on the shard (ggamma = sum g*xh, gbeta = sum g, g = gy * act') -> the host adds
+ *             them over the ranks -> gc_batchnorm_act_bwd_apply with means = [2][C] = (sum g, sum g*xh) / global count.
+ * Workspace: gc_batchnorm_workspace_bytes(P, C) with the shard's P. */
+int gc_batchnorm_stats(const void* x, float* mean, float* var_unbiased, void* workspace, size_t workspace_bytes, int64_t P, int32_t C,
+                       int32_t dtype, void* stream);
+int gc_batchnorm_act_bwd_sums(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                              const float* save_rstd, float* ggamma, float* gbeta, void* workspace, size_t workspace_bytes, int64_t P,
+                              int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
+int gc_batchnorm_act_bwd_apply(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_rstd, const float* means, void* gx, void* gx_bf16, int64_t P, int32_t C, int32_t dtype,
+                               int32_t act, float slope, void* stream);
+
 int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* mean,
                                 const float* var_unbiased, int32_t C, float momentum, void* stream);
 
@@ -204,6 +221,15 @@ int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t
  * a HIP graph.  Same operation order as torch's single-tensor Adam. */
 int gc_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const int64_t* numel, float* step, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* The same step that also keeps the exponential moving average of the parameters in the same launch:
+ *   ema[i] = ema_weight * ema[i] + (1 - ema_weight) * params[i]   (with the updated params)
+ * Replaces optimizer_G.step() followed by moving_average(averaged_G, net_G, weight) (StyleGAN/train.py:71-76, called
+ * after each generator step), which reads and writes both parameter sets once more.  ema: host array of device
+ * pointers, entries may be null (no average kept for that tensor); ema_weight in [0, 1]. */
+int gc_adam_ema_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                     float* const* ema, float ema_weight, const int64_t* numel, float* step, float lr, float beta1, float beta2,
+                     float eps, void* stream);
 
 /* StyleGAN's chain behind every synthesis convolution as one kernel per direction (StyleGAN/model.py:179-208,249-261:
  * NoiseInput, LeakyReLU(0.2), InstanceNorm2d, style affine):

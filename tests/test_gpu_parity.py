@@ -958,6 +958,39 @@ def test_fused_adam_matches_torch_adam(gan, betas):
         gan.optim.Adam(pa, weight_decay=0.1)
 
 
+def test_fused_adam_keeps_the_moving_average(gan):
+    """Adam.average_into: optimizer step + moving_average(averaged, net, 0.999) of StyleGAN/train.py:71-76 in one launch,
+    against torch.optim.Adam followed by the reference's two in-place operations per parameter; gan_amd.optim.moving_average
+    (the stand-alone form) against the same."""
+    torch.manual_seed(5)
+
+    def net():
+        return torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Conv2d(3, 5, 3), torch.nn.Linear(19, 1, bias=False)).cuda()
+
+    a, b = net(), net()
+    b.load_state_dict(a.state_dict())
+    ea, eb, ec = net(), net(), net()
+    eb.load_state_dict(ea.state_dict()); ec.load_state_dict(ea.state_dict())
+    start = [p.detach().clone() for p in ea.parameters()]
+    oa = gan.optim.Adam(a.parameters(), lr=2e-3, betas=(0.0, 0.9)).average_into(ea, a, 0.999)
+    ob = torch.optim.Adam(b.parameters(), lr=2e-3, betas=(0.0, 0.9))
+    for step in range(5):
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            g = torch.randn_like(pa)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+        for e, p in zip(eb.parameters(), b.parameters()):
+            e.data.mul_(0.999).add_(p.data, alpha=1 - 0.999)
+        gan.optim.moving_average(ec, b, 0.999)
+    for e, f, h, e0 in zip(ea.parameters(), eb.parameters(), ec.parameters(), start):
+        assert torch.allclose(e, f, rtol=2e-6, atol=1e-7)
+        assert torch.allclose(h, f, rtol=2e-6, atol=1e-7)
+        assert not torch.equal(e, e0)
+    with pytest.raises(RuntimeError):
+        gan.optim.Adam(a.parameters()).average_into(torch.nn.Sequential(torch.nn.Linear(37, 20), torch.nn.Conv2d(3, 5, 3),
+                                                                        torch.nn.Linear(19, 1, bias=False)).cuda(), a)
+
+
 # ---- bf16 activation storage --------------------------------------------------------------------------------------
 MIXED = [  # N, Cin, H, W, Cout, k, s, p, x dtype, y dtype   -- every storage combination through every kernel family
     (2, 3, 32, 32, 64, 4, 2, 1, "f32", "bf16"),      # image -> bf16 activations (thin input), data gradient bf16 -> f32 image
