@@ -2,7 +2,7 @@
 convolution modules.
 
 Graphs and parameter names follow Pix2Pix/models.py:4-147 (Generator, DownSample, UpSample) and :221-243
-(Discriminator); the step follows Pix2Pix/train.py:94-145.  Reference quirks kept: the U-Net is pre-activation
+(Discriminator), :150-218 (GeneratorHD, ResNetBlock); the step follows Pix2Pix/train.py:94-145.  Reference quirks kept: the U-Net is pre-activation
 (LeakyReLU -> conv -> BN going down, ReLU -> transposed conv -> BN going up, `UpSample.leaky_relu` is a ReLU), the
 discriminator uses ReLU, dropout(0.5) is always on after the first three up blocks, `interpolation` is ignored.
 The dropout masks can be passed in so that a step is repeatable across devices.
@@ -82,6 +82,61 @@ class Generator(torch.nn.Module):
         out = self.upsample_7(torch.cat((out, x2), dim=1))
         out = self.upsample_8(torch.cat((out, x1), dim=1))
         return torch.tanh(out)
+
+
+class ResNetBlock(torch.nn.Module):
+    """Residual block of the Pix2PixHD generator (Pix2Pix/models.py:198-218): x + [reflection pad 1, 3x3 conv, BatchNorm,
+    ReLU, dropout 0.5, reflection pad 1, 3x3 conv, BatchNorm](x).  `main` keeps the reference's module indices (conv at
+    1 and 6, BatchNorm at 2 and 7), so its state_dict loads unchanged; BatchNorm + ReLU run as one fused layer."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.main = torch.nn.Sequential(
+            torch.nn.ReflectionPad2d(1), gnn.Conv2d(ch, ch, kernel_size=3, padding=0), gnn.BatchNormAct2d(ch, activation="relu"),
+            torch.nn.Identity(), torch.nn.Dropout(0.5),
+            torch.nn.ReflectionPad2d(1), gnn.Conv2d(ch, ch, kernel_size=3, padding=0), gnn.BatchNormAct2d(ch, activation=None))
+
+    def forward(self, x, mask=None):
+        h = self.main[2](self.main[1](self.main[0](x)))
+        h = self.main[4](h) if mask is None else h * mask
+        return x + self.main[7](self.main[6](self.main[5](h)))
+
+
+class GeneratorHD(torch.nn.Module):
+    """Global generator of Pix2PixHD (Pix2Pix/models.py:150-195) on the gan_amd layers: reflection-padded 7x7 convolution
+    (49 taps), stride-2 3x3 convolutions, residual blocks, ConvTranspose2d(k3, s2, p1, output_padding=1) -- the data
+    gradient kernel with an odd filter on the four output parities --, reflection-padded 7x7 convolution with the tanh in
+    its epilogue.  Same constructor, parameter names and initialisation order as the reference."""
+
+    def __init__(self, input_dim=3, output_dim=3, ch=64, n_downsampling=3, n_blocks=9):
+        super().__init__()
+        nn = torch.nn
+        self.main = nn.ModuleList()
+        self.main.append(nn.Sequential(nn.ReflectionPad2d(3), gnn.Conv2d(input_dim, ch, kernel_size=7, padding=0),
+                                       gnn.BatchNormAct2d(ch, activation="relu"), nn.Identity()))
+        for i in range(n_downsampling):
+            m = 2 ** i
+            self.main.append(nn.Sequential(gnn.Conv2d(ch * m, ch * m * 2, kernel_size=3, stride=2, padding=1),
+                                           gnn.BatchNormAct2d(ch * m * 2, activation="relu"), nn.Identity()))
+        for i in range(n_blocks):
+            self.main.append(ResNetBlock(ch * 2 ** n_downsampling))
+        for i in range(n_downsampling):
+            m = 2 ** (n_downsampling - i)
+            self.main.append(nn.Sequential(gnn.ConvTranspose2d(ch * m, ch * m // 2, kernel_size=3, stride=2, padding=1, output_padding=1),
+                                           gnn.BatchNormAct2d(ch * m // 2, activation="relu"), nn.Identity()))
+        self.main.append(nn.Sequential(nn.ReflectionPad2d(3), gnn.Conv2d(ch, output_dim, kernel_size=7, padding=0, activation="tanh"),
+                                       nn.Identity()))
+
+    def forward(self, x, dropout_masks=None):
+        """dropout_masks: optional one tensor per residual block (already scaled by 1 / (1 - p))."""
+        out, bi = x, 0
+        for layer in self.main:
+            if isinstance(layer, ResNetBlock):
+                out = layer(out, None if dropout_masks is None else dropout_masks[bi])
+                bi += 1
+            else:
+                out = layer(out)
+        return out
 
 
 class Discriminator(torch.nn.Module):

@@ -257,6 +257,55 @@ class P2PDiscriminator(torch.nn.Module):
         return torch.sigmoid(self.conv_5(o))
 
 
+class P2PResNetBlock(torch.nn.Module):
+    """x + [reflection pad 1, 3x3 conv, BatchNorm, ReLU, dropout 0.5, reflection pad 1, 3x3 conv, BatchNorm](x)
+    (Pix2Pix/models.py:198-218).  Module indices inside `main` are the reference's, so state_dict keys agree."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.main = torch.nn.Sequential(
+            torch.nn.ReflectionPad2d(1), torch.nn.Conv2d(ch, ch, kernel_size=3, padding=0), torch.nn.BatchNorm2d(ch),
+            torch.nn.ReLU(), torch.nn.Identity(),
+            torch.nn.ReflectionPad2d(1), torch.nn.Conv2d(ch, ch, kernel_size=3, padding=0), torch.nn.BatchNorm2d(ch))
+
+    def forward(self, x, mask=None):
+        h = self.main[3](self.main[2](self.main[1](self.main[0](x))))
+        h = torch.nn.functional.dropout(h, 0.5, training=self.training) if mask is None else h * mask
+        return x + self.main[7](self.main[6](self.main[5](h)))
+
+
+class P2PGeneratorHD(torch.nn.Module):
+    """Global generator of Pix2PixHD as the reference builds it (Pix2Pix/models.py:150-195): reflection-padded 7x7 conv,
+    n_downsampling stride-2 3x3 convs, n_blocks residual blocks, as many ConvTranspose2d(k3, s2, p1, output_padding 1),
+    reflection-padded 7x7 conv to the image, tanh; BatchNorm + ReLU after every conv but the last."""
+
+    def __init__(self, input_dim=3, output_dim=3, ch=64, n_downsampling=3, n_blocks=9):
+        super().__init__()
+        nn = torch.nn
+        self.main = nn.ModuleList()
+        self.main.append(nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(input_dim, ch, kernel_size=7, padding=0), nn.BatchNorm2d(ch), nn.ReLU()))
+        for i in range(n_downsampling):
+            m = 2 ** i
+            self.main.append(nn.Sequential(nn.Conv2d(ch * m, ch * m * 2, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(ch * m * 2), nn.ReLU()))
+        for i in range(n_blocks):
+            self.main.append(P2PResNetBlock(ch * 2 ** n_downsampling))
+        for i in range(n_downsampling):
+            m = 2 ** (n_downsampling - i)
+            self.main.append(nn.Sequential(nn.ConvTranspose2d(ch * m, ch * m // 2, kernel_size=3, stride=2, padding=1, output_padding=1),
+                                           nn.BatchNorm2d(ch * m // 2), nn.ReLU()))
+        self.main.append(nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(ch, output_dim, kernel_size=7, padding=0), nn.Tanh()))
+
+    def forward(self, x, dropout_masks=None):
+        out, bi = x, 0
+        for layer in self.main:
+            if isinstance(layer, P2PResNetBlock):
+                out = layer(out, None if dropout_masks is None else dropout_masks[bi])
+                bi += 1
+            else:
+                out = layer(out)
+        return out
+
+
 def _set_requires_grad(model, flag):
     for p in model.parameters():
         p.requires_grad = flag

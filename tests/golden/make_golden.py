@@ -15,6 +15,7 @@ imported by path (BasicGANs/models.py, BasicGANs/loss_functions.py):
                        BasicGANs/train.py:95-119) incl. the gradient-penalty double backward, reduced model
   dcgan_losses.json    loss scalars of 3 full-size DCGAN-64 steps (hidden 64, batch 128) with Adam
   wgangp_losses.json   loss scalars of 1 full cycle (5 critic + 1 generator) WGAN-GP-64 at batch 64 with Adam
+  pix2pixhd_trace.npz  forward + backward of the Pix2PixHD global generator (Pix2Pix/models.py:150-218), reduced size
   pix2pix_trace.npz    one Pix2Pix step (Pix2Pix/models.py, step order of Pix2Pix/train.py:94-145) at 256x256, ch 8,
                        batch 2: losses, discriminator gradients, sampled generator gradients, output crops, masks
   stylegan_trace.npz   StyleGAN-v1 (StyleGAN/model.py) at 128x128 (pg step 5), batch 2: critic phase with style mixing and
@@ -307,6 +308,53 @@ def make_pix2pix_trace(ref, out):
     print("pix2pix_trace.npz:", len(blob), "arrays; losses", blob["d.loss"], blob["g.loss"], rec["param_count"])
 
 
+def make_pix2pixhd_trace(ref, out):
+    """Forward + backward of the Pix2PixHD global generator (Pix2Pix/models.py:150-218: reflection-padded 7x7 and 3x3
+    convolutions, stride-2 3x3 convolutions, residual blocks with dropout, ConvTranspose2d k3 s2 p1 output_padding 1) at
+    64x64 with ch = 8, two residual blocks, batch 2, under an L1 loss against a random target.  Default initialisation
+    regenerated from the seed by the tests and pinned by a checksum; dropout masks captured."""
+    models = load_by_path("ref_p2p_models", os.path.join(ref, "Pix2Pix/models.py"))
+    seed_all()
+    B, ch, blocks, res = 2, 8, 2, 64
+    net = models.GeneratorHD(ch=ch, n_blocks=blocks)
+    blob = {"cfg": np.array([B, ch, blocks, res], np.int64)}
+    rec = {"param_count": sum(p.numel() for p in net.parameters()),
+           "init_checksum": checksum(torch.cat([p.flatten() for p in net.parameters()])),
+           "state_dict_keys": list(net.state_dict().keys())}
+    gen = torch.Generator().manual_seed(SEED + 5)
+    label = (torch.rand(B, 3, res, res, generator=gen) * 2 - 1).requires_grad_(True)
+    target = torch.rand(B, 3, res, res, generator=gen) * 2 - 1
+    masks = []
+    orig_dropout = F.dropout
+
+    def dropout_spy(x, p=0.5, training=True, inplace=False):
+        m = (torch.rand(x.shape, generator=gen) >= p).to(x.dtype) / (1 - p)
+        masks.append(m)
+        return x * m
+    F.dropout = dropout_spy
+    torch.nn.functional.dropout = dropout_spy
+    try:
+        fake = net(label)
+        loss = torch.nn.L1Loss()(fake, target)
+        loss.backward()
+    finally:
+        F.dropout = orig_dropout
+        torch.nn.functional.dropout = orig_dropout
+    blob["label"] = label.detach().numpy(); blob["target"] = target.numpy()
+    blob["fake"] = fake.detach().numpy(); blob["loss"] = np.array([loss.item()])
+    blob["grad_label"] = label.grad.numpy()
+    for k, p in net.named_parameters():
+        blob["grad." + k] = p.grad.clone().numpy()
+    for k, b in net.named_buffers():
+        if "running" in k:
+            blob["buf." + k] = b.clone().numpy()
+    for i, m in enumerate(masks):
+        blob[f"mask{i}"] = m.numpy()
+    np.savez_compressed(os.path.join(out, "pix2pixhd_trace.npz"), **blob)
+    json.dump(rec, open(os.path.join(out, "pix2pixhd_trace.json"), "w"), indent=1)
+    print("pix2pixhd_trace.npz:", len(blob), "arrays; loss", blob["loss"], rec["param_count"], "masks", len(masks))
+
+
 def _sample(g, n=4096):
     g = np.asarray(g)
     return g if g.size <= 20000 else g.ravel()[::max(1, g.size // n)][:n].copy()
@@ -541,12 +589,13 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "stylegan_trace", "biggan_trace"]
+    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "pix2pixhd_trace", "stylegan_trace", "biggan_trace"]
     if "ops" in todo: make_ops(a.out)
     if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
     if "wgangp_trace" in todo: make_wgangp_trace(a.ref, a.out)
     if "dcgan_losses" in todo: make_dcgan_losses(a.ref, a.out)
     if "wgangp_losses" in todo: make_wgangp_losses(a.ref, a.out)
     if "pix2pix_trace" in todo: make_pix2pix_trace(a.ref, a.out)
+    if "pix2pixhd_trace" in todo: make_pix2pixhd_trace(a.ref, a.out)
     if "stylegan_trace" in todo: make_stylegan_trace(a.ref, a.out)
     if "biggan_trace" in todo: make_biggan_trace(a.ref, a.out)

@@ -172,6 +172,38 @@ def pix2pix_setup(golden_dir, make_G, make_D):
     return z, rec, G, D, real, label, masks[:n_d], masks[n_d:]
 
 
+def pix2pixhd_setup(golden_dir, make_G):
+    """Generator re-initialised from the reference's seed (PyTorch default init), inputs and dropout masks from the fixture."""
+    z = np.load(os.path.join(golden_dir, "pix2pixhd_trace.npz"))
+    rec = json.load(open(os.path.join(golden_dir, "pix2pixhd_trace.json")))
+    B, ch, blocks, res = [int(v) for v in z["cfg"]]
+    torch.manual_seed(5000)
+    G = make_G(ch, blocks)
+    assert sum(p.numel() for p in G.parameters()) == rec["param_count"]
+    assert _checksum(torch.cat([p.flatten() for p in G.parameters()])) == rec["init_checksum"]
+    assert list(G.state_dict().keys()) == rec["state_dict_keys"]
+    masks = [torch.from_numpy(z[f"mask{i}"]) for i in range(blocks)]
+    return z, G, torch.from_numpy(z["label"]), torch.from_numpy(z["target"]), masks
+
+
+def test_restated_pix2pixhd_generator_matches_reference(golden_dir):
+    """Pix2Pix/models.py:150-218 (GeneratorHD, ResNetBlock): output, loss, input gradient, every parameter gradient and
+    the BatchNorm running statistics of one forward + backward."""
+    z, G, label, target, masks = pix2pixhd_setup(golden_dir, lambda ch, nb: R.P2PGeneratorHD(ch=ch, n_blocks=nb))
+    label.requires_grad_(True)
+    fake = G(label, masks)
+    loss = torch.nn.functional.l1_loss(fake, target)
+    loss.backward()
+    assert abs(loss.item() - z["loss"][0]) < 1e-6
+    assert rel_err(fake.detach().numpy(), z["fake"]) < 1e-5
+    assert rel_err(label.grad.numpy(), z["grad_label"]) < 1e-4
+    for k, p in G.named_parameters():
+        assert rel_err(p.grad.numpy(), z["grad." + k]) < 1e-4 or np.linalg.norm(z["grad." + k]) < 1e-7, k
+    for k, b in G.named_buffers():
+        if "running" in k:
+            assert rel_err(b.numpy(), z["buf." + k]) < 1e-5, k
+
+
 def test_restated_pix2pix_step_matches_reference(golden_dir):
     z, rec, G, D, real, label, masks_d, masks_g = pix2pix_setup(golden_dir, lambda ch: R.P2PGenerator(ch=ch), lambda ch: R.P2PDiscriminator(ch=ch))
     assert sum(p.numel() for p in G.parameters()) == rec["param_count"]["G"]
