@@ -118,6 +118,32 @@ if want("pix2pix"):
     kernel_table(p2p_gpu, "Pix2Pix")
     del G, D, Gr, Dr
 
+if want("pix2pixhd"):
+    # ---- Pix2PixHD global generator (ch 64, 9 residual blocks) + PatchGAN on 256x256 (Pix2Pix/train.py:27 selects it by name)
+    B = 8 if FULL else 4
+    real, label = torch.rand(B, 3, 256, 256) * 2 - 1, torch.rand(B, 3, 256, 256)
+    G, D = pix2pix.GeneratorHD(ch=64).to(dev), pix2pix.Discriminator(ch=64).to(dev)
+    Gr, Dr = ref_models.P2PGeneratorHD(ch=64), ref_models.P2PDiscriminator(ch=64)
+    rg, lg = real.to(dev), label.to(dev)
+
+
+    def hd_gpu():
+        zero(G, D)
+        pix2pix.discriminator_phase(G, D, rg, lg)
+        pix2pix.generator_phase(G, D, rg, lg)
+
+
+    def hd_cpu():
+        zero(Gr, Dr)
+        ref_models.pix2pix_discriminator_phase(Gr, Dr, real[:CPU_B], label[:CPU_B])
+        ref_models.pix2pix_generator_phase(Gr, Dr, real[:CPU_B], label[:CPU_B])
+
+
+    rows.append((f"Pix2PixHD global generator + PatchGAN, 256x256, batch {B}", B, gpu_time(hd_gpu), cpu_time(hd_cpu), graph_time(hd_gpu)))
+    note("pix2pixhd done")
+    kernel_table(hd_gpu, "Pix2PixHD")
+    del G, D, Gr, Dr
+
 if want("stylegan"):
     # ---- StyleGAN-v1 at progressive step 5 (128x128), batch 16, style mixing, gradient penalty
     if FAST:
