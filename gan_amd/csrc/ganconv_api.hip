@@ -120,37 +120,89 @@ __global__ __launch_bounds__(kThreads) void pack_weights_kernel(const PackTable 
 }
 
 // ---- depthwise 3x3 binomial blur, NHWC ----------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* x, T* y, int N, int H, int W, int C4) {
-  // one thread per (pixel, group of 4 channels): 16-byte (fp32) or 8-byte (bf16) accesses
-  const size_t total = (size_t)N * H * W * C4;
-  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
-    const int c4 = (int)(e % C4);
-    size_t pix = e / C4;
-    const int w = (int)(pix % W);
-    const int h = (int)((pix / W) % H);
-    const size_t n = pix / ((size_t)W * H);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+// [1 2 1] x [1 2 1] / 16 with zero padding, separable: a thread owns one column w of a strip of kBlurRows rows for a group
+// of V channels (16-byte accesses: V = 4 fp32 or 8 bf16); per row it loads the pixel and its two horizontal neighbours
+// (which its neighbour lanes load as well: L1 hits), forms the horizontal sum, and combines the last three horizontal
+// sums from registers.  Reads of a strip: (kBlurRows + 2) / kBlurRows of the tensor; consecutive lanes run along
+// (w, channel group), i.e. along memory.
+constexpr int kBlurRows = 16;
+
+template <typename T, int V>
+__device__ __forceinline__ void blur_load(const T* x, size_t off, bool ok, float (&v)[V]) {
+  if (!ok) {
 #pragma unroll
-    for (int dr = -1; dr <= 1; dr++) {
-      const int hh = h + dr;
-      if ((unsigned)hh >= (unsigned)H) continue;
+    for (int i = 0; i < V; i++) v[i] = 0.f;
+    return;
+  }
+  if constexpr (sizeof(T) == 4) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(x + off);
 #pragma unroll
-      for (int dc = -1; dc <= 1; dc++) {
-        const int ww = w + dc;
-        if ((unsigned)ww >= (unsigned)W) continue;
-        const float k = (float)((2 - (dr != 0)) * (2 - (dc != 0)));
-        const size_t off = (((n * H + hh) * W + ww) * C4 + c4) * 4;
-        f32x4 v;
-        if (sizeof(T) == 4) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + off);
-        else v = widen_bf16x4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(x) + off));
-        acc += k * v;
-      }
+    for (int i = 0; i < 4; i++) v[i] = q[i];
+  } else if constexpr (V == 8) {
+    const u32x4 q = *reinterpret_cast<const u32x4*>(x + off);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      v[2 * i] = __builtin_bit_cast(float, q[i] << 16);
+      v[2 * i + 1] = __builtin_bit_cast(float, q[i] & 0xffff0000u);
     }
-    acc *= (1.f / 16.f);
-    const size_t off = e * 4;
-    if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + off) = acc;
-    else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(y) + off) = cvt_bf16x4(acc);
+  } else {
+    const u32x2 q = *reinterpret_cast<const u32x2*>(x + off);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      v[2 * i] = __builtin_bit_cast(float, q[i] << 16);
+      v[2 * i + 1] = __builtin_bit_cast(float, q[i] & 0xffff0000u);
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int CV,
+                                                             int strips, uint32_t total) {
+  const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= total) return;
+  const int cv = (int)(e % (uint32_t)CV);
+  uint32_t r = e / (uint32_t)CV;
+  const int w = (int)(r % (uint32_t)W);
+  r /= (uint32_t)W;
+  const int strip = (int)(r % (uint32_t)strips);
+  const int n = (int)(r / (uint32_t)strips);
+  const int h0 = strip * kBlurRows, h1 = min(H, h0 + kBlurRows);
+  const size_t rowp = (size_t)W * CV * V;                                   // elements per image row
+  const size_t base = (size_t)n * H * rowp + (size_t)w * CV * V + (size_t)cv * V;
+  const bool lok = w > 0, rok = w + 1 < W;
+  float prev[V], cur[V], nxt[V];
+  auto hsum = [&](int h, float (&o)[V]) {
+    if ((unsigned)h >= (unsigned)H) {
+#pragma unroll
+      for (int i = 0; i < V; i++) o[i] = 0.f;
+      return;
+    }
+    const size_t off = base + (size_t)h * rowp;
+    float a[V], c[V], b[V];
+    blur_load<T, V>(x, off - (size_t)CV * V, lok, a);
+    blur_load<T, V>(x, off, true, c);
+    blur_load<T, V>(x, off + (size_t)CV * V, rok, b);
+#pragma unroll
+    for (int i = 0; i < V; i++) o[i] = a[i] + 2.f * c[i] + b[i];
+  };
+  hsum(h0 - 1, prev);
+  hsum(h0, cur);
+  for (int h = h0; h < h1; h++) {
+    hsum(h + 1, nxt);
+    float o[V];
+#pragma unroll
+    for (int i = 0; i < V; i++) o[i] = (prev[i] + 2.f * cur[i] + nxt[i]) * (1.f / 16.f);
+    const size_t off = base + (size_t)h * rowp;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<f32x4*>(y + off) = f32x4{o[0], o[1], o[2], o[3]};
+    } else if constexpr (V == 8) {
+      const u32x2 lo = cvt_bf16x4(f32x4{o[0], o[1], o[2], o[3]}), hi = cvt_bf16x4(f32x4{o[4], o[5], o[6], o[7]});
+      *reinterpret_cast<u32x4*>(y + off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    } else {
+      *reinterpret_cast<u32x2*>(y + off) = cvt_bf16x4(f32x4{o[0], o[1], o[2], o[3]});
+    }
+#pragma unroll
+    for (int i = 0; i < V; i++) { prev[i] = cur[i]; cur[i] = nxt[i]; }
   }
 }
 
@@ -537,14 +589,21 @@ int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_
     set_error("gc_dwblur3x3: channels must be a multiple of 4 and buffers 16-byte aligned (C=%d)", C);
     return GC_UNSUPPORTED_GEOMETRY;
   }
-  const size_t total = (size_t)N * H * W * (C / 4);
-  size_t blocks = (total + kThreads - 1) / kThreads;
-  if (blocks > 8192) blocks = 8192;
+  const int V = (dtype == GC_BF16 && C % 8 == 0) ? 8 : 4;
+  const int strips = (H + kBlurRows - 1) / kBlurRows;
+  const size_t total = (size_t)N * strips * W * (C / V);
+  if (total >= (1ull << 32) - kThreads) { set_error("gc_dwblur3x3: tensor too large"); return GC_UNSUPPORTED_GEOMETRY; }
+  const unsigned blocks = (unsigned)((total + kThreads - 1) / kThreads);
   ProfScope ps("gc::dwblur3x3_kernel", 0.0, (hipStream_t)stream);
   if (dtype == GC_F32)
-    hipLaunchKernelGGL(dwblur3x3_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C / 4);
+    hipLaunchKernelGGL((dwblur3x3_kernel<float, 4>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W,
+                       C / 4, strips, (uint32_t)total);
+  else if (V == 4)
+    hipLaunchKernelGGL((dwblur3x3_kernel<uint16_t, 4>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint16_t*)y, N, H, W, C / 4, strips, (uint32_t)total);
   else
-    hipLaunchKernelGGL(dwblur3x3_kernel<uint16_t>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, N, H, W, C / 4);
+    hipLaunchKernelGGL((dwblur3x3_kernel<uint16_t, 8>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint16_t*)y, N, H, W, C / 8, strips, (uint32_t)total);
   return check_hip(hipGetLastError(), "dwblur3x3 launch");
 }
 

@@ -257,6 +257,22 @@ def test_blur(gan, ops_golden):
     assert rel(xx.grad, oracle.dwblur3x3(g.cpu().numpy())) < 1e-6   # self-adjoint
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 8, 1, 1), (1, 12, 5, 7), (2, 16, 16, 16), (1, 8, 17, 33), (3, 64, 35, 20), (1, 4, 64, 3), (2, 128, 48, 48)])
+def test_blur_shapes_against_oracle(gan, shape, dt):
+    """Strip boundaries (16 rows), single-pixel images, channel groups of 4 and 8, both storage types; inputs are small
+    integers, so the fp32 sums are exact and only the bf16 store rounds."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randint(-8, 9, shape, generator=g).float()
+    want = oracle.dwblur3x3(x.numpy())
+    y = gan.functional.blur3x3(x.cuda().to(dt).contiguous(memory_format=torch.channels_last))
+    assert y.dtype == dt and y.shape == x.shape
+    if dt == torch.float32:
+        assert np.array_equal(y.cpu().numpy(), want)
+    else:
+        assert np.array_equal(y.float().cpu().numpy(), torch.from_numpy(want).bfloat16().float().numpy())
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 128, 16, 16), (2, 512, 4, 4), (1, 8, 5, 7), (2, 64, 32, 32), (1, 40, 40, 33)])
 @pytest.mark.parametrize("slope", [0.2, None])
 def test_instnorm_act_first_and_second_order(gan, shape, slope):
