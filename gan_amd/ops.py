@@ -960,6 +960,11 @@ def _adain_args(x, noise, sf, ys, yb):
     return N, C, H * W, f(noise), f(sf).reshape(-1), f(ys), f(yb)
 
 
+def _adain_workspace(N, HW, C, device):
+    n = _lib.lib().gc_noise_lrelu_adain_workspace_bytes(N, HW, C)
+    return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
 @torch.library.custom_op("ganconv::noise_lrelu_adain", mutates_args=())
 def noise_lrelu_adain(x: Tensor, noise: Tensor, sf: Tensor, ys: Tensor, yb: Tensor, eps: float, slope: float) -> tuple[Tensor, Tensor, Tensor]:
     """ys * InstanceNorm(leaky_relu(x + sf * noise)) + yb (reference StyleGAN/model.py:249-261).  Returns (out, mean,
@@ -968,8 +973,10 @@ def noise_lrelu_adain(x: Tensor, noise: Tensor, sf: Tensor, ys: Tensor, yb: Tens
     N, C, HW, noise, sf, ys, yb = _adain_args(x, noise, sf, ys, yb)
     out = torch.empty_like(x, memory_format=torch.channels_last)
     mu, r = (torch.empty(N, C, dtype=torch.float32, device=x.device) for _ in range(2))
-    _lib.check(_lib.lib().gc_noise_lrelu_adain_fwd(_ptr(x), _ptr(noise), _ptr(sf), _ptr(ys), _ptr(yb), _ptr(out), _ptr(mu), _ptr(r), N, HW, C,
-                                                   _dtype_code(x), eps, slope, _stream()), "gc_noise_lrelu_adain_fwd")
+    ws = _adain_workspace(N, HW, C, x.device)
+    _lib.check(_lib.lib().gc_noise_lrelu_adain_fwd(_ptr(x), _ptr(noise), _ptr(sf), _ptr(ys), _ptr(yb), _ptr(out), _ptr(mu), _ptr(r),
+                                                   _optr(ws), 0 if ws is None else ws.numel(), N, HW, C, _dtype_code(x), eps, slope,
+                                                   _stream()), "gc_noise_lrelu_adain_fwd")
     return out, mu, r
 
 
@@ -988,9 +995,10 @@ def noise_lrelu_adain_bwd(x: Tensor, noise: Tensor, sf: Tensor, ys: Tensor, yb: 
     N, C, HW, noise, sf, ys, yb = _adain_args(x, noise, sf, ys, yb)
     gx = torch.empty_like(x, memory_format=torch.channels_last)
     g_sf, g_ys, g_yb = (torch.empty(N, C, dtype=torch.float32, device=x.device) for _ in range(3))
+    ws = _adain_workspace(N, HW, C, x.device)
     _lib.check(_lib.lib().gc_noise_lrelu_adain_bwd(_ptr(x), _ptr(noise), _ptr(sf), _ptr(ys), _ptr(yb), _ptr(mu), _ptr(r), _ptr(gout), _ptr(gx),
-                                                   _ptr(g_sf), _ptr(g_ys), _ptr(g_yb), N, HW, C, _dtype_code(x), slope, _stream()),
-               "gc_noise_lrelu_adain_bwd")
+                                                   _ptr(g_sf), _ptr(g_ys), _ptr(g_yb), _optr(ws), 0 if ws is None else ws.numel(), N, HW, C,
+                                                   _dtype_code(x), slope, _stream()), "gc_noise_lrelu_adain_bwd")
     return gx, g_sf, g_ys, g_yb
 
 

@@ -237,12 +237,16 @@ int gc_adam_ema_step(int32_t n, float* const* params, const float* const* grads,
  * x / out / gout / gx NHWC fp32 or bf16 (`dtype`), C a multiple of 4; noise float [N, HW]; sf float [C]; ys, yb float
  * [N, C].  The forward pass writes the per-(n, c) mean and rsqrt(var + eps) of the activated tensor to mu / r
  * (float [N, C]) for the backward pass, which returns gx, g_ys / g_yb [N, C] and g_sf per sample [N, C] (sum over n
- * for the parameter's gradient).  First order only; the noise gets no gradient. */
+ * for the parameter's gradient).  First order only; the noise gets no gradient.  Large images are processed in slabs of
+ * pixels (partial statistics, then merge + apply) and need the caller's workspace (16-byte aligned, may be NULL when
+ * the size query returns 0). */
+size_t gc_noise_lrelu_adain_workspace_bytes(int32_t N, int32_t HW, int32_t C);   /* 0 for small images (one launch, no workspace) */
 int gc_noise_lrelu_adain_fwd(const void* x, const float* noise, const float* sf, const float* ys, const float* yb, void* out, float* mu,
-                             float* r, int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, float slope, void* stream);
+                             float* r, void* workspace, size_t workspace_bytes, int32_t N, int32_t HW, int32_t C, int32_t dtype,
+                             float eps, float slope, void* stream);
 int gc_noise_lrelu_adain_bwd(const void* x, const float* noise, const float* sf, const float* ys, const float* yb, const float* mu,
-                             const float* r, const void* gout, void* gx, float* g_sf, float* g_ys, float* g_yb, int32_t N, int32_t HW,
-                             int32_t C, int32_t dtype, float slope, void* stream);
+                             const float* r, const void* gout, void* gx, float* g_sf, float* g_ys, float* g_yb, void* workspace,
+                             size_t workspace_bytes, int32_t N, int32_t HW, int32_t C, int32_t dtype, float slope, void* stream);
 
 /* 2x2 sum-pooling and 2x nearest replication, NHWC, fp32 or bf16 (`dtype`), C a multiple of 8, 16-byte aligned:
  *   gc_pool2x2     : y[n,h,w,c] = scale * (x[n,2h,2w,c] + x[n,2h,2w+1,c] + x[n,2h+1,2w,c] + x[n,2h+1,2w+1,c]),  x is [N,2Ho,2Wo,C]

@@ -79,10 +79,12 @@ def test_argument_validation_of_the_layer_kernels():
     assert L.gc_cond_batchnorm_act_fwd(q, q, q, q, None, None, None, q, q, q, q, 16, 4, 1024, 64, _lib.GC_F32, 1e-5, 0.1, 1, 0.0, 1, None) == -3
     assert L.gc_cond_batchnorm_act_fwd(q, q, q, q, None, None, None, q, q, q, q, ws, 4, 1024, 66, _lib.GC_F32, 1e-5, 0.1, 1, 0.0, 1, None) == -2
     # noise -> LeakyReLU -> InstanceNorm -> style chain
-    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, 2, 64, 30, _lib.GC_BF16, 1e-5, 0.2, None) == -2
-    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, 2, 64, 32, _lib.GC_BF16, 1e-5, 0.0, None) == -2     # slope must be positive
-    assert L.gc_noise_lrelu_adain_fwd(q, None, q, q, q, q, q, q, 2, 64, 32, _lib.GC_BF16, 1e-5, 0.2, None) == -5
-    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, 0, 64, 32, _lib.GC_BF16, 1e-5, 0.2, None) == 0
+    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, None, 0, 2, 64, 30, _lib.GC_BF16, 1e-5, 0.2, None) == -2
+    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, None, 0, 2, 64, 32, _lib.GC_BF16, 1e-5, 0.0, None) == -2     # slope must be positive
+    assert L.gc_noise_lrelu_adain_fwd(q, None, q, q, q, q, q, q, None, 0, 2, 64, 32, _lib.GC_BF16, 1e-5, 0.2, None) == -5
+    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, None, 0, 0, 64, 32, _lib.GC_BF16, 1e-5, 0.2, None) == 0
+    assert L.gc_noise_lrelu_adain_workspace_bytes(4, 64, 64) == 0 and L.gc_noise_lrelu_adain_workspace_bytes(4, 65536, 64) >= 4 * 2 * 64 * 12
+    assert L.gc_noise_lrelu_adain_fwd(q, q, q, q, q, q, q, q, None, 0, 4, 65536, 64, _lib.GC_BF16, 1e-5, 0.2, None) == -3    # large image: workspace
     # the split-reduction switch reports the previous setting
     assert L.gc_set_split_reduction(0) == 1 and L.gc_set_split_reduction(1) == 0 and L.gc_set_split_reduction(1) == 1
 

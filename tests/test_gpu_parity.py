@@ -764,7 +764,7 @@ def test_attention_against_unfused_product(gan, B, N, d, C):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(3, 32, 8, 8), (2, 64, 40, 24), (4, 8, 4, 4), (1, 512, 16, 16)])
+@pytest.mark.parametrize("shape", [(3, 32, 8, 8), (2, 64, 40, 24), (4, 8, 4, 4), (1, 512, 16, 16), (2, 64, 64, 64), (1, 24, 70, 61), (3, 128, 32, 48)])
 def test_noise_lrelu_adain_against_torch(gan, shape, dt):
     """ys * InstanceNorm2d(leaky_relu(x + sf * noise)) + yb (reference StyleGAN/model.py:249-261) and the gradients of x,
     the noise scale and the two styles against the torch composition in fp32."""
