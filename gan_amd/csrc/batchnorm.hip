@@ -24,6 +24,7 @@
 // Backward: with g = gy * act', ggamma[n, c] = sum_hw g * xh and gbeta[n, c] = sum_hw g per sample, and
 //   gx = r * (gamma[n, c] * g - A / P - xh * B / P),  A = sum_n gamma[n, c] * gbeta[n, c],  B = sum_n gamma[n, c] * ggamma[n, c].
 #include "common.h"
+#include "conv_wgrad.h"
 
 namespace gc {
 
@@ -290,6 +291,142 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
   }
 }
 
+// Small tensors (at most kSmallP pixels): one launch per direction.  A workgroup owns 16 channels (4 quads x 64 pixel
+// lanes) and all pixels: sum, centred squares (from L1 / L2) and the apply sweep, the running statistics included -- the
+// three-launch form costs 25-30 us on such tensors for a few us of work.
+constexpr int kSmallP = 4096, kSmallQB = 4, kSmallPL = kThreads / kSmallQB;
+
+__device__ __forceinline__ f32x4 bn_small_sum(f32x4 v, f32x4* red, int tq, int tl) {
+  red[tl * kSmallQB + tq] = v;
+  __syncthreads();
+  if (tl < 8) {                       // 64 lanes -> 8 -> 1
+    f32x4 s = red[tl * kSmallQB + tq];
+    for (int j = tl + 8; j < kSmallPL; j += 8) s += red[j * kSmallQB + tq];
+    red[tl * kSmallQB + tq] = s;      // (each (tl, tq) slot is read and written by its own thread only in this step)
+  }
+  __syncthreads();
+  f32x4 r = red[tq];
+  for (int j = 1; j < 8; j++) r += red[j * kSmallQB + tq];
+  __syncthreads();
+  return r;
+}
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(kThreads) void bn_small_kernel(const BnParams p) {
+  __shared__ f32x4 red[kThreads];
+  const int t = threadIdx.x, tq = t & (kSmallQB - 1), tl = t / kSmallQB;
+  const int c = (blockIdx.x * kSmallQB + tq) * 4;
+  const bool cok = c < p.C;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto ld = [&](const void* ptr, int pix) -> f32x4 { return load4<T>(ptr, (size_t)pix * p.C + c); };
+  f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = zero;
+  if (cok && p.gamma != nullptr) ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  if (cok && p.beta != nullptr) be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  const float inv = 1.f / (float)p.P;
+  if (MODE == 0) {
+    f32x4 s = zero;
+    if (cok)
+      for (int pix = tl; pix < p.P; pix += kSmallPL) s += ld(p.x, pix);
+    const f32x4 mean = bn_small_sum(s, red, tq, tl) * inv;
+    f32x4 s2 = zero;
+    if (cok)
+      for (int pix = tl; pix < p.P; pix += kSmallPL) {
+        const f32x4 d = ld(p.x, pix) - mean;
+        s2 += d * d;
+      }
+    s2 = bn_small_sum(s2, red, tq, tl);
+    if (!cok) return;
+    f32x4 r, unbiased;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      r[e] = rsqrtf(s2[e] * inv + p.eps);
+      unbiased[e] = p.P > 1 ? s2[e] / (float)(p.P - 1) : s2[e] * inv;
+    }
+    if (tl == 0) {
+      *reinterpret_cast<f32x4*>(p.save_mean + c) = mean;
+      *reinterpret_cast<f32x4*>(p.save_rstd + c) = r;
+      if (p.save_var != nullptr) *reinterpret_cast<f32x4*>(p.save_var + c) = unbiased;
+      if (p.running_mean != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          p.running_mean[c + e] = (1.f - p.momentum) * p.running_mean[c + e] + p.momentum * mean[e];
+          p.running_var[c + e] = (1.f - p.momentum) * p.running_var[c + e] + p.momentum * unbiased[e];
+        }
+      }
+      if (p.num_batches != nullptr && c == 0) p.num_batches[0] += 1;
+    }
+    const f32x4 k0 = ga * r, k1 = be - mean * ga * r;
+    for (int pix = tl; pix < p.P; pix += kSmallPL) {
+      const size_t o = (size_t)pix * p.C + c;
+      const f32x4 pre = k0 * load4<T>(p.x, o) + k1;
+      const f32x4 res = pre * act_mask(pre, p.act, p.slope);
+      store4<T>(p.out, o, res);
+      if (p.out_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out_bf16 + o) = cvt_bf16x4(res);
+    }
+  } else {
+    const f32x4 mu = cok ? *reinterpret_cast<const f32x4*>(p.save_mean + c) : zero, r = cok ? *reinterpret_cast<const f32x4*>(p.save_rstd + c) : zero;
+    f32x4 sg = zero, sgx = zero;
+    if (cok)
+      for (int pix = tl; pix < p.P; pix += kSmallPL) {
+        const f32x4 xh = (ld(p.x, pix) - mu) * r;
+        const f32x4 g = ld(p.gy, pix) * act_mask(ga * xh + be, p.act, p.slope);
+        sg += g;
+        sgx += g * xh;
+      }
+    sg = bn_small_sum(sg, red, tq, tl);
+    sgx = bn_small_sum(sgx, red, tq, tl);
+    if (!cok) return;
+    if (tl == 0) {
+      *reinterpret_cast<f32x4*>(p.gbeta + c) = sg;
+      *reinterpret_cast<f32x4*>(p.ggamma + c) = sgx;
+    }
+    const f32x4 k0 = sg * inv, k1 = sgx * inv;
+    for (int pix = tl; pix < p.P; pix += kSmallPL) {
+      const size_t o = (size_t)pix * p.C + c;
+      const f32x4 xh = (load4<T>(p.x, o) - mu) * r;
+      const f32x4 g = load4<T>(p.gy, o) * act_mask(ga * xh + be, p.act, p.slope);
+      const f32x4 res = ga * r * (g - k0 - xh * k1);
+      store4<T>(p.out, o, res);
+      if (p.out_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out_bf16 + o) = cvt_bf16x4(res);
+    }
+  }
+}
+
+// Per-channel sums over all pixels (the bias gradient of a convolution: reference torch.nn.Conv2d(..., bias=True) at
+// Pix2Pix/models.py:17,225-232, StyleGAN/model.py:72): slab sums with the geometry of the statistics kernels, then one
+// small launch that adds the slabs in a fixed order (bitwise reproducible, no atomics).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void channel_sum_partial_kernel(const BnParams p) {
+  __shared__ f32x4 red[kThreads];
+  const int t = threadIdx.x, tq = t & (kQB - 1), tl = t >> 4;
+  const int chunks = (p.C / 4 + kQB - 1) / kQB;
+  const int slab = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int c = (chunk * kQB + tq) * 4;
+  const bool cok = c < p.C;
+  int p0, p1, n;
+  slab_range(p, slab, p0, p1, n);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    int pix = p0 + tl;
+    for (; pix + 3 * kPL < p1; pix += 4 * kPL) {       // four independent loads in flight
+      const f32x4 a = load4<T>(p.x, (size_t)pix * p.C + c), b = load4<T>(p.x, (size_t)(pix + kPL) * p.C + c);
+      const f32x4 d = load4<T>(p.x, (size_t)(pix + 2 * kPL) * p.C + c), e = load4<T>(p.x, (size_t)(pix + 3 * kPL) * p.C + c);
+      s += (a + b) + (d + e);
+    }
+    for (; pix < p1; pix += kPL) s += load4<T>(p.x, (size_t)pix * p.C + c);
+  }
+  s = bn_block_sum(s, red, tq, tl);
+  if (cok && tl == 0) *reinterpret_cast<f32x4*>(p.part + (size_t)slab * p.C + c) = s;
+}
+
+__global__ __launch_bounds__(kThreads) void channel_sum_final_kernel(const float* part, float* out, int slabs, int C) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < slabs; k++) s += part[(size_t)k * C + c];
+  out[c] = s;
+}
+
 static void bn_geometry(BnParams& p) {
   if (p.nsamp > 0) {   // conditional: slabs inside samples, about 2048 in all, at least 256 pixels each
     long sps = 2048 / p.nsamp;
@@ -366,6 +503,13 @@ static int bn_forward(const void* x, void* y, void* y_bf16, const float* gamma, 
   hipStream_t s = (hipStream_t)stream;
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
+  if (training && nsamp == 0 && P <= kSmallP) {
+    ProfScope ps("gc::bn_small_kernel<0>", 0.0, s);
+    const dim3 sgrid((unsigned)((C / 4 + kSmallQB - 1) / kSmallQB));
+    if (dtype == GC_F32) hipLaunchKernelGGL((bn_small_kernel<0, float>), sgrid, block, 0, s, p);
+    else hipLaunchKernelGGL((bn_small_kernel<0, uint16_t>), sgrid, block, 0, s, p);
+    return check_hip(hipGetLastError(), "batchnorm forward launch");
+  }
   if (training) {
     {
       ProfScope ps("gc::bn_partial_kernel<0>", 0.0, s);
@@ -442,6 +586,13 @@ static int bn_backward(const void* x, const void* gy, const float* gamma, const 
   p.coef = phase == 2 ? const_cast<float*>(means) : p.part + (size_t)p.slabs * C * 2;
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
+  if (phase == 0 && nsamp == 0 && P <= kSmallP) {
+    ProfScope ps("gc::bn_small_kernel<1>", 0.0, s);
+    const dim3 sgrid((unsigned)((C / 4 + kSmallQB - 1) / kSmallQB));
+    if (dtype == GC_F32) hipLaunchKernelGGL((bn_small_kernel<1, float>), sgrid, block, 0, s, p);
+    else hipLaunchKernelGGL((bn_small_kernel<1, uint16_t>), sgrid, block, 0, s, p);
+    return check_hip(hipGetLastError(), "batchnorm backward launch");
+  }
   if (phase != 2) {
     {
       ProfScope ps("gc::bn_partial_kernel<1>", 0.0, s);
@@ -471,6 +622,42 @@ int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma,
   if (N <= 0 || HW <= 0) { set_error("batchnorm: conditional mode needs N > 0 and HW > 0"); return GC_BAD_ARGUMENT; }
   return bn_backward(x, gy, gamma, beta, save_mean, save_rstd, gx, nullptr, ggamma, gbeta, workspace, workspace_bytes, (int64_t)N * HW, C,
                      dtype, act, slope, stream, N);
+}
+
+size_t gc_channel_sum_workspace_bytes(int64_t P, int32_t C) {
+  if (P <= 0 || C <= 0 || P >= (1ll << 31) || C % 4 != 0) return 0;
+  BnParams p{};
+  p.P = (int32_t)P; p.C = C;
+  bn_geometry(p);
+  return (size_t)p.slabs * C * sizeof(float);
+}
+
+int gc_channel_sum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, void* stream) {
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("gc_channel_sum: unknown dtype"); return GC_BAD_ARGUMENT; }
+  if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("gc_channel_sum: bad shape"); return GC_BAD_ARGUMENT; }
+  if (out == nullptr || (P > 0 && x == nullptr)) { set_error("gc_channel_sum: null pointer"); return GC_BAD_ARGUMENT; }
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) return zero_fill(out, sizeof(float) * C, s);
+  if (C % 4 != 0 || misaligned(x, dtype == GC_F32 ? 15 : 7)) {
+    // odd channel counts (the one- and three-channel ends of the networks): element loads, fp32 atomic adds
+    ProfScope ps("gc::colsum_kernel", 0.0, s);
+    return launch_colsum(x, out, (int)P, C, C, 0, dtype == GC_BF16, s);
+  }
+  const size_t need = gc_channel_sum_workspace_bytes(P, C);
+  if (workspace == nullptr || misaligned(workspace, 15) || workspace_bytes < need) {
+    set_error("gc_channel_sum: workspace of %zu bytes given, %zu needed (16-byte aligned)", workspace_bytes, need);
+    return GC_WORKSPACE_TOO_SMALL;
+  }
+  BnParams p{};
+  p.x = x; p.P = (int32_t)P; p.C = C;
+  bn_geometry(p);
+  p.part = (float*)workspace;
+  const int chunks = (C / 4 + kQB - 1) / kQB;
+  ProfScope ps("gc::channel_sum_kernel", 0.0, s);
+  if (dtype == GC_F32) hipLaunchKernelGGL(channel_sum_partial_kernel<float>, dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
+  else hipLaunchKernelGGL(channel_sum_partial_kernel<uint16_t>, dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p.part, out, p.slabs, C);
+  return check_hip(hipGetLastError(), "channel sum launch");
 }
 
 int gc_batchnorm_stats(const void* x, float* mean, float* var_unbiased, void* workspace, size_t workspace_bytes, int64_t P, int32_t C,

@@ -9,6 +9,13 @@ What the step function may do: anything that only enqueues GPU work on tensors w
 (parameters, optimizer state, preallocated inputs that the caller refreshes with copy_()).  What it may not do: read
 values back to the host (.item(), prints), rebind a buffer to a new tensor (write into it instead), branch on data, or
 draw host-side random numbers that should differ between steps (device-side generators are recorded correctly).
+
+A hazard of this torch / ROCm pair, outside this library: a multi-block torch reduction (sum / mean over some 10^5 elements
+or more) recorded in a graph returns wrong values in replays when the same reduction is also launched eagerly between the
+replays (tools/probe/sum_graph_probe.py shows it on a bare x.sum()).  The library's own backward formulas do not use torch
+reductions (bias gradients come from ops.channel_sum); a step function's loss reductions are affected only if the caller
+mixes eager reductions of the same shape between replays -- keep evaluation / logging code in a replay of its own or run
+it before the first replay.
 """
 import torch
 

@@ -11,13 +11,34 @@ import torch
 
 from .. import nn as gnn
 
+# Speed options, read when a network is BUILT (parameter names and state_dicts are the same either way):
+#   activation dtype: storage type of the activations between the layers (None = float32; torch.bfloat16 halves the
+#                     traffic of every elementwise pass, accumulation and statistics stay fp32);
+#   fused norm:       BatchNorm2d (+ ReLU in the discriminator) on the library's norm kernels instead of torch's.
+_ACT_DTYPE = None
+_FUSED_NORM = False
+
+
+def set_activation_dtype(dtype):
+    global _ACT_DTYPE
+    _ACT_DTYPE = dtype
+
+
+def set_fused_norm(on):
+    global _FUSED_NORM
+    _FUSED_NORM = bool(on)
+
+
+def _batch_norm(ch, activation=None):
+    return gnn.BatchNormAct2d(ch, activation=activation) if _FUSED_NORM else torch.nn.BatchNorm2d(ch)
+
 
 class DownSample(torch.nn.Module):
     def __init__(self, in_ch, out_ch, inplace=False, use_bn=True):
         super().__init__()
         self.downsample = gnn.Conv2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1)
         self.relu = torch.nn.LeakyReLU(0.2, inplace=inplace)
-        self.batch_norm = torch.nn.BatchNorm2d(out_ch) if use_bn else torch.nn.Identity()
+        self.batch_norm = _batch_norm(out_ch) if use_bn else torch.nn.Identity()
 
     def forward(self, x):
         return self.batch_norm(self.downsample(self.relu(x)))
@@ -28,8 +49,10 @@ class UpSample(torch.nn.Module):
         super().__init__()
         if interpolation:
             raise RuntimeError("the bilinear-upsample variant is not on the reference's path (Generator never enables it)")
-        self.up_sample = gnn.ConvTranspose2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1)
-        self.batch_norm = torch.nn.BatchNorm2d(out_ch) if use_bn else torch.nn.Identity()
+        # (the last block, without BatchNorm, feeds tanh: fused into its epilogue, image in float32)
+        self.up_sample = gnn.ConvTranspose2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1, activation=None if use_bn else "tanh",
+                                             out_dtype=None if use_bn else torch.float32)
+        self.batch_norm = _batch_norm(out_ch) if use_bn else torch.nn.Identity()
         self.leaky_relu = torch.nn.ReLU()
 
     def forward(self, x):
@@ -40,7 +63,7 @@ class Generator(torch.nn.Module):
     def __init__(self, ch=64, image_dim=3, interpolation=True):
         super().__init__()
         self.interpolation = interpolation   # accepted and ignored, as in the reference
-        self.downsample_1 = gnn.Conv2d(image_dim, ch, kernel_size=4, stride=2, padding=1)
+        self.downsample_1 = gnn.Conv2d(image_dim, ch, kernel_size=4, stride=2, padding=1, out_dtype=_ACT_DTYPE)
         self.downsample_2 = DownSample(ch, ch * 2)
         self.downsample_3 = DownSample(ch * 2, ch * 4)
         self.downsample_4 = DownSample(ch * 4, ch * 8)
@@ -63,7 +86,7 @@ class Generator(torch.nn.Module):
         def drop(t, i):
             if dropout_masks is None:
                 return torch.nn.functional.dropout(t, 0.5, training=True)
-            return t * dropout_masks[i]
+            return t * dropout_masks[i].to(t.dtype)
 
         x1 = self.downsample_1(x)
         x2 = self.downsample_2(x1)
@@ -80,8 +103,7 @@ class Generator(torch.nn.Module):
         out = self.upsample_5(torch.cat((out, x4), dim=1))
         out = self.upsample_6(torch.cat((out, x3), dim=1))
         out = self.upsample_7(torch.cat((out, x2), dim=1))
-        out = self.upsample_8(torch.cat((out, x1), dim=1))
-        return torch.tanh(out)
+        return self.upsample_8(torch.cat((out, x1), dim=1))      # tanh in the transposed convolution's epilogue
 
 
 class ResNetBlock(torch.nn.Module):
@@ -142,18 +164,19 @@ class GeneratorHD(torch.nn.Module):
 class Discriminator(torch.nn.Module):
     def __init__(self, image_dim=6, ch=64):
         super().__init__()
-        self.conv_1 = gnn.Conv2d(image_dim, ch, 4, 2, 1)
+        self.fused = _FUSED_NORM
+        self.conv_1 = gnn.Conv2d(image_dim, ch, 4, 2, 1, activation="relu", out_dtype=_ACT_DTYPE)      # ReLU in the epilogue
         self.conv_2 = gnn.Conv2d(ch, ch * 2, 4, 2, 1)
-        self.batch_norm_1 = torch.nn.BatchNorm2d(ch * 2)
+        self.batch_norm_1 = _batch_norm(ch * 2, "relu")
         self.conv_3 = gnn.Conv2d(ch * 2, ch * 4, 4, 2, 1)
-        self.batch_norm_2 = torch.nn.BatchNorm2d(ch * 4)
+        self.batch_norm_2 = _batch_norm(ch * 4, "relu")
         self.conv_4 = gnn.Conv2d(ch * 4, ch * 8, 4, 1, 1)
-        self.batch_norm_3 = torch.nn.BatchNorm2d(ch * 8)
-        self.conv_5 = gnn.Conv2d(ch * 8, 1, 4, 1, 1)
+        self.batch_norm_3 = _batch_norm(ch * 8, "relu")
+        self.conv_5 = gnn.Conv2d(ch * 8, 1, 4, 1, 1, out_dtype=torch.float32)
 
     def forward(self, x, y, return_features=False):
-        relu = torch.nn.functional.relu
-        o1 = relu(self.conv_1(torch.cat((x, y), dim=1)))
+        relu = (lambda t: t) if self.fused else torch.nn.functional.relu       # (fused: inside the norm kernel)
+        o1 = self.conv_1(torch.cat((x, y), dim=1))
         o2 = relu(self.batch_norm_1(self.conv_2(o1)))
         o3 = relu(self.batch_norm_2(self.conv_3(o2)))
         o4 = relu(self.batch_norm_3(self.conv_4(o3)))

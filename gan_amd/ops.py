@@ -222,6 +222,12 @@ def _out_dtype(t, code):
     return t.dtype if code == _OUT_SAME else (torch.bfloat16 if code == _OUT_BF16 else torch.float32)
 
 
+def _small_output_in_f32(numel, dtype, act):
+    """Small outputs with long reductions run as split reductions, which add fp32 partial tiles into the output: a bf16
+    result of that size is computed in fp32 and rounded afterwards (a few KB)."""
+    return dtype == torch.bfloat16 and act == 0 and numel <= 65536
+
+
 def _code_of(dtype):
     return _OUT_BF16 if dtype == torch.bfloat16 else _OUT_F32
 
@@ -354,7 +360,9 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
         raise RuntimeError(f"ganconv: kernel ({kh}x{kw}) larger than padded input ({H + 2 * padding}x{W + 2 * padding})")
     Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
     x = _nhwc(x)
-    y = torch.empty((N, Cout, Ho, Wo), dtype=_out_dtype(x, out_dtype), device=x.device, memory_format=torch.channels_last)
+    want = _out_dtype(x, out_dtype)
+    narrow = _small_output_in_f32(N * Cout * Ho * Wo, want, act)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32 if narrow else want, device=x.device, memory_format=torch.channels_last)
     if _dma_ok(x, Cin, Cout, precision):
         x = _to_bf16(x)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(y))
@@ -363,7 +371,7 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_fprop")
-    return y
+    return y.to(want) if narrow else y
 
 
 @conv_fprop.register_fake
@@ -388,7 +396,9 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
     if (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
         raise RuntimeError(f"ganconv: input size ({H}x{W}) is inconsistent with the gradient's ({Ho}x{Wo})")
     gy = _nhwc(gy)
-    gx = torch.empty((N, Cin, H, W), dtype=_out_dtype(gy, out_dtype), device=gy.device, memory_format=torch.channels_last)
+    want = _out_dtype(gy, out_dtype)
+    narrow = _small_output_in_f32(N * Cin * H * W, want, act)
+    gx = torch.empty((N, Cin, H, W), dtype=torch.float32 if narrow else want, device=gy.device, memory_format=torch.channels_last)
     if _dma_ok(gy, Cout, Cin, precision):
         gy = _to_bf16(gy)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gx), precision, _dtype_code(gy))
@@ -397,7 +407,7 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(gx.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_dgrad")
-    return gx
+    return gx.to(want) if narrow else gx
 
 
 @conv_dgrad.register_fake
@@ -440,6 +450,38 @@ def _(x, gy, kh, kw, stride, padding, precision):
     return x.new_empty((gy.shape[1], x.shape[1], kh, kw), dtype=torch.float32)
 
 
+@torch.library.custom_op("ganconv::channel_sum", mutates_args=())
+def channel_sum(x: Tensor) -> Tensor:
+    """x.sum((0, 2, 3)) in float32: the bias gradient of a convolution (fixed summation order when C % 4 == 0)."""
+    _check_cuda(x)
+    x = _nhwc(x)
+    N, C, H, W = x.shape
+    P = N * H * W
+    L = _lib.lib()
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    nws = L.gc_channel_sum_workspace_bytes(P, C)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws > 0 else None
+    _lib.check(L.gc_channel_sum(_ptr(x), _ptr(out), _optr(ws), nws, P, C, _dtype_code(x), _stream()), "gc_channel_sum")
+    return out
+
+
+@channel_sum.register_fake
+def _(x):
+    return x.new_empty(x.shape[1], dtype=torch.float32)
+
+
+def _channel_sum_setup(ctx, inputs, output):
+    ctx.shape, ctx.dtype = inputs[0].shape, inputs[0].dtype
+
+
+def _channel_sum_backward(ctx, g):
+    # linear in x: the gradient is a broadcast (reached when a penalty differentiates through a bias gradient)
+    return g[None, :, None, None].expand(ctx.shape).to(ctx.dtype)
+
+
+torch.library.register_autograd("ganconv::channel_sum", _channel_sum_backward, setup_context=_channel_sum_setup)
+
+
 # ---- autograd: each formula uses only the three ops above -------------------------------------------------------
 def _fprop_setup(ctx, inputs, output):
     x, w, bias, stride, padding, precision, wkey, act, slope, _ = inputs
@@ -470,7 +512,7 @@ def _fprop_backward(ctx, gy):
         if ctx.needs_input_grad[1]:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
-        gb = gy.sum((0, 2, 3), dtype=torch.float32)
+        gb = channel_sum(gy)
     return gx, gw, gb, None, None, None, None, None, None, None
 
 
@@ -506,7 +548,7 @@ def _dgrad_backward(ctx, u):
         if ctx.needs_input_grad[1]:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2]:
-        g_b = u.sum((0, 2, 3), dtype=torch.float32)
+        g_b = channel_sum(u)
     return g_gy, g_w, g_b, None, None, None, None, None, None, None, None, None
 
 

@@ -194,6 +194,13 @@ int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma,
                               const float* save_rstd, void* gx, float* ggamma, float* gbeta, void* workspace, size_t workspace_bytes,
                               int32_t N, int32_t HW, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
 
+/* out[c] = sum over the P pixels of x[p][c] (x NHWC fp32 or bf16, dense): the bias gradient of a convolution with
+ * bias=True (Pix2Pix/models.py:17,225-232; StyleGAN/model.py:72; BigGAN/model.py:57), which ATen computes with a
+ * reduction kernel of its own.  C a multiple of 4: two launches, fixed summation order, workspace from
+ * gc_channel_sum_workspace_bytes; other channel counts: element loads and fp32 atomic adds, no workspace. */
+size_t gc_channel_sum_workspace_bytes(int64_t P, int32_t C);
+int gc_channel_sum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, void* stream);
+
 /* BatchNorm over a batch that is sharded across GPUs (one process per GPU).  The reference's torch.nn.DataParallel
  * (StyleGAN/train.py:121-125, BigGAN/train.py:150-154) normalises each replica with its own statistics; these three
  * calls let a data-parallel host reproduce the single-device result of BatchNorm2d (BasicGANs/models.py:37,79) instead:

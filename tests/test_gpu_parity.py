@@ -258,6 +258,21 @@ def test_blur(gan, ops_golden):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 8, 1, 1), (3, 3, 9, 7), (1, 1, 30, 30), (2, 16, 64, 64), (4, 100, 5, 5), (2, 64, 130, 70), (0, 8, 4, 4)])
+def test_channel_sum_exact_on_small_integers(gan, shape, dt):
+    """gan_amd.ops.channel_sum (the bias gradient of the convolutions) on small integers: every partial sum is exact in
+    fp32, so the result must equal the integer sum whatever the order; also its gradient (a broadcast)."""
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randint(-8, 9, shape, generator=g).float()
+    xs = x.cuda().to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = gan.ops.channel_sum(xs)
+    assert out.dtype == torch.float32 and torch.equal(out.cpu(), x.sum((0, 2, 3)))
+    w = torch.arange(shape[1], dtype=torch.float32, device="cuda")
+    (out * w).sum().backward()
+    assert xs.grad.dtype == dt and torch.equal(xs.grad.float().cpu(), w.cpu()[None, :, None, None].expand(shape))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 8, 1, 1), (1, 12, 5, 7), (2, 16, 16, 16), (1, 8, 17, 33), (3, 64, 35, 20), (1, 4, 64, 3), (2, 128, 48, 48)])
 def test_blur_shapes_against_oracle(gan, shape, dt):
     """Strip boundaries (16 rows), single-pixel images, channel groups of 4 and 8, both storage types; inputs are small
@@ -586,13 +601,17 @@ def test_pix2pixhd_generator_against_reference_trace(gan, golden_dir, prec, tol,
         gan.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec,tol,coarse", [("fp32x3", 2e-4, 5e-2), ("bf16", 2e-2, 3e-1)])
-def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse):
+@pytest.mark.parametrize("prec,tol,coarse,fast", [("fp32x3", 2e-4, 5e-2, False), ("bf16", 2e-2, 3e-1, False), ("fp32x3", 2e-4, 5e-2, "norm"),
+                                                  ("bf16", 3e-2, 4e-1, "norm+bf16")],
+                         ids=["fp32x3", "bf16", "fp32x3_fused_norm", "bf16_storage_fused_norm"])
+def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse, fast):
     """One Pix2Pix step (U-Net + PatchGAN at 256x256, reference trace with ch = 8, batch 2): losses, generator output,
     discriminator gradients, generator gradient norms."""
     from gan_amd.harness import pix2pix as P
     from test_oracle_golden import pix2pix_setup
     gan.set_precision(prec)
+    P.set_fused_norm(bool(fast))
+    P.set_activation_dtype(torch.bfloat16 if fast == "norm+bf16" else None)
     try:
         z, rec, G, D, real, label, masks_d, masks_g = pix2pix_setup(golden_dir, lambda ch: P.Generator(ch=ch), lambda ch: P.Discriminator(ch=ch))
         assert list(G.state_dict().keys()) == list(R.P2PGenerator(ch=4).state_dict().keys())
@@ -606,7 +625,8 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
             want = z["d.gradD." + k]
             if np.linalg.norm(want) < 1e-5 * biggest:
                 # the bias of a conv that feeds BatchNorm has a mathematically zero gradient: only rounding noise to compare
-                assert p.grad.norm().item() < 1e-4 * biggest, k
+                # (it grows with the storage precision: 3.5e-4 of the largest gradient with bf16 activations)
+                assert p.grad.norm().item() < max(1e-4, 2e-2 * tol) * biggest, k
                 continue
             assert_grad_close(p.grad, want, tol, coarse, k)
         g_err, fake = P.generator_phase(G, D, real, label, 100.0, masks_g)
@@ -617,7 +637,7 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
             want = z["g.gradG_norm." + k][0]
             got = p.grad.double().norm().item()
             if want < 1e-5 * biggest:
-                assert got < 1e-4 * biggest, k
+                assert got < max(1e-4, 2e-2 * tol) * biggest, k
                 continue
             assert abs(got - want) < coarse * want, (k, got, want)
             ref = z["g.gradG." + k]
@@ -626,6 +646,8 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
             assert_grad_close(g, ref, tol, 2 * coarse, k)
     finally:
         gan.set_precision("bf16")
+        P.set_fused_norm(False)
+        P.set_activation_dtype(None)
 
 
 # (bf16: the gradients of the noise scaling factors and of the biases are sums of signed terms that largely cancel; the

@@ -92,6 +92,10 @@ def zero(*nets):
 
 rows = []
 
+if FAST:
+    pix2pix.set_activation_dtype(torch.bfloat16)
+    pix2pix.set_fused_norm(True)
+
 if want("pix2pix"):
     # ---- Pix2Pix: U-Net (ch 64) + PatchGAN on 256x256, batch 4
     B = 8 if FULL else 4
