@@ -419,12 +419,42 @@ __global__ __launch_bounds__(kThreads) void channel_sum_partial_kernel(const BnP
   if (cok && tl == 0) *reinterpret_cast<f32x4*>(p.part + (size_t)slab * p.C + c) = s;
 }
 
+// 16 channels x 16 slab lanes per workgroup: lane l adds slabs l, l + 16, ... (independent loads), then the 16 lanes are
+// added in a fixed order.
 __global__ __launch_bounds__(kThreads) void channel_sum_final_kernel(const float* part, float* out, int slabs, int C) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[kThreads];
+  const int t = threadIdx.x, tc = t & 15, lane = t >> 4;
+  const int c = blockIdx.x * 16 + tc;
   float s = 0.f;
-  for (int k = 0; k < slabs; k++) s += part[(size_t)k * C + c];
-  out[c] = s;
+  if (c < C)
+    for (int k = lane; k < slabs; k += 16) s += part[(size_t)k * C + c];
+  red[t] = s;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    for (int l = 1; l < 16; l++) s += red[l * 16 + tc];
+    out[c] = s;
+  }
+}
+
+// Few pixels: one launch, a workgroup owns 16 channels and all pixels (same summation tree for every launch).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void channel_sum_small_kernel(const void* x, float* out, int P, int C) {
+  __shared__ f32x4 red[kThreads];
+  const int t = threadIdx.x, tq = t & (kSmallQB - 1), tl = t / kSmallQB;
+  const int c = (blockIdx.x * kSmallQB + tq) * 4;
+  const bool cok = c < C;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    int pix = tl;
+    for (; pix + 3 * kSmallPL < P; pix += 4 * kSmallPL) {      // four independent loads in flight
+      const f32x4 a = load4<T>(x, (size_t)pix * C + c), b = load4<T>(x, (size_t)(pix + kSmallPL) * C + c);
+      const f32x4 d = load4<T>(x, (size_t)(pix + 2 * kSmallPL) * C + c), e = load4<T>(x, (size_t)(pix + 3 * kSmallPL) * C + c);
+      s += (a + b) + (d + e);
+    }
+    for (; pix < P; pix += kSmallPL) s += load4<T>(x, (size_t)pix * C + c);
+  }
+  s = bn_small_sum(s, red, tq, tl);
+  if (cok && tl == 0) *reinterpret_cast<f32x4*>(out + c) = s;
 }
 
 static void bn_geometry(BnParams& p) {
@@ -643,6 +673,13 @@ int gc_channel_sum(const void* x, float* out, void* workspace, size_t workspace_
     ProfScope ps("gc::colsum_kernel", 0.0, s);
     return launch_colsum(x, out, (int)P, C, C, 0, dtype == GC_BF16, s);
   }
+  if (P <= kSmallP && !misaligned(out, 15)) {
+    ProfScope ps("gc::channel_sum_kernel", 0.0, s);
+    const dim3 grid((unsigned)((C / 4 + kSmallQB - 1) / kSmallQB));
+    if (dtype == GC_F32) hipLaunchKernelGGL(channel_sum_small_kernel<float>, grid, dim3(kThreads), 0, s, x, out, (int)P, C);
+    else hipLaunchKernelGGL(channel_sum_small_kernel<uint16_t>, grid, dim3(kThreads), 0, s, x, out, (int)P, C);
+    return check_hip(hipGetLastError(), "channel sum launch");
+  }
   const size_t need = gc_channel_sum_workspace_bytes(P, C);
   if (workspace == nullptr || misaligned(workspace, 15) || workspace_bytes < need) {
     set_error("gc_channel_sum: workspace of %zu bytes given, %zu needed (16-byte aligned)", workspace_bytes, need);
@@ -656,7 +693,7 @@ int gc_channel_sum(const void* x, float* out, void* workspace, size_t workspace_
   ProfScope ps("gc::channel_sum_kernel", 0.0, s);
   if (dtype == GC_F32) hipLaunchKernelGGL(channel_sum_partial_kernel<float>, dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
   else hipLaunchKernelGGL(channel_sum_partial_kernel<uint16_t>, dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p.part, out, p.slabs, C);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)((C + 15) / 16)), dim3(kThreads), 0, s, p.part, out, p.slabs, C);
   return check_hip(hipGetLastError(), "channel sum launch");
 }
 
