@@ -314,7 +314,9 @@ def test_instnorm_act_first_and_second_order(gan, shape, slope):
         assert rel(a, b) < 2e-5, name
 
 
-@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (256, 8, 5, 3), (3, 512, 4, 4), (2, 100, 7, 9)])
+# (at most 4096 pixels: the single-launch kernels; more: statistics / finalize / apply launches)
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (256, 8, 5, 3), (3, 512, 4, 4), (2, 100, 7, 9), (1, 8, 64, 64), (1, 8, 64, 65),
+                                   (8, 64, 32, 32), (2, 32, 70, 61)])
 @pytest.mark.parametrize("activation", ["relu", "leaky_relu", None])
 def test_batchnorm_act_against_torch(gan, shape, activation):
     """Fused BatchNorm2d + activation: outputs, all three gradients, running statistics (two steps) and the
@@ -1105,7 +1107,7 @@ def test_mixed_storage_dtypes_against_oracle(gan, case):
     assert rel(gw, oracle.conv2d_wgrad(x, gy, w.shape, s, p)) < TOL_EXACT
 
 
-@pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 128, 16, 16), (2, 64, 32, 32)])
+@pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 128, 16, 16), (2, 64, 32, 32), (4, 64, 48, 48)])
 def test_norm_kernels_bf16_storage(gan, shape):
     """InstanceNorm (+LeakyReLU, first and second order) and BatchNorm (+ReLU, first order) on bf16 tensors equal the
     fp32 kernels applied to the same (bf16-representable) values, up to the rounding of the stored results."""
