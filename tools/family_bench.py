@@ -122,6 +122,42 @@ if want("pix2pix"):
     kernel_table(p2p_gpu, "Pix2Pix")
     del G, D, Gr, Dr
 
+if want("dcgan"):
+    # ---- DCGAN 64x64 (hidden 64, nz 100), batch 128: one discriminator + one generator update (BasicGANs/DCGAN.py:165-181)
+    B = 128
+    act = torch.bfloat16 if FAST else torch.float32
+    torch.manual_seed(5000)
+    G = basic_gans.Generator(100, 64, 3, 64, activation_dtype=act).to(dev)
+    D = basic_gans.Discriminator(3, 64, 64, is_wgan=False, activation_dtype=act).to(dev)
+    G.apply(basic_gans.weights_init); D.apply(basic_gans.weights_init)
+    Gr, Dr = ref_models.Generator(100, 64, 3, resolution=64), ref_models.Discriminator(3, 64, resolution=64)
+    Gr.apply(ref_models.weights_init); Dr.apply(ref_models.weights_init)
+    oG = gan_amd.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999)); oD = gan_amd.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    oGr = torch.optim.Adam(Gr.parameters(), lr=2e-4, betas=(0.5, 0.999)); oDr = torch.optim.Adam(Dr.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    real, z = torch.rand(B, 3, 64, 64) * 2 - 1, torch.randn(B, 100, 1, 1)
+    rg, zg = real.to(dev).contiguous(memory_format=torch.channels_last), z.to(dev)
+
+
+    def dc_gpu():
+        oD.zero_grad(set_to_none=False)
+        *_, fake = basic_gans.dcgan_discriminator_phase(G, D, rg, zg)
+        oD.step()
+        oG.zero_grad(set_to_none=False)
+        basic_gans.dcgan_generator_phase(D, fake)
+        oG.step()
+
+
+    def dc_cpu():
+        for _ in range(4):     # four steps, scaled below: one step is too short to time
+            ref_models.dcgan_train_step(Gr, Dr, oGr, oDr, real, z)
+
+
+    t_cpu = cpu_time(dc_cpu) / 4 * CPU_B / B       # (the table divides CPU_B by the time: rescale to the full batch)
+    rows.append((f"DCGAN 64x64, batch {B}, with both Adam steps", B, gpu_time(dc_gpu), t_cpu, graph_time(dc_gpu)))
+    note("dcgan done")
+    kernel_table(dc_gpu, "DCGAN")
+    del G, D, Gr, Dr
+
 if want("pix2pixhd"):
     # ---- Pix2PixHD global generator (ch 64, 9 residual blocks) + PatchGAN on 256x256 (Pix2Pix/train.py:27 selects it by name)
     B = 8 if FULL else 4
