@@ -95,6 +95,83 @@ unsigned grid_for(size_t total) {
 
 using namespace gc;
 
+// Reflection padding by `pad` pixels on all four sides (torch.nn.ReflectionPad2d; reference Pix2Pix/models.py:162,185,
+// 204,210: in front of the 7x7 and 3x3 convolutions of the Pix2PixHD generator), NHWC, and its adjoint:
+//   forward   y[n, oh, ow, :] = x[n, r(oh - pad, H), r(ow - pad, W), :],  r(i, L) = i < 0 ? -i : (i >= L ? 2 (L - 1) - i : i)
+//   adjoint   gx[n, h, w, :]  = sum of gy over the (at most 3 x 3) padded positions that read (h, w)
+// One thread moves 8 channels of one output pixel; H, W are the extents of the unpadded tensor in both directions.
+__device__ __forceinline__ int reflect_index(int i, int L) { return i < 0 ? -i : (i >= L ? 2 * (L - 1) - i : i); }
+
+// padded positions that read unpadded index h (extent L): h + pad always, pad - h for 1 <= h <= pad, and
+// pad + 2 (L - 1) - h for L - 1 - pad <= h <= L - 2
+__device__ __forceinline__ int reflect_sources(int h, int L, int pad, int (&src)[3]) {
+  int n = 0;
+  src[n++] = h + pad;
+  if (h >= 1 && h <= pad) src[n++] = pad - h;
+  if (h >= L - 1 - pad && h <= L - 2) src[n++] = pad + 2 * (L - 1) - h;
+  return n;
+}
+
+template <bool ADJOINT, typename T>
+__global__ __launch_bounds__(kThreads) void reflect_pad_kernel(const T* x, T* y, uint32_t total, int H, int W, int C8, int pad) {
+  const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= total) return;
+  const int HP = H + 2 * pad, WP = W + 2 * pad;
+  const int OH = ADJOINT ? H : HP, OW = ADJOINT ? W : WP;          // extents of the tensor this launch writes
+  const int c = (int)(e % (uint32_t)C8);
+  uint32_t r = e / (uint32_t)C8;
+  const int ow = (int)(r % (uint32_t)OW);
+  r /= (uint32_t)OW;
+  const int oh = (int)(r % (uint32_t)OH);
+  const size_t n = r / (uint32_t)OH;
+  if (!ADJOINT) {
+    const int h = reflect_index(oh - pad, H), w = reflect_index(ow - pad, W);
+    Vec8<T>::load(x + (((n * H + h) * W + w) * C8 + c) * 8).store(y + (size_t)e * 8);
+  } else {
+    int hs[3], ws[3];
+    const int nh = reflect_sources(oh, H, pad, hs), nw = reflect_sources(ow, W, pad, ws);
+    Vec8<T> acc;
+    acc.a = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc.b = acc.a;
+    for (int i = 0; i < nh; i++)
+      for (int j = 0; j < nw; j++) {
+        const Vec8<T> v = Vec8<T>::load(x + (((n * HP + hs[i]) * WP + ws[j]) * C8 + c) * 8);
+        acc.a += v.a;
+        acc.b += v.b;
+      }
+    acc.store(y + (size_t)e * 8);
+  }
+}
+
+static int reflect_launch(bool adjoint, const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
+                          void* stream) {
+  if (int e = check_args(x, y, N, H, W, C, dtype)) return e;
+  if (pad < 0 || pad >= H || pad >= W) { set_error("reflect_pad: the padding (%d) must be smaller than the extents (%dx%d)", pad, H, W); return GC_BAD_ARGUMENT; }
+  const size_t total = (size_t)N * (adjoint ? H : H + 2 * pad) * (adjoint ? W : W + 2 * pad) * (C / 8);
+  if (total == 0) return GC_OK;
+  if ((size_t)N * (H + 2 * pad) * (W + 2 * pad) * (C / 8) >= (1ull << 32) - kThreads) { set_error("reflect_pad: tensor too large"); return GC_UNSUPPORTED_GEOMETRY; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((total + kThreads - 1) / kThreads)), block(kThreads);
+  ProfScope ps(adjoint ? "gc::reflect_pad_kernel<adjoint>" : "gc::reflect_pad_kernel", 0.0, s);
+  if (dtype == GC_F32) {
+    if (adjoint) hipLaunchKernelGGL((reflect_pad_kernel<true, float>), grid, block, 0, s, (const float*)x, (float*)y, (uint32_t)total, H, W, C / 8, pad);
+    else hipLaunchKernelGGL((reflect_pad_kernel<false, float>), grid, block, 0, s, (const float*)x, (float*)y, (uint32_t)total, H, W, C / 8, pad);
+  } else {
+    if (adjoint) hipLaunchKernelGGL((reflect_pad_kernel<true, uint16_t>), grid, block, 0, s, (const uint16_t*)x, (uint16_t*)y, (uint32_t)total, H, W, C / 8, pad);
+    else hipLaunchKernelGGL((reflect_pad_kernel<false, uint16_t>), grid, block, 0, s, (const uint16_t*)x, (uint16_t*)y, (uint32_t)total, H, W, C / 8, pad);
+  }
+  return check_hip(hipGetLastError(), "reflect_pad launch");
+}
+
+extern "C" int gc_reflect_pad(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype, void* stream) {
+  return reflect_launch(false, x, y, N, H, W, C, pad, dtype, stream);
+}
+
+extern "C" int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
+                                      void* stream) {
+  return reflect_launch(true, gy, gx, N, H, W, C, pad, dtype, stream);
+}
+
 extern "C" int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream) {
   if (int e = check_args(x, y, N, Ho, Wo, C, dtype)) return e;
   const size_t total = (size_t)N * Ho * Wo * (C / 8);

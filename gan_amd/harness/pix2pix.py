@@ -114,9 +114,9 @@ class ResNetBlock(torch.nn.Module):
     def __init__(self, ch):
         super().__init__()
         self.main = torch.nn.Sequential(
-            torch.nn.ReflectionPad2d(1), gnn.Conv2d(ch, ch, kernel_size=3, padding=0), gnn.BatchNormAct2d(ch, activation="relu"),
+            gnn.ReflectionPad2d(1), gnn.Conv2d(ch, ch, kernel_size=3, padding=0), gnn.BatchNormAct2d(ch, activation="relu"),
             torch.nn.Identity(), torch.nn.Dropout(0.5),
-            torch.nn.ReflectionPad2d(1), gnn.Conv2d(ch, ch, kernel_size=3, padding=0), gnn.BatchNormAct2d(ch, activation=None))
+            gnn.ReflectionPad2d(1), gnn.Conv2d(ch, ch, kernel_size=3, padding=0), gnn.BatchNormAct2d(ch, activation=None))
 
     def forward(self, x, mask=None):
         h = self.main[2](self.main[1](self.main[0](x)))
@@ -134,7 +134,7 @@ class GeneratorHD(torch.nn.Module):
         super().__init__()
         nn = torch.nn
         self.main = nn.ModuleList()
-        self.main.append(nn.Sequential(nn.ReflectionPad2d(3), gnn.Conv2d(input_dim, ch, kernel_size=7, padding=0),
+        self.main.append(nn.Sequential(gnn.ReflectionPad2d(3), gnn.Conv2d(input_dim, ch, kernel_size=7, padding=0),
                                        gnn.BatchNormAct2d(ch, activation="relu"), nn.Identity()))
         for i in range(n_downsampling):
             m = 2 ** i
@@ -146,7 +146,7 @@ class GeneratorHD(torch.nn.Module):
             m = 2 ** (n_downsampling - i)
             self.main.append(nn.Sequential(gnn.ConvTranspose2d(ch * m, ch * m // 2, kernel_size=3, stride=2, padding=1, output_padding=1),
                                            gnn.BatchNormAct2d(ch * m // 2, activation="relu"), nn.Identity()))
-        self.main.append(nn.Sequential(nn.ReflectionPad2d(3), gnn.Conv2d(ch, output_dim, kernel_size=7, padding=0, activation="tanh"),
+        self.main.append(nn.Sequential(gnn.ReflectionPad2d(3), gnn.Conv2d(ch, output_dim, kernel_size=7, padding=0, activation="tanh"),
                                        nn.Identity()))
 
     def forward(self, x, dropout_masks=None):

@@ -100,6 +100,19 @@ class UpsampleNearest2x(torch.nn.Module):
         return F.upsample_nearest2x(input)
 
 
+class ReflectionPad2d(torch.nn.ReflectionPad2d):
+    """torch.nn.ReflectionPad2d on the NHWC padding kernel (reference Pix2Pix/models.py:162,185,204,210) when all four
+    sides are padded alike, the tensor lives on the GPU in fp32 or bf16 and its channel count is a multiple of 8;
+    anything else (the three-channel image in front of the first convolution) goes to the torch operator."""
+
+    def forward(self, input):
+        p = self.padding
+        if (input.is_cuda and input.dim() == 4 and len(set(p)) == 1 and input.shape[1] % 8 == 0 and 0 < p[0] < min(input.shape[2:])
+                and input.dtype in (torch.float32, torch.bfloat16)):
+            return ops.reflect_pad(input, int(p[0]))
+        return super().forward(input)
+
+
 class InstanceNormAct2d(torch.nn.Module):
     """InstanceNorm2d(affine=False, track_running_stats=False) followed by LeakyReLU(negative_slope), or by nothing
     when negative_slope is None, as ONE kernel with hand-written backward and double-backward kernels.  Holds no

@@ -992,6 +992,49 @@ torch.library.register_autograd("ganconv::pool2x2", lambda ctx, g: (replicate2x(
 torch.library.register_autograd("ganconv::replicate2x", lambda ctx, g: (pool2x2(g, ctx.scale), None), setup_context=_scale_ctx)
 
 
+# ---- reflection padding (Pix2Pix/models.py:162,185,204,210) and its adjoint, each other's gradient ---------------
+def _reflect(fn_name, x, pad, H, W, shape):
+    _check_cuda(x)
+    x = _nhwc(x)
+    y = torch.empty(shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _lib.check(getattr(_lib.lib(), fn_name)(_ptr(x), _ptr(y), x.shape[0], H, W, x.shape[1], pad, _dtype_code(x), _stream()), fn_name)
+    return y
+
+
+@torch.library.custom_op("ganconv::reflect_pad", mutates_args=())
+def reflect_pad(x: Tensor, pad: int) -> Tensor:
+    """torch.nn.ReflectionPad2d(pad)(x); C a multiple of 8, pad smaller than both extents."""
+    N, C, H, W = x.shape
+    return _reflect("gc_reflect_pad", x, pad, H, W, (N, C, H + 2 * pad, W + 2 * pad))
+
+
+@reflect_pad.register_fake
+def _(x, pad):
+    N, C, H, W = x.shape
+    return x.new_empty(N, C, H + 2 * pad, W + 2 * pad)
+
+
+@torch.library.custom_op("ganconv::reflect_pad_adjoint", mutates_args=())
+def reflect_pad_adjoint(gy: Tensor, pad: int) -> Tensor:
+    """The gradient of reflect_pad: every unpadded pixel collects the padded positions that read it."""
+    N, C, HP, WP = gy.shape
+    return _reflect("gc_reflect_pad_adjoint", gy, pad, HP - 2 * pad, WP - 2 * pad, (N, C, HP - 2 * pad, WP - 2 * pad))
+
+
+@reflect_pad_adjoint.register_fake
+def _(gy, pad):
+    N, C, HP, WP = gy.shape
+    return gy.new_empty(N, C, HP - 2 * pad, WP - 2 * pad)
+
+
+def _pad_ctx(ctx, inputs, output):
+    ctx.pad = inputs[1]
+
+
+torch.library.register_autograd("ganconv::reflect_pad", lambda ctx, g: (reflect_pad_adjoint(g, ctx.pad), None), setup_context=_pad_ctx)
+torch.library.register_autograd("ganconv::reflect_pad_adjoint", lambda ctx, g: (reflect_pad(g, ctx.pad), None), setup_context=_pad_ctx)
+
+
 # ---- StyleGAN: noise injection -> LeakyReLU -> InstanceNorm -> style affine as one op (first-order backward) -----
 def _adain_args(x, noise, sf, ys, yb):
     _check_cuda(x, noise, sf, ys, yb)

@@ -255,6 +255,14 @@ int gc_noise_lrelu_adain_bwd(const void* x, const float* noise, const float* sf,
                              const float* r, const void* gout, void* gx, float* g_sf, float* g_ys, float* g_yb, void* workspace,
                              size_t workspace_bytes, int32_t N, int32_t HW, int32_t C, int32_t dtype, float slope, void* stream);
 
+/* torch.nn.ReflectionPad2d(pad) on NHWC tensors and its adjoint (the gradient of the padding), fp32 or bf16, C a multiple
+ * of 8, 16-byte aligned, pad < H and pad < W.  Reference: the reflection-padded 7x7 / 3x3 convolutions of the Pix2PixHD
+ * generator (Pix2Pix/models.py:162-163, 185-186, 204-205, 210-211).  H, W are the UNPADDED extents in both calls:
+ *   gc_reflect_pad         : x [N, H, W, C] -> y [N, H + 2 pad, W + 2 pad, C]
+ *   gc_reflect_pad_adjoint : gy [N, H + 2 pad, W + 2 pad, C] -> gx [N, H, W, C] */
+int gc_reflect_pad(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype, void* stream);
+int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype, void* stream);
+
 /* 2x2 sum-pooling and 2x nearest replication, NHWC, fp32 or bf16 (`dtype`), C a multiple of 8, 16-byte aligned:
  *   gc_pool2x2     : y[n,h,w,c] = scale * (x[n,2h,2w,c] + x[n,2h,2w+1,c] + x[n,2h+1,2w,c] + x[n,2h+1,2w+1,c]),  x is [N,2Ho,2Wo,C]
  *   gc_replicate2x : y[n,2h+a,2w+b,c] = scale * x[n,h,w,c] (a, b in {0,1}),  x is [N,H,W,C], y [N,2H,2W,C]

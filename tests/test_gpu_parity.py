@@ -258,6 +258,32 @@ def test_blur(gan, ops_golden):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape,pad", [((2, 8, 5, 7), 1), ((1, 16, 4, 4), 3), ((3, 64, 33, 20), 3), ((1, 8, 2, 9), 1), ((2, 24, 16, 16), 2)])
+def test_reflection_pad_and_its_gradient_against_torch(gan, shape, pad, dt):
+    """gan_amd.nn.ReflectionPad2d against torch.nn.ReflectionPad2d (Pix2Pix/models.py:162,185,204,210): a copy, so the
+    outputs are equal bit for bit; the gradient sums at most nine small integers (exact), also for extents where both
+    mirrors of a pixel exist (H = 4, pad = 3); the gradient of the gradient is the padding again."""
+    g = torch.Generator().manual_seed(3 + sum(shape))
+    x = torch.randint(-8, 9, shape, generator=g).float().cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    gy = torch.randint(-8, 9, (shape[0], shape[1], shape[2] + 2 * pad, shape[3] + 2 * pad), generator=g).float().cuda().to(dt)
+    xa, xb = x.clone().requires_grad_(True), x.clone().float().requires_grad_(True)
+    ya = gan.nn.ReflectionPad2d(pad)(xa)
+    yb = torch.nn.ReflectionPad2d(pad)(xb)
+    assert ya.dtype == dt and torch.equal(ya.float(), yb)
+    ga, = torch.autograd.grad(ya, xa, gy, create_graph=True)
+    gb, = torch.autograd.grad(yb, xb, gy.float())
+    assert torch.equal(ga.float(), gb.to(dt).float())
+    u = torch.randint(-4, 5, shape, generator=g).float().cuda().to(dt)
+    gy2 = gy.clone().requires_grad_(True)
+    back = gan.ops.reflect_pad_adjoint(gy2, pad)
+    gg, = torch.autograd.grad(back, gy2, u)
+    assert torch.equal(gg.float(), torch.nn.ReflectionPad2d(pad)(u.float()))
+    # three-channel images go to the torch operator
+    img = torch.randn(1, 3, 8, 8, device="cuda")
+    assert torch.equal(gan.nn.ReflectionPad2d(3)(img), torch.nn.ReflectionPad2d(3)(img))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 8, 1, 1), (3, 3, 9, 7), (1, 1, 30, 30), (2, 16, 64, 64), (4, 100, 5, 5), (2, 64, 130, 70), (0, 8, 4, 4)])
 def test_channel_sum_exact_on_small_integers(gan, shape, dt):
     """gan_amd.ops.channel_sum (the bias gradient of the convolutions) on small integers: every partial sum is exact in
