@@ -120,7 +120,7 @@ class ResNetBlock(torch.nn.Module):
 
     def forward(self, x, mask=None):
         h = self.main[2](self.main[1](self.main[0](x)))
-        h = self.main[4](h) if mask is None else h * mask
+        h = self.main[4](h) if mask is None else h * mask.to(h.dtype)
         return x + self.main[7](self.main[6](self.main[5](h)))
 
 
@@ -134,7 +134,7 @@ class GeneratorHD(torch.nn.Module):
         super().__init__()
         nn = torch.nn
         self.main = nn.ModuleList()
-        self.main.append(nn.Sequential(gnn.ReflectionPad2d(3), gnn.Conv2d(input_dim, ch, kernel_size=7, padding=0),
+        self.main.append(nn.Sequential(gnn.ReflectionPad2d(3), gnn.Conv2d(input_dim, ch, kernel_size=7, padding=0, out_dtype=_ACT_DTYPE),
                                        gnn.BatchNormAct2d(ch, activation="relu"), nn.Identity()))
         for i in range(n_downsampling):
             m = 2 ** i
@@ -146,7 +146,7 @@ class GeneratorHD(torch.nn.Module):
             m = 2 ** (n_downsampling - i)
             self.main.append(nn.Sequential(gnn.ConvTranspose2d(ch * m, ch * m // 2, kernel_size=3, stride=2, padding=1, output_padding=1),
                                            gnn.BatchNormAct2d(ch * m // 2, activation="relu"), nn.Identity()))
-        self.main.append(nn.Sequential(gnn.ReflectionPad2d(3), gnn.Conv2d(ch, output_dim, kernel_size=7, padding=0, activation="tanh"),
+        self.main.append(nn.Sequential(gnn.ReflectionPad2d(3), gnn.Conv2d(ch, output_dim, kernel_size=7, padding=0, activation="tanh", out_dtype=torch.float32),
                                        nn.Identity()))
 
     def forward(self, x, dropout_masks=None):

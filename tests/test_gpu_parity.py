@@ -589,8 +589,9 @@ def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched, fu
         gan.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec,tol,coarse", [("fp32x3", 2e-4, 5e-2), ("bf16", 2e-2, 5e-1)])
-def test_pix2pixhd_generator_against_reference_trace(gan, golden_dir, prec, tol, coarse):
+@pytest.mark.parametrize("prec,tol,coarse,bf16_storage", [("fp32x3", 2e-4, 5e-2, False), ("bf16", 2e-2, 5e-1, False), ("bf16", 3e-2, 6e-1, True)],
+                         ids=["fp32x3", "bf16", "bf16_storage"])
+def test_pix2pixhd_generator_against_reference_trace(gan, golden_dir, prec, tol, coarse, bf16_storage):
     """Forward + backward of the Pix2PixHD global generator (Pix2Pix/models.py:150-218, reference trace with ch = 8, two
     residual blocks, 64x64, batch 2): 7x7 convolutions behind reflection padding, stride-2 3x3 convolutions,
     ConvTranspose2d(k3, s2, p1, output_padding 1), fused BatchNorm + ReLU, tanh in the last convolution's epilogue.
@@ -599,6 +600,7 @@ def test_pix2pixhd_generator_against_reference_trace(gan, golden_dir, prec, tol,
     from gan_amd.harness import pix2pix as P
     from test_oracle_golden import pix2pixhd_setup
     gan.set_precision(prec)
+    P.set_activation_dtype(torch.bfloat16 if bf16_storage else None)
     try:
         z, G, label, target, masks = pix2pixhd_setup(golden_dir, lambda ch, nb: P.GeneratorHD(ch=ch, n_blocks=nb))
         G.cuda()
@@ -627,6 +629,7 @@ def test_pix2pixhd_generator_against_reference_trace(gan, golden_dir, prec, tol,
                 assert rel(b, z["buf." + k]) < 5 * tol, k
     finally:
         gan.set_precision("bf16")
+        P.set_activation_dtype(None)
 
 
 @pytest.mark.parametrize("prec,tol,coarse,fast", [("fp32x3", 2e-4, 5e-2, False), ("bf16", 2e-2, 3e-1, False), ("fp32x3", 2e-4, 5e-2, "norm"),
