@@ -13,6 +13,7 @@ struct WgradParams {
   int32_t K;             // N*Ho*Wo: length of the reduction
   int32_t k_per_split;   // multiple of the reduction step
   int32_t n_co_tiles, n_ci_tiles, splits;
+  int32_t y_elem;        // register-staged kernel, vector instantiation: the gy side still needs element loads (odd Cout)
   int32_t thin;          // 1: Cin <= 32; the tile's columns run over (tap, channel) jointly, channel padded to ICp
   int32_t ICp, icp_log2, ncols;   // thin mode: padded channels per tap, its log2, T * ICp
   int32_t n_tap_groups, tpt, cw_log2;   // LDS-DMA kernel: a 128-column tile holds tpt taps of (1 << cw_log2) channels

@@ -71,9 +71,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
     }
   }
 
-  auto load_chunk = [&](const T* src, int c_first, int c_limit, bool ok) -> u32x4 {
+  auto load_chunk = [&](const T* src, int c_first, int c_limit, bool ok, bool vec) -> u32x4 {
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (ALIGNED) {
+    if (ALIGNED && vec) {
       if (ok && c_first < c_limit) v = *reinterpret_cast<const u32x4*>(src);
     } else if (ok) {
       if (sizeof(T) == 4) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
     for (int i = 0; i < PY; i++) {
       const int k = kb + t / CPRY + RPPY * i;
       const int c = co0 + cy * EPC;
-      yreg[i] = load_chunk(gy + ((size_t)k * p.y_cstride + p.y_coff + c), c, p.Cout, k < kend);
+      yreg[i] = load_chunk(gy + ((size_t)k * p.y_cstride + p.y_coff + c), c, p.Cout, k < kend, p.y_elem == 0);
     }
 #pragma unroll
     for (int i = 0; i < PX; i++) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
       const int ih = ho_ * p.sh - p.ph + r, iw = wo_ * p.sw - p.pw + s;
       const bool ok = k < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       const int c = ci0 + cx * EPC;
-      xreg[i] = load_chunk(x + (((size_t)n * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff + c, c, p.Cin, ok);
+      xreg[i] = load_chunk(x + (((size_t)n * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff + c, c, p.Cin, ok, true);
     }
   };
 

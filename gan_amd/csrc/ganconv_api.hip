@@ -561,7 +561,10 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   const int epc = elems_per_chunk(d->x_dtype);
   const bool x_vec = aligned16(x) && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0);
   const bool y_vec = aligned16(gy) && (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
-  l.aligned = y_vec && (p.thin || x_vec);
+  // thin input: the template flag is about the gy side (the x side always takes element loads); otherwise it is about the
+  // x side, and a gy side with an odd channel count (1- and 3-channel outputs) takes element loads inside that kernel
+  l.aligned = p.thin ? y_vec : x_vec;
+  p.y_elem = (!p.thin && x_vec && !y_vec) ? 1 : 0;
   l.flops = conv_flops(d);
   if ((rc = l.dma ? launch_wgrad_dma(p, l, (hipStream_t)stream) : launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
   WgradReduceParams r;
