@@ -291,10 +291,13 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const BnParams p) {
   }
 }
 
-// Small tensors (at most kSmallP pixels): one launch per direction.  A workgroup owns 16 channels (4 quads x 64 pixel
+// Small tensors (at most kSmallPBn pixels): one launch per direction.  A workgroup owns 16 channels (4 quads x 64 pixel
 // lanes) and all pixels: sum, centred squares (from L1 / L2) and the apply sweep, the running statistics included -- the
 // three-launch form costs 25-30 us on such tensors for a few us of work.
 constexpr int kSmallP = 4096, kSmallQB = 4, kSmallPL = kThreads / kSmallQB;
+// (BatchNorm takes that form up to 1024 pixels only: its sweeps are chains of dependent loads, 16 per lane at that size;
+//  at 4096 pixels x 512 channels the single launch measured 48 us against 33 us for the three launches)
+constexpr int kSmallPBn = 1024;
 
 __device__ __forceinline__ f32x4 bn_small_sum(f32x4 v, f32x4* red, int tq, int tl) {
   red[tl * kSmallQB + tq] = v;
@@ -533,7 +536,7 @@ static int bn_forward(const void* x, void* y, void* y_bf16, const float* gamma, 
   hipStream_t s = (hipStream_t)stream;
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
-  if (training && nsamp == 0 && P <= kSmallP) {
+  if (training && nsamp == 0 && P <= kSmallPBn) {
     ProfScope ps("gc::bn_small_kernel<0>", 0.0, s);
     const dim3 sgrid((unsigned)((C / 4 + kSmallQB - 1) / kSmallQB));
     if (dtype == GC_F32) hipLaunchKernelGGL((bn_small_kernel<0, float>), sgrid, block, 0, s, p);
@@ -616,7 +619,7 @@ static int bn_backward(const void* x, const void* gy, const float* gamma, const 
   p.coef = phase == 2 ? const_cast<float*>(means) : p.part + (size_t)p.slabs * C * 2;
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
-  if (phase == 0 && nsamp == 0 && P <= kSmallP) {
+  if (phase == 0 && nsamp == 0 && P <= kSmallPBn) {
     ProfScope ps("gc::bn_small_kernel<1>", 0.0, s);
     const dim3 sgrid((unsigned)((C / 4 + kSmallQB - 1) / kSmallQB));
     if (dtype == GC_F32) hipLaunchKernelGGL((bn_small_kernel<1, float>), sgrid, block, 0, s, p);
