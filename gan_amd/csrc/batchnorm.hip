@@ -422,6 +422,56 @@ __global__ __launch_bounds__(kThreads) void channel_sum_partial_kernel(const BnP
   if (cok && tl == 0) *reinterpret_cast<f32x4*>(p.part + (size_t)slab * p.C + c) = s;
 }
 
+// The gradient through an activation that was fused into a convolution's epilogue, from the activation's OUTPUT y, and
+// the bias gradient of that convolution in the same sweep:  out = gy * act'(y),  slab sums of out (added by
+// channel_sum_final_kernel).  act'(y): ReLU y > 0; LeakyReLU y > 0 ? 1 : slope; tanh 1 - y^2; sigmoid y (1 - y).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void act_backward_sum_kernel(const BnParams p) {
+  __shared__ f32x4 red[kThreads];
+  const int t = threadIdx.x, tq = t & (kQB - 1), tl = t >> 4;
+  const int chunks = (p.C / 4 + kQB - 1) / kQB;
+  const int slab = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int c = (chunk * kQB + tq) * 4;
+  const bool cok = c < p.C;
+  int p0, p1, n;
+  slab_range(p, slab, p0, p1, n);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  auto one = [&](size_t o, f32x4 y, f32x4 g) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float d = p.act == GC_ACT_RELU ? (y[e] > 0.f ? 1.f : 0.f)
+                    : p.act == GC_ACT_LRELU ? (y[e] > 0.f ? 1.f : p.slope)
+                    : p.act == GC_ACT_TANH ? 1.f - y[e] * y[e] : y[e] * (1.f - y[e]);
+      r[e] = g[e] * d;
+    }
+    store4<T>(p.out, o, r);
+    if (sizeof(T) == 2) r = widen_bf16x4(cvt_bf16x4(r));      // the sum is that of the stored (rounded) values
+    s += r;
+  };
+  if (cok) {
+    int pix = p0 + tl;
+    for (; pix + 3 * kPL < p1; pix += 4 * kPL) {         // eight independent loads in flight
+      size_t o[4];
+      f32x4 y[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        o[u] = (size_t)(pix + u * kPL) * p.C + c;
+        y[u] = load4<T>(p.x, o[u]);
+        g[u] = load4<T>(p.gy, o[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) one(o[u], y[u], g[u]);
+    }
+    for (; pix < p1; pix += kPL) {
+      const size_t o = (size_t)pix * p.C + c;
+      one(o, load4<T>(p.x, o), load4<T>(p.gy, o));
+    }
+  }
+  s = bn_block_sum(s, red, tq, tl);
+  if (cok && tl == 0) *reinterpret_cast<f32x4*>(p.part + (size_t)slab * p.C + c) = s;
+}
+
 // 16 channels x 16 slab lanes per workgroup: lane l adds slabs l, l + 16, ... (independent loads), then the 16 lanes are
 // added in a fixed order.
 __global__ __launch_bounds__(kThreads) void channel_sum_final_kernel(const float* part, float* out, int slabs, int C) {
@@ -698,6 +748,38 @@ int gc_channel_sum(const void* x, float* out, void* workspace, size_t workspace_
   else hipLaunchKernelGGL(channel_sum_partial_kernel<uint16_t>, dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
   hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)((C + 15) / 16)), dim3(kThreads), 0, s, p.part, out, p.slabs, C);
   return check_hip(hipGetLastError(), "channel sum launch");
+}
+
+int gc_act_backward_channel_sum(const void* gy, const void* y, void* out, float* colsum, void* workspace, size_t workspace_bytes,
+                                int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream) {
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("gc_act_backward_channel_sum: unknown dtype"); return GC_BAD_ARGUMENT; }
+  if (act != GC_ACT_RELU && act != GC_ACT_LRELU && act != GC_ACT_TANH && act != GC_ACT_SIGMOID) {
+    set_error("gc_act_backward_channel_sum: activation must be ReLU, LeakyReLU, tanh or sigmoid"); return GC_BAD_ARGUMENT;
+  }
+  if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("gc_act_backward_channel_sum: bad shape"); return GC_BAD_ARGUMENT; }
+  if (C % 4 != 0) { set_error("gc_act_backward_channel_sum: channels must be a multiple of 4 (C=%d)", C); return GC_UNSUPPORTED_GEOMETRY; }
+  if (colsum == nullptr) { set_error("gc_act_backward_channel_sum: null pointer"); return GC_BAD_ARGUMENT; }
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) return zero_fill(colsum, sizeof(float) * C, s);
+  const unsigned am = dtype == GC_F32 ? 15 : 7;
+  if (gy == nullptr || y == nullptr || out == nullptr || misaligned(gy, am) || misaligned(y, am) || misaligned(out, am)) {
+    set_error("gc_act_backward_channel_sum: null or misaligned tensor"); return GC_BAD_ARGUMENT;
+  }
+  const size_t need = gc_channel_sum_workspace_bytes(P, C);
+  if (workspace == nullptr || misaligned(workspace, 15) || workspace_bytes < need) {
+    set_error("gc_act_backward_channel_sum: workspace of %zu bytes given, %zu needed (16-byte aligned)", workspace_bytes, need);
+    return GC_WORKSPACE_TOO_SMALL;
+  }
+  BnParams p{};
+  p.x = y; p.gy = gy; p.out = out; p.P = (int32_t)P; p.C = C; p.act = act; p.slope = slope;
+  bn_geometry(p);
+  p.part = (float*)workspace;
+  const int chunks = (C / 4 + kQB - 1) / kQB;
+  ProfScope ps("gc::act_backward_sum_kernel", 0.0, s);
+  if (dtype == GC_F32) hipLaunchKernelGGL(act_backward_sum_kernel<float>, dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
+  else hipLaunchKernelGGL(act_backward_sum_kernel<uint16_t>, dim3((unsigned)(p.slabs * chunks)), dim3(kThreads), 0, s, p);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)((C + 15) / 16)), dim3(kThreads), 0, s, p.part, colsum, p.slabs, C);
+  return check_hip(hipGetLastError(), "activation backward launch");
 }
 
 int gc_batchnorm_stats(const void* x, float* mean, float* var_unbiased, void* workspace, size_t workspace_bytes, int64_t P, int32_t C,

@@ -470,6 +470,34 @@ def _(x):
     return x.new_empty(x.shape[1], dtype=torch.float32)
 
 
+@torch.library.custom_op("ganconv::act_backward_sum", mutates_args=())
+def act_backward_sum(gy: Tensor, y: Tensor, act: int, slope: float) -> tuple[Tensor, Tensor]:
+    """(gy * act'(y), its sum over (N, H, W)): the gradient through an epilogue activation and the bias gradient of its
+    convolution in one sweep.  No autograd formula: the backward formulas use it only when nothing differentiates them."""
+    _check_cuda(gy, y)
+    gy, y = _nhwc(gy), _nhwc(y)
+    N, C, H, W = gy.shape
+    P = N * H * W
+    L = _lib.lib()
+    out = torch.empty_like(gy, memory_format=torch.channels_last)
+    colsum = torch.empty(C, dtype=torch.float32, device=gy.device)
+    nws = L.gc_channel_sum_workspace_bytes(P, C)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=gy.device)
+    _lib.check(L.gc_act_backward_channel_sum(_ptr(gy), _ptr(y), _ptr(out), _ptr(colsum), _ptr(ws), ws.numel(), P, C, _dtype_code(gy),
+                                             act, slope, _stream()), "gc_act_backward_channel_sum")
+    return out, colsum
+
+
+@act_backward_sum.register_fake
+def _(gy, y, act, slope):
+    return torch.empty_like(gy), gy.new_empty(gy.shape[1], dtype=torch.float32)
+
+
+def _act_sum_fusable(g, y):
+    return (g.is_cuda and g.dtype == y.dtype and g.dtype in (torch.float32, torch.bfloat16) and g.shape == y.shape and g.shape[1] % 4 == 0
+            and g.numel() > 0 and not (torch.is_grad_enabled() and (g.requires_grad or y.requires_grad)))
+
+
 def _channel_sum_setup(ctx, inputs, output):
     ctx.shape, ctx.dtype = inputs[0].shape, inputs[0].dtype
 
@@ -494,12 +522,16 @@ def _fprop_setup(ctx, inputs, output):
 
 def _fprop_backward(ctx, gy):
     stride, padding, precision, wkey, has_bias, act, slope = ctx.cfg
+    gb = None
     if act != 0:
         x, w, y = ctx.saved_tensors
-        gy = _act_backward(gy, y, act, slope)
+        if has_bias and ctx.needs_input_grad[2] and _act_sum_fusable(gy, y):
+            gy, gb = act_backward_sum(gy, y, act, slope)
+        else:
+            gy = _act_backward(gy, y, act, slope)
     else:
         x, w = ctx.saved_tensors
-    gx = gw = gb = None
+    gx = gw = None
     if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and gy.is_cuda:
         with _SideLaunch(gy.device) as side:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision)
@@ -511,7 +543,7 @@ def _fprop_backward(ctx, gy):
             gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype))
         if ctx.needs_input_grad[1]:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
-    if has_bias and ctx.needs_input_grad[2]:
+    if has_bias and ctx.needs_input_grad[2] and gb is None:
         gb = channel_sum(gy)
     return gx, gw, gb, None, None, None, None, None, None, None
 
@@ -530,12 +562,16 @@ def _dgrad_setup(ctx, inputs, output):
 
 def _dgrad_backward(ctx, u):
     stride, padding, precision, wkey, has_bias, act, slope = ctx.cfg
+    g_b = None
     if act != 0:
         gy, w, out = ctx.saved_tensors
-        u = _act_backward(u, out, act, slope)
+        if has_bias and ctx.needs_input_grad[2] and _act_sum_fusable(u, out):
+            u, g_b = act_backward_sum(u, out, act, slope)
+        else:
+            u = _act_backward(u, out, act, slope)
     else:
         gy, w = ctx.saved_tensors
-    g_gy = g_w = g_b = None
+    g_gy = g_w = None
     if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and u.is_cuda:
         with _SideLaunch(u.device) as side:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision)
@@ -547,7 +583,7 @@ def _dgrad_backward(ctx, u):
             g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype))
         if ctx.needs_input_grad[1]:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
-    if has_bias and ctx.needs_input_grad[2]:
+    if has_bias and ctx.needs_input_grad[2] and g_b is None:
         g_b = channel_sum(u)
     return g_gy, g_w, g_b, None, None, None, None, None, None, None, None, None
 

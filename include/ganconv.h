@@ -201,6 +201,14 @@ int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma,
 size_t gc_channel_sum_workspace_bytes(int64_t P, int32_t C);
 int gc_channel_sum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, void* stream);
 
+/* Backward of an activation that ran in a convolution's epilogue, together with that convolution's bias gradient:
+ *   out = gy * act'(y)  (from the activation's output y),  colsum[c] = sum over pixels of out.
+ * Replaces leaky_relu_backward / threshold_backward followed by a sum over (N, H, W) for the reference's
+ * Conv2d(bias=True) + ReLU / LeakyReLU pairs (Pix2Pix/models.py:235; StyleGAN/model.py:424-447).  NHWC fp32 or bf16, C a
+ * multiple of 4, workspace of gc_channel_sum_workspace_bytes(P, C) bytes.  First order only. */
+int gc_act_backward_channel_sum(const void* gy, const void* y, void* out, float* colsum, void* workspace, size_t workspace_bytes,
+                                int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
+
 /* BatchNorm over a batch that is sharded across GPUs (one process per GPU).  The reference's torch.nn.DataParallel
  * (StyleGAN/train.py:121-125, BigGAN/train.py:150-154) normalises each replica with its own statistics; these three
  * calls let a data-parallel host reproduce the single-device result of BatchNorm2d (BasicGANs/models.py:37,79) instead:
