@@ -95,6 +95,10 @@ class GradReducer:
         for w in self._works:
             if w is not None:
                 w.wait()
+        # (a phase that never armed the hooks -- gradients computed with torch.autograd.grad and added by the caller --
+        #  must find every bucket unlaunched again the next time)
+        self._works = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         if self.average and self.world > 1:
             for flat in self.buckets:
                 flat.div_(self.world)

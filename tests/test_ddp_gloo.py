@@ -64,6 +64,13 @@ def _worker(rank, world, port, q):
         red.all_reduce(); red.average_()
         grads3 = [p.grad.detach().clone() for p in D.parameters()]
         ok = ok and all(torch.allclose(a, b, rtol=1e-8, atol=1e-12) for a, b in zip(grads, grads3))
+        # a phase that never arms the hooks (gradients added by the caller), twice in a row: finish() must reduce both times
+        for _ in range(2):
+            red.zero_grad()
+            wgan_critic_phase(G, D, real[sl], z[sl], eps[sl], 10.0, None, True)
+            red.finish()
+            grads4 = [p.grad.detach().clone() for p in D.parameters()]
+            ok = ok and all(torch.allclose(a, b, rtol=1e-8, atol=1e-12) for a, b in zip(grads, grads4))
         q.put((rank, [g.numpy() for g in grads], len(red.buckets), ok))
     finally:
         dist.destroy_process_group()

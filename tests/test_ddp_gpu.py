@@ -1,0 +1,71 @@
+"""The data-parallel training cycle with two ranks on one GPU (gloo carries the gradient buckets), eager launches with the
+hook-driven reducer, concurrent chains, fused Adam.  Both ranks start from rank 0's parameters and see different data;
+after every cycle their parameters must be identical (the averaged gradients are), finite, and different from the
+start.  (The graph-per-phase form is covered on one rank in test_gpu_parity.py: with two processes sharing one GPU its
+replays did not complete -- a topology the product never runs, one process per GPU -- so it is not exercised here.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q, graphs):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gan_amd
+        from gan_amd.ddp import GradReducer
+        from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
+        B = 8
+        tr = WganGpTrainer(B, 32, 100, 64, device="cuda:0", reducer_factory=GradReducer, capturable=graphs, batch_real_fake=True,
+                           fused_adam=True, activation_dtype=torch.bfloat16, two_streams=True, seed=5000 + rank)
+        nets = list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers())
+        for p in nets:
+            dist.broadcast(p.data, 0)
+        start = torch.cat([p.detach().float().flatten() for p in tr.net_D.parameters()]).clone()
+        g = torch.Generator().manual_seed(77 + rank)
+        real, zs = synth_inputs(g, B, 100, 64, 6)
+        tr.set_inputs(real, zs, torch.rand(5, B, 1, 1, 1, generator=g))
+        if graphs:
+            tr.capture(warmup=1)
+        sums = []
+        for _ in range(2):
+            out = tr.cycle() if graphs else tr.cycle_eager()
+            torch.cuda.synchronize()
+            d = torch.cat([p.detach().float().flatten() for p in tr.net_D.parameters()])
+            gpar = torch.cat([p.detach().float().flatten() for p in tr.net_G.parameters()])
+            sums.append((d.double().sum().item(), d.double().abs().sum().item(), gpar.double().sum().item(), gpar.double().abs().sum().item(),
+                         bool(torch.isfinite(out).all()), float((d - start).abs().max())))
+        q.put((rank, sums))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphs", [False], ids=["eager_hooks"])
+def test_two_ranks_stay_in_step(graphs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graphs)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=280) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for cyc in range(2):
+        a, b = res[0][cyc], res[1][cyc]
+        assert a[4] and b[4]                                   # finite losses on both ranks
+        assert a[5] > 1e-5                                      # the critic moved
+        # the discriminator has no batch-coupled layer: identical averaged gradients -> identical parameters
+        assert a[0] == b[0] and a[1] == b[1], (cyc, a, b)
+        # the generator's BatchNorm statistics are per rank, its gradients are still averaged: parameters agree as well
+        assert a[2] == b[2] and a[3] == b[3], (cyc, a, b)
