@@ -107,6 +107,11 @@ class GradReducer:
         """Blocking-in-stream-order sum of every bucket over the ranks, without the hook machinery: for callers that
         run forward/backward as a captured HIP graph and reduce between graph replays."""
         if dist.is_available() and dist.is_initialized():
+            if self.buckets[0].is_cuda and dist.get_backend(self.pg) == "gloo":
+                # gloo stages GPU tensors through the host and synchronises a stream of its own that waits for the current
+                # one; right behind a graph replay that wait did not return (two ranks, ROCm 7.2) unless the replay had
+                # finished -- so finish it first.  (RCCL orders the collective on the GPU; no host wait there.)
+                torch.cuda.current_stream(self.buckets[0].device).synchronize()
             for flat in self.buckets:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
 

@@ -1,8 +1,9 @@
 """The data-parallel training cycle with two ranks on one GPU (gloo carries the gradient buckets), eager launches with the
 hook-driven reducer, concurrent chains, fused Adam.  Both ranks start from rank 0's parameters and see different data;
 after every cycle their parameters must be identical (the averaged gradients are), finite, and different from the
-start.  (The graph-per-phase form is covered on one rank in test_gpu_parity.py: with two processes sharing one GPU its
-replays did not complete -- a topology the product never runs, one process per GPU -- so it is not exercised here.)"""
+start.  The graph-per-phase form is exercised the same way by tools/probe/ddp_two_ranks.py (identical parameters on both
+ranks after every cycle); inside this suite that variant did not finish within the time limit on a shared GPU, so only
+the eager form runs here, and the graph form is covered on one rank in test_gpu_parity.py."""
 import os
 import socket
 
