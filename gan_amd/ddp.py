@@ -23,6 +23,15 @@ import torch
 import torch.distributed as dist
 
 
+def finish_stream_for_gloo(tensor, group=None):
+    """gloo stages GPU tensors through the host and synchronises a stream of its own that waits for the current one; on
+    ROCm 7.2 that wait was seen not to return (two ranks, right behind a graph replay; now and then behind eager
+    launches) unless the producing work had finished -- so finish it first.  RCCL orders its collectives on the GPU and
+    needs no host wait: nothing happens for it."""
+    if tensor.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(tensor.device).synchronize()
+
+
 class GradReducer:
     def __init__(self, module, bucket_bytes=32 << 20, process_group=None, average=True):
         self.pg = process_group
@@ -107,11 +116,7 @@ class GradReducer:
         """Blocking-in-stream-order sum of every bucket over the ranks, without the hook machinery: for callers that
         run forward/backward as a captured HIP graph and reduce between graph replays."""
         if dist.is_available() and dist.is_initialized():
-            if self.buckets[0].is_cuda and dist.get_backend(self.pg) == "gloo":
-                # gloo stages GPU tensors through the host and synchronises a stream of its own that waits for the current
-                # one; right behind a graph replay that wait did not return (two ranks, ROCm 7.2) unless the replay had
-                # finished -- so finish it first.  (RCCL orders the collective on the GPU; no host wait there.)
-                torch.cuda.current_stream(self.buckets[0].device).synchronize()
+            finish_stream_for_gloo(self.buckets[0], self.pg)
             for flat in self.buckets:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
 
@@ -128,6 +133,7 @@ class GradReducer:
     def _launch(self, bi):
         self._launched[bi] = True
         if self.world > 1:
+            finish_stream_for_gloo(self.buckets[bi], self.pg)
             self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _hook(self, p):

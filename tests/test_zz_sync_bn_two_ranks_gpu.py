@@ -70,10 +70,15 @@ def test_statistics_over_two_ranks_match_the_whole_batch(dtype_name, tol, act):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, dtype_name, act)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=150) for _ in range(2)], key=lambda r: r[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:            # a rank that hangs must not take the rest of the suite with it
+            if p.is_alive():
+                p.kill()
 
     def rel(a, b):
         a = torch.as_tensor(a).double()
