@@ -13,6 +13,7 @@ struct TapTable {
   int32_t cls_tap_start[kMaxClasses + 1];   // first entry of each class in dh/dw/wtap
   int8_t cls_ph[kMaxClasses], cls_pw[kMaxClasses];    // output pixel of class-local (oh', ow') is (oh'*b + ph, ow'*b + pw)
   int16_t cls_oh[kMaxClasses], cls_ow[kMaxClasses];   // class extent
+  FastDiv cls_div_ow[kMaxClasses], cls_div_oh[kMaxClasses];   // division by the class extents (LDS-DMA kernel)
   int8_t dh[kMaxTaps], dw[kMaxTaps];        // input row / column of a tap: oh'*a + dh, ow'*a + dw
   uint8_t wtap[kMaxTaps];                   // index r*kw + s into the packed weight
 };
@@ -32,6 +33,7 @@ struct GatherParams {
   int32_t act;
   float slope;
   int32_t out_vec;     // 1: 16-byte (fp32) / 8-byte (bf16) stores of 4 channels are aligned
+  int32_t out_vec8;    // 1: 16-byte stores of 8 bf16 channels are aligned as well, and so are 16-byte loads of the bias
   int32_t out_f32;     // element type of `out`: 1 fp32, 0 bf16 (independent of the input's type)
   int32_t icp_log2;    // log2(ICp) in the thin-input mode (reduction over (tap, channel) jointly, 64 per step)
   int32_t ksplit;      // > 1: the reduction is split over ksplit workgroups that add into a zeroed fp32 output
@@ -75,6 +77,10 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
 // rewrites the tile bookkeeping in p when it accepts.
 bool plan_patch(GatherParams& p, const GatherLaunch& l);
 int launch_patch(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
+// Persistent wave-specialised LDS-DMA kernel for mid-size layers (conv_gather_ws.hip): full channel tiles of 64 / 128,
+// 128-pixel tiles, 16-byte aligned output rows, none / ReLU / LeakyReLU epilogues.
+bool plan_ws(const GatherParams& p, const GatherLaunch& l);
+int launch_ws(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // LDS-DMA fast path: bf16 input, vector-aligned channels, 64- or 128-channel tile, no reduction split.
 int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 

@@ -17,6 +17,8 @@
 // Small problems (few tiles, long reduction: 4x4 -> 1x1 "full window" layers) split the reduction over several
 // workgroups that add their partial tiles into a zeroed fp32 output.
 #include <stdio.h>
+
+#include <mutex>
 #include <stdlib.h>
 
 #include "conv_gather.h"
@@ -435,13 +437,13 @@ static int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int PL = X3 ? 2 : 1;
   constexpr int smem = 2 * PL * (TO + TP) * 128 + kMaxTaps * 4;
   auto kern = conv_gather_kernel<TIn, TO, TP, X3, MODE>;
-  static bool attr_set = false;
-  if (smem > 64 * 1024 && !attr_set) {
-    if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
-                  "hipFuncSetAttribute"))
-      return GC_HIP_ERROR;
-    attr_set = true;
-  }
+  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&]() {
+    if (smem > 64 * 1024)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  });
+  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
   if (p.ksplit > 1) {
     const size_t bytes = (size_t)p.N * p.OH * p.OW * p.OC * sizeof(float);
     if (zero_fill(p.out, bytes, stream) != GC_OK) return GC_HIP_ERROR;

@@ -15,6 +15,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "conv_gather.h"
 
 namespace gc {
@@ -28,6 +30,16 @@ struct DmaCfg {
 };
 
 __device__ __forceinline__ int dswz(int row) { return (row >> 1) & 7; }
+
+// Which output channel (relative to the tile) the weight row at LDS row `row` holds.  Rows are permuted inside groups of
+// 32 so that the accumulators of two neighbouring 16-row MFMA blocks give a lane 8 CONSECUTIVE channels: MFMA block f,
+// accumulator row 4g + e  <->  channel 32 (f >> 1) + 8 g + 4 (f & 1) + e.  A lane (g = lane >> 4) then stores its bf16
+// results of blocks (f, f + 1) with one 16-byte instruction.  The fragment reads keep their conflict-free row order;
+// only the loader's source address and the epilogue's channel index know about the permutation.
+__device__ __forceinline__ int oc_of_row(int row) {
+  const int f = (row >> 4) & 1, g = (row >> 2) & 3, e = row & 3;
+  return (row & ~31) + 8 * g + 4 * f + e;
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {   // s_waitcnt vmcnt(N) alone (expcnt / lgkmcnt fields at "no wait")
@@ -75,6 +87,7 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
     m0 = (pix_tile - p.tt.cls_tile_start[cls]) * TP;
   }
   const int OHc = p.tt.cls_oh[cls], OWc = p.tt.cls_ow[cls];
+  const FastDiv div_ow = p.tt.cls_div_ow[cls], div_oh = p.tt.cls_div_oh[cls];
   const int Mc = p.N * OHc * OWc;
   const int tap_begin = p.tt.cls_tap_start[cls], tap_end = p.tt.cls_tap_start[cls + 1];
 
@@ -94,9 +107,9 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
     const int row = (wave * AJ + j) * 8 + sub_row;
     const int m = m0 + row;
     const bool ok = m < Mc;
-    const int mm = ok ? m : 0;
-    const int ow = mm % OWc, tmp = mm / OWc;
-    const int oh = tmp % OHc, n = tmp / OHc;
+    const uint32_t mm = ok ? (uint32_t)m : 0u;
+    const uint32_t tmp = fd_div(mm, div_ow), n = fd_div(tmp, div_oh);
+    const int ow = (int)(mm - tmp * (uint32_t)OWc), oh = (int)(tmp - n * (uint32_t)OHc);
     a_ih[j] = ok ? oh * p.a : -(1 << 20);
     a_iw[j] = ow * p.a;
     a_chunk[j] = (pos ^ dswz(row)) * 8;        // source chunk (elements) that lands at LDS position `pos` of this row
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
 #pragma unroll
   for (int j = 0; j < WJ; j++) {
     const int row = (wave * WJ + j) * 8 + sub_row;
-    const int oc = oc0 + row;
+    const int oc = oc0 + oc_of_row(row);
     w_voff[j] = oc < p.OC ? (uint32_t)(((size_t)oc * p.row_pitch + (pos ^ dswz(row)) * 8) * 2) : kOutOfRange;
   }
 
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
     wait_vmcnt<(STAGES - 2) * LOADS>();
     __builtin_amdgcn_s_barrier();                 // every wave's part of step `it` has landed; step it-1's buffer is free
     __builtin_amdgcn_sched_barrier(0);
-    issue(st_i);                                  // goes into the buffer consumed at step it-1
+    issue(st_i);               // goes into the buffer consumed at step it-1
     st_i = next_stage(st_i);
     compute(st_c);
     st_c = next_stage(st_c);
@@ -250,51 +263,104 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
   (void)consumer;
 
   // ---- epilogue ----------------------------------------------------------------------------------------
-  const bool vec_ok = p.out_vec != 0;
+  // A wave alone on its SIMD issues one vector instruction every 4-5 cycles, so this part is written for instruction
+  // count: full tiles with aligned rows (the common case) take a branch-free path, two 16-row blocks per 16-byte store.
+  const int g = lane >> 4;
+  const bool stats = p.ch_sum != nullptr;
+  TOut* out = reinterpret_cast<TOut*>(p.out);
+  const int oc_w = oc0 + wo * (TO / C::WO);          // first channel of this wave's rows
+  const bool linear = p.tt.n_classes == 1 && p.b == 1;   // forward pass: output pixel index == GEMM column index
+  const bool fast = (C::FO % 2 == 0) && (m0 + TP <= Mc) && (oc0 + TO <= p.OC) && p.out_vec8 != 0 && p.act <= GC_ACT_LRELU;
   float ssum[C::FO][4], ssq[C::FO][4];
 #pragma unroll
   for (int i = 0; i < C::FO; i++)
 #pragma unroll
     for (int r = 0; r < 4; r++) ssum[i][r] = ssq[i][r] = 0.f;
-  const bool stats = p.ch_sum != nullptr;
-  TOut* out = reinterpret_cast<TOut*>(p.out);
-#pragma unroll
-  for (int j = 0; j < C::FP; j++) {
-    const int m = m0 + wp_ * (TP / C::WP) + j * 16 + (lane & 15);
-    const bool mok = m < Mc;
-    const int mm = mok ? m : 0;
-    const int ow = mm % OWc, tmp = mm / OWc;
-    const int oh = tmp % OHc, n = tmp / OHc;
-    const size_t pix = ((size_t)n * p.OH + (oh * p.b + p.tt.cls_ph[cls])) * p.OW + (ow * p.b + p.tt.cls_pw[cls]);
-    TOut* dst = out + pix * p.out_cstride + p.out_coff;
+  if (fast) {
+    // none / relu / leaky relu as one formula: v > 0 ? v : v * s with s = 1, 0, slope
+    const float sl = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);
+    f32x4 bias_v[C::FO];
 #pragma unroll
     for (int i = 0; i < C::FO; i++) {
-      const int oc = oc0 + wo * (TO / C::WO) + i * 16 + (lane >> 4) * 4;
-      float v[4];
+      const int oc = oc_w + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
+      bias_v[i] = p.bias != nullptr ? *reinterpret_cast<const f32x4*>(p.bias + oc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float x = acc[i][j][r];
-        if (p.bias != nullptr && oc + r < p.OC) x += p.bias[oc + r];
-        x = apply_act(x, p.act, p.slope);
-        if (sizeof(TOut) == 2) x = bf16_bits_to_float(float_to_bf16_bits(x));
-        v[r] = x;
-        if (stats && mok && oc + r < p.OC) { ssum[i][r] += x; ssq[i][r] += x * x; }
+    for (int j = 0; j < C::FP; j++) {
+      const uint32_t m = (uint32_t)(m0 + wp_ * (TP / C::WP) + j * 16 + (lane & 15));
+      size_t pix = m;
+      if (!linear) {
+        const uint32_t tmp = fd_div(m, div_ow), n = fd_div(tmp, div_oh);
+        const int ow = (int)(m - tmp * (uint32_t)OWc), oh = (int)(tmp - n * (uint32_t)OHc);
+        pix = ((size_t)n * p.OH + (oh * p.b + p.tt.cls_ph[cls])) * p.OW + (ow * p.b + p.tt.cls_pw[cls]);
       }
-      if (!mok) continue;
-      if (vec_ok && oc + 3 < p.OC) {
-        if (sizeof(TOut) == 4) {
-          *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
-          if (p.out_bf16 != nullptr)
-            *reinterpret_cast<u32x2*>(p.out_bf16 + pix * p.out_cstride + p.out_coff + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
-        }
-        else *reinterpret_cast<u32x2*>(dst + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
-      } else {
+      const size_t eoff = pix * p.out_cstride + p.out_coff + oc_w + g * 8;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (oc + r < p.OC) {
-            if (sizeof(TOut) == 4) reinterpret_cast<float*>(dst)[oc + r] = v[r];
-            else reinterpret_cast<uint16_t*>(dst)[oc + r] = float_to_bf16_bits(v[r]);
+      for (int i = 0; i < C::FO; i += 2) {
+        f32x4 a = acc[i][j] + bias_v[i], b = acc[i + 1][j] + bias_v[i + 1];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          a[r] = a[r] > 0.f ? a[r] : a[r] * sl;
+          b[r] = b[r] > 0.f ? b[r] : b[r] * sl;
+        }
+        const u32x2 pa = cvt_bf16x4(a), pb = cvt_bf16x4(b);
+        if (sizeof(TOut) == 2) {
+          *reinterpret_cast<u32x4*>(out + eoff + (i >> 1) * 32) = u32x4{pa[0], pa[1], pb[0], pb[1]};
+          if (stats) { a = widen_bf16x4(pa); b = widen_bf16x4(pb); }     // statistics of the stored values
+        } else {
+          *reinterpret_cast<f32x4*>(out + eoff + (i >> 1) * 32) = a;
+          *reinterpret_cast<f32x4*>(out + eoff + (i >> 1) * 32 + 4) = b;
+          if (p.out_bf16 != nullptr) *reinterpret_cast<u32x4*>(p.out_bf16 + eoff + (i >> 1) * 32) = u32x4{pa[0], pa[1], pb[0], pb[1]};
+        }
+        if (stats) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            ssum[i][r] += a[r]; ssq[i][r] += a[r] * a[r];
+            ssum[i + 1][r] += b[r]; ssq[i + 1][r] += b[r] * b[r];
           }
+        }
+      }
+    }
+  } else {
+    const bool vec_ok = p.out_vec != 0;
+#pragma unroll
+    for (int j = 0; j < C::FP; j++) {
+      const int m = m0 + wp_ * (TP / C::WP) + j * 16 + (lane & 15);
+      const bool mok = m < Mc;
+      const uint32_t mm = mok ? (uint32_t)m : 0u;
+      const uint32_t tmp = fd_div(mm, div_ow), n = fd_div(tmp, div_oh);
+      const int ow = (int)(mm - tmp * (uint32_t)OWc), oh = (int)(tmp - n * (uint32_t)OHc);
+      const size_t pix = ((size_t)n * p.OH + (oh * p.b + p.tt.cls_ph[cls])) * p.OW + (ow * p.b + p.tt.cls_pw[cls]);
+      TOut* dst = out + pix * p.out_cstride + p.out_coff;
+#pragma unroll
+      for (int i = 0; i < C::FO; i++) {
+        const int oc = oc0 + oc_of_row(wo * (TO / C::WO) + i * 16 + g * 4);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float x = acc[i][j][r];
+          if (p.bias != nullptr && oc + r < p.OC) x += p.bias[oc + r];
+          x = apply_act(x, p.act, p.slope);
+          if (sizeof(TOut) == 2) x = bf16_bits_to_float(float_to_bf16_bits(x));
+          v[r] = x;
+          if (stats && mok && oc + r < p.OC) { ssum[i][r] += x; ssq[i][r] += x * x; }
+        }
+        if (!mok) continue;
+        if (vec_ok && oc + 3 < p.OC) {
+          if (sizeof(TOut) == 4) {
+            *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
+            if (p.out_bf16 != nullptr)
+              *reinterpret_cast<u32x2*>(p.out_bf16 + pix * p.out_cstride + p.out_coff + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+          }
+          else *reinterpret_cast<u32x2*>(dst + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (oc + r < p.OC) {
+              if (sizeof(TOut) == 4) reinterpret_cast<float*>(dst)[oc + r] = v[r];
+              else reinterpret_cast<uint16_t*>(dst)[oc + r] = float_to_bf16_bits(v[r]);
+            }
+        }
       }
     }
   }
@@ -309,7 +375,7 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
           s += __shfl_xor(s, d, 64);
           q += __shfl_xor(q, d, 64);
         }
-        const int oc = oc0 + wo * (TO / C::WO) + i * 16 + (lane >> 4) * 4 + r;
+        const int oc = oc0 + oc_of_row(wo * (TO / C::WO) + i * 16 + g * 4) + r;
         if ((lane & 15) == 0 && oc < p.OC) {
           atomicAdd(p.ch_sum + oc, s);
           if (p.ch_sumsq != nullptr) atomicAdd(p.ch_sumsq + oc, q);
@@ -322,13 +388,13 @@ template <typename TOut, int TO, int TP, int STAGES, int NW, bool WS = false>
 static int launch_dma_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * (TO + TP) * 128 + kMaxTaps * 4;
   auto kern = conv_gather_dma_kernel<TOut, TO, TP, STAGES, NW, WS>;
-  static bool attr_set = false;
-  if (smem > 64 * 1024 && !attr_set) {
-    if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
-                  "hipFuncSetAttribute"))
-      return GC_HIP_ERROR;
-    attr_set = true;
-  }
+  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&]() {
+    if (smem > 64 * 1024)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  });
+  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
   const unsigned nblocks = (unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_gather_dma_kernel<%s, %d, %d, %d, %d%s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, TP, STAGES,

@@ -20,6 +20,8 @@
 // against 8 + 4 fragment reads.
 #include <stdio.h>
 
+#include <mutex>
+
 #include "conv_gather.h"
 
 namespace gc {
@@ -241,13 +243,12 @@ template <typename TOut, int TS>
 int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int kSmem = smem_bytes(TS);
   auto kern = conv_patch_kernel<TOut, TS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem),
-                  "hipFuncSetAttribute"))
-      return GC_HIP_ERROR;
-    attr_set = true;
-  }
+  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&]() {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+  });
+  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_patch_kernel<%s, %d>", sizeof(TOut) == 4 ? "float" : "unsigned short", TS);
   ProfScope ps(name, flops, stream);

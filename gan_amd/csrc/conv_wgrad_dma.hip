@@ -10,6 +10,8 @@
 // of one output channel and the partial tile is written with 16-byte stores.
 #include <stdio.h>
 
+#include <mutex>
+
 #include "conv_wgrad.h"
 
 namespace gc {
@@ -240,13 +242,13 @@ template <int TO, int STAGES>
 static int launch_dma_one(const WgradParams& p, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * kStepPix * (TO + kTC) * 2;
   auto kern = conv_wgrad_dma_kernel<TO, STAGES>;
-  static bool attr_set = false;
-  if (smem > 64 * 1024 && !attr_set) {
-    if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem),
-                  "hipFuncSetAttribute"))
-      return GC_HIP_ERROR;
-    attr_set = true;
-  }
+  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&]() {
+    if (smem > 64 * 1024)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  });
+  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_wgrad_dma_kernel<%d, %d>", TO, STAGES);
   ProfScope ps(name, flops, stream);

@@ -268,6 +268,12 @@ static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t 
   if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   l.big_tile_ok = true;
   plan_gather(p, l);
+  for (int c = 0; c < p.tt.n_classes; c++) {
+    p.tt.cls_div_ow[c] = make_fastdiv((uint32_t)p.tt.cls_ow[c]);
+    p.tt.cls_div_oh[c] = make_fastdiv((uint32_t)p.tt.cls_oh[c]);
+  }
+  p.out_vec8 = p.out_vec && (reinterpret_cast<uintptr_t>(p.out) % 16 == 0) && (p.out_cstride % 8 == 0) && (p.out_coff % 8 == 0) &&
+               (reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.out_bf16) % 16 == 0);
   // LDS-DMA path: buffer addressing with 32-bit offsets, so both tensors have to stay below 2 GiB
   p.in_bytes = (int64_t)p.N * p.IH * p.IW * p.in_cstride * 2;
   p.w_bytes = (int64_t)p.OC * p.row_pitch * 2;
@@ -281,6 +287,7 @@ static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t 
   const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 256 || l.to == 128 || l.to == 64) &&
                    p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
   if (dma && patch_kernel_allowed() && plan_patch(p, l)) return launch_patch(p, l, out_dt == GC_F32, stream);
+  if (dma && plan_ws(p, l)) return launch_ws(p, l, out_dt == GC_F32, stream);
   if (dma) return launch_gather_dma(p, l, out_dt == GC_F32, stream);
   return launch_gather(p, l, stream);
 }

@@ -36,7 +36,7 @@ class GraphedStep:
         ops.clear_weight_cache()
         ops.clear_cast_cache()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph), ops.capturing_on():
             self.out = step()
         ops.clear_cast_cache()
 

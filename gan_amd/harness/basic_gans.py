@@ -369,7 +369,7 @@ class WganGpTrainer:
         gops.clear_cast_cache()
         if self.red_D is None:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph), gops.capturing_on():
                 self.static_out = self.cycle_eager()
             return self.graph
         self.graphs, outs, pool = [], [], None
@@ -377,7 +377,7 @@ class WganGpTrainer:
         def record(fn):
             nonlocal pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool), gops.capturing_on():
                 out = fn()
             pool = pool or g.pool()
             return g, out

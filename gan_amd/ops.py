@@ -15,6 +15,7 @@ include/ganconv.h.  There is no fallback: on a CPU tensor, a missing library or 
 raise RuntimeError.
 """
 import ctypes
+import threading
 import weakref
 from typing import Optional
 
@@ -42,20 +43,23 @@ def get_precision():
 # ---- packed-weight cache -------------------------------------------------------------------------------------
 # A module that owns a Parameter registers a key; the cache entry remembers which storage/version it was packed
 # from and is refreshed when the parameter has been modified in place (optimizer step, weights_init, load).
-_wcache = {}
+# The caches below are shared by the thread that runs the forward pass and the autograd engine's worker threads
+# (backward formulas run there): every compound look-up / insert holds _lock.
+_lock = threading.RLock()
+_wcache = {}          # module key -> {(pass, precision, image bytes): _Image}
 _next_key = [1]
 
 
 def new_weight_key():
-    k = _next_key[0]
-    _next_key[0] += 1
-    return k
+    with _lock:
+        k = _next_key[0]
+        _next_key[0] += 1
+        return k
 
 
 def drop_weight_key(key):
-    for p in (_lib.GC_PASS_FPROP, _lib.GC_PASS_DGRAD):
-        for prec in (0, 1):
-            _wcache.pop((key, p, prec), None)
+    with _lock:
+        _wcache.pop(key, None)
 
 
 def _dtype_code(t):
@@ -79,7 +83,24 @@ def _stream():
 # never sees the side stream.  Works inside HIP-graph capture (the fork/join becomes two graph branches).
 _overlap = False
 _side_streams = {}
-_side_keep = []       # workspaces and operand copies in use on the side stream
+_capture_origin = [None]     # the stream a HIP-graph capture was started on (see capturing_on)
+
+
+class capturing_on:
+    """Context a graph recorder enters around its capture: names the stream the capture starts on.  A weight-gradient
+    side stream is forked only from that stream while a capture is running: a fork from a stream that is itself forked
+    inside the capture made hipStreamEndCapture abort (ROCm 7.2; tools/probe/nested_fork_capture.hip)."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+
+    def __enter__(self):
+        st = self.stream if self.stream is not None else torch.cuda.current_stream()
+        self.was, _capture_origin[0] = _capture_origin[0], st.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _capture_origin[0] = self.was
 
 
 def set_split_reduction(on):
@@ -119,11 +140,15 @@ class _SideLaunch:
 
     def __init__(self, device):
         self.main = torch.cuda.current_stream(device)
-        side = _side_streams.get(device)
-        if side is None:
-            side = _side_streams[device] = torch.cuda.Stream(device)
+        with _lock:
+            side = _side_streams.get(device)
+            if side is None:
+                side = _side_streams[device] = torch.cuda.Stream(device)
         self.side = side
         self.forked = False
+        self.keep = []        # workspaces and operand copies in use on the side stream, released at the join
+        # under a capture, fork only from the stream the capture started on
+        self.allowed = not (torch.cuda.is_current_stream_capturing() and _capture_origin[0] != self.main.cuda_stream)
 
     def __enter__(self):
         _SideLaunch.active = self
@@ -134,15 +159,17 @@ class _SideLaunch:
 
     def fork(self, *keep):
         """Called by the op right before its launches: everything enqueued so far (operand copies) is waited for."""
+        if not self.allowed:
+            return ctypes.c_void_p(self.main.cuda_stream)
         self.side.wait_stream(self.main)
         self.forked = True
-        _side_keep.extend(keep)
+        self.keep.extend(keep)
         return ctypes.c_void_p(self.side.cuda_stream)
 
     def join(self):
         if self.forked:
             self.main.wait_stream(self.side)
-            _side_keep.clear()
+        self.keep.clear()
 
 
 def _check_cuda(*ts):
@@ -176,25 +203,33 @@ _CAST_CACHE_MAX = 128
 
 
 def clear_cast_cache():
-    _cast_cache.clear()
+    with _lock:
+        _cast_cache.clear()
 
 
 def clear_weight_cache():
     """Forget every packed weight image.  Needed before recording a HIP graph: an image packed before the capture
     would be a cache hit inside it, the pack kernel would not be part of the graph, and every replay would read
     the weights as they were when the graph was recorded."""
-    _wcache.clear()
+    with _lock:
+        _wcache.clear()
+
+
+def _cast_insert(key, t, tb):
+    with _lock:
+        if len(_cast_cache) >= _CAST_CACHE_MAX:
+            _cast_cache.pop(next(iter(_cast_cache)), None)
+        _cast_cache[key] = (t, tb)
 
 
 def _to_bf16(t):
     key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
-    ent = _cast_cache.get(key)
+    with _lock:
+        ent = _cast_cache.get(key)
     if ent is not None:
         return ent[1]
     tb = t.to(torch.bfloat16, memory_format=torch.channels_last)
-    if len(_cast_cache) >= _CAST_CACHE_MAX:
-        _cast_cache.pop(next(iter(_cast_cache)))
-    _cast_cache[key] = (t, tb)
+    _cast_insert(key, t, tb)
     return tb
 
 
@@ -205,9 +240,7 @@ def _bf16_twin(t):
     if _default_precision != _lib.GC_PREC_BF16 or t.dtype != torch.float32 or C % 8 != 0 or C <= 32 or t.numel() * 2 >= (1 << 31) - (1 << 21):
         return None
     tb = torch.empty_like(t, dtype=torch.bfloat16, memory_format=torch.channels_last)
-    if len(_cast_cache) >= _CAST_CACHE_MAX:
-        _cast_cache.pop(next(iter(_cast_cache)))
-    _cast_cache[(t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))] = (t, tb)
+    _cast_insert((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())), t, tb)
     return tb
 
 
@@ -240,7 +273,7 @@ def _dma_ok(t, ic, oc, precision):
 
 class _Image:
     """A cached packed weight image and what it was made from / on."""
-    __slots__ = ("ptr", "version", "shape", "buf", "desc", "wref", "stream", "event")
+    __slots__ = ("ptr", "version", "shape", "buf", "desc", "wref", "stream", "event", "alpha")
 
     def mark_packed(self, w):
         """Called right after a pack launch on the current stream."""
@@ -259,60 +292,68 @@ class _Image:
         return self.buf
 
 
-def _packed(desc, w, pass_, wkey):
-    """bf16 image of w for `pass_`; cached per registered key and refreshed when the weight's version moved."""
+def _packed(desc, w, pass_, wkey, alpha=1.0):
+    """bf16 image of alpha * w for `pass_`; cached per registered key and refreshed when the weight's version moved.
+    The image layout depends on the layer geometry as well as on the weight (a window that covers its whole input packs
+    its data-gradient image differently), so an entry is also keyed by the image size the library reports for `desc`:
+    one module used at two input sizes keeps one image per layout."""
     L = _lib.lib()
-    ck = (wkey, pass_, int(desc.precision))
-    if wkey:
-        ent = _wcache.get(ck)
-        if ent is not None and ent.ptr == w.data_ptr() and ent.shape == tuple(w.shape):
-            if ent.version == w._version:
-                return ent.ready(w)
-            if w.dtype == torch.float32:
-                # same storage, new values: refresh the image in place (keeps repack() able to find it)
-                _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), 1.0,
-                                            ctypes.c_void_p(ent.buf.data_ptr()), _stream()), "gc_pack_weight")
-                ent.mark_packed(w)
-                return ent.buf
-    w32 = w if w.dtype == torch.float32 else w.float()
     nbytes = L.gc_packed_weight_bytes(ctypes.byref(desc), pass_)
     if nbytes == 0:
         _lib.check(-1, "gc_packed_weight_bytes")
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w32.data_ptr()), _lib.strides4(w32), 1.0,
-                                ctypes.c_void_p(buf.data_ptr()), _stream()), "gc_pack_weight")
-    if wkey:
-        ent = _Image()
-        ent.buf, ent.desc, ent.wref = buf, ConvDesc.from_buffer_copy(desc), weakref.ref(w)
-        ent.mark_packed(w)
-        _wcache[ck] = ent
-    return buf
+    ik = (pass_, int(desc.precision), int(nbytes))
+    alpha = float(alpha)
+    with _lock:
+        if wkey:
+            ent = _wcache.get(wkey, {}).get(ik)
+            if ent is not None and ent.ptr == w.data_ptr() and ent.shape == tuple(w.shape):
+                if ent.version == w._version and ent.alpha == alpha:
+                    return ent.ready(w)
+                if w.dtype == torch.float32:
+                    # same storage, new values: refresh the image in place (keeps repack() able to find it)
+                    _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), alpha,
+                                                ctypes.c_void_p(ent.buf.data_ptr()), _stream()), "gc_pack_weight")
+                    ent.alpha = alpha
+                    ent.mark_packed(w)
+                    return ent.buf
+        w32 = w if w.dtype == torch.float32 else w.float()
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w32.data_ptr()), _lib.strides4(w32), alpha,
+                                    ctypes.c_void_p(buf.data_ptr()), _stream()), "gc_pack_weight")
+        if wkey:
+            ent = _Image()
+            ent.buf, ent.desc, ent.wref, ent.alpha = buf, ConvDesc.from_buffer_copy(desc), weakref.ref(w), alpha
+            ent.mark_packed(w)
+            _wcache.setdefault(wkey, {})[ik] = ent
+        return buf
 
 
 def repack(wkeys):
     """Refreshes, in ONE launch, every cached weight image of the given module keys whose parameter has changed since
     it was packed (call right after an optimizer step: the convolutions that follow then find current images instead
     of re-packing one weight at a time).  Images are rewritten in place."""
-    jobs = []
-    for ck, ent in _wcache.items():
-        if ck[0] not in wkeys:
-            continue
-        w = ent.wref()
-        if w is None or w.dtype != torch.float32 or w.data_ptr() != ent.ptr or tuple(w.shape) != ent.shape or w._version == ent.version:
-            continue
-        jobs.append((ck, ent, w))
-    if not jobs:
-        return 0
-    n = len(jobs)
-    descs = (ConvDesc * n)(*[e.desc for _, e, _ in jobs])
-    passes = (ctypes.c_int32 * n)(*[ck[1] for ck, _, _ in jobs])
-    ws = (ctypes.c_void_p * n)(*[w.data_ptr() for _, _, w in jobs])
-    strides = (ctypes.c_int64 * (4 * n))(*[s_ for _, _, w in jobs for s_ in w.stride()])
-    packed = (ctypes.c_void_p * n)(*[e.buf.data_ptr() for _, e, _ in jobs])
-    _lib.check(_lib.lib().gc_pack_weights(n, descs, passes, ws, strides, None, packed, _stream()), "gc_pack_weights")
-    for _, e, w in jobs:
-        e.mark_packed(w)
-    return n
+    with _lock:
+        jobs = []
+        for key in wkeys:
+            for ik, ent in _wcache.get(key, {}).items():
+                w = ent.wref()
+                if (w is None or w.dtype != torch.float32 or w.data_ptr() != ent.ptr or tuple(w.shape) != ent.shape
+                        or w._version == ent.version):
+                    continue
+                jobs.append((ik, ent, w))
+        if not jobs:
+            return 0
+        n = len(jobs)
+        descs = (ConvDesc * n)(*[e.desc for _, e, _ in jobs])
+        passes = (ctypes.c_int32 * n)(*[ik[0] for ik, _, _ in jobs])
+        ws = (ctypes.c_void_p * n)(*[w.data_ptr() for _, _, w in jobs])
+        strides = (ctypes.c_int64 * (4 * n))(*[s_ for _, _, w in jobs for s_ in w.stride()])
+        alphas = (ctypes.c_float * n)(*[e.alpha for _, e, _ in jobs])
+        packed = (ctypes.c_void_p * n)(*[e.buf.data_ptr() for _, e, _ in jobs])
+        _lib.check(_lib.lib().gc_pack_weights(n, descs, passes, ws, strides, alphas, packed, _stream()), "gc_pack_weights")
+        for _, e, w in jobs:
+            e.mark_packed(w)
+        return n
 
 
 def _epilogue(bias, act=0, slope=0.0, out=None):

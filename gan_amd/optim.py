@@ -1,10 +1,14 @@
-"""torch.optim.Adam as one fused launch (plus a one-thread counter tick) per step.
+"""torch.optim.Adam as one fused launch (plus a one-wavefront counter tick) per step.
 
 Drop-in for the reference's `torch.optim.Adam(net.parameters(), lr=..., betas=...)` (BasicGANs/train.py:79-80,
 Pix2Pix/train.py, StyleGAN/train.py, BigGAN/train.py): same constructor arguments for the features the reference uses
-(lr, betas, eps; weight_decay / amsgrad / maximize must stay at their defaults), same arithmetic in the same order.
-The step counter lives on the device, so step() can be recorded into a HIP graph.  State per parameter: `exp_avg`,
-`exp_avg_sq`; per group: `step` (a device float tensor shared by the group's parameters).
+(lr, betas, eps; weight_decay / amsgrad / maximize must stay at their defaults), same arithmetic in the same order,
+same state layout as torch.optim.Adam(capturable=True): per parameter `step` (a float32 scalar on the parameter's
+device), `exp_avg`, `exp_avg_sq`.  A parameter that gets its first gradient late (the higher-resolution blocks of a
+progressively grown StyleGAN) starts its bias correction at step 1, as in torch.  The step counts live on the device,
+so step() can be recorded into a HIP graph.  state_dict() / load_state_dict() interchange with torch.optim.Adam
+(StyleGAN/train.py:150-151 restores both optimizers from a checkpoint): a loaded `step` may be a Python number, a CPU
+tensor (torch's default) or a device tensor.
 
 `Adam.average_into(averaged_net, net, weight)` folds the reference's `moving_average(averaged_G, net_G, weight)`
 (StyleGAN/train.py:71-76, called after every generator step) into the step's launch; `moving_average` below is the
@@ -22,7 +26,8 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("gan_amd.optim.Adam supports weight_decay=0, amsgrad=False, maximize=False only")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError("invalid Adam hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # capturable=True: torch's state_dict machinery then keeps `step` as a float32 tensor on the parameter's device
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, capturable=True))
         self._tables = {}
         self._nets = []
         self._ema = {}          # id(parameter) -> its moving average (a tensor of another module)
@@ -53,22 +58,55 @@ class Adam(torch.optim.Optimizer):
         self._nets = list(nets)
         return self
 
+    def _init_state(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        step = st.get("step")
+        if not (torch.is_tensor(step) and step.device == p.device and step.dtype == torch.float32 and step.numel() == 1):
+            # absent, a Python number, or a tensor somewhere else (a checkpoint of torch.optim.Adam read to the CPU)
+            value = 0.0 if step is None else float(step)
+            st["step"] = torch.full((), value, dtype=torch.float32, device=p.device)
+        return st
+
     def _table(self, gi, params):
         """Host arrays of device pointers for the parameters that have a gradient; rebuilt when anything moved."""
         ema = [self._ema.get(id(p)) for p in params]
-        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), 0 if e is None else e.data_ptr()) for p, e in zip(params, ema))
+        st = [self.state[p] for p in params]
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), s["step"].data_ptr(),
+                     0 if e is None else e.data_ptr()) for p, s, e in zip(params, st, ema))
         ent = self._tables.get(gi)
         if ent is not None and ent[0] == sig:
             return ent[1]
         n = len(params)
         vp, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
-        st = [self.state[p] for p in params]
         arrays = (n, vp(*[p.data_ptr() for p in params]), vp(*[p.grad.data_ptr() for p in params]),
                   vp(*[s["exp_avg"].data_ptr() for s in st]), vp(*[s["exp_avg_sq"].data_ptr() for s in st]),
-                  i64(*[p.numel() for p in params]),
+                  i64(*[p.numel() for p in params]), vp(*[s["step"].data_ptr() for s in st]),
                   vp(*[None if e is None else e.data_ptr() for e in ema]) if any(e is not None for e in ema) else None)
         self._tables[gi] = (sig, arrays)
         return arrays
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict, then the state put where the kernel needs it: moments on the parameter's
+        device in float32, one float32 device scalar `step` per parameter (whatever form the checkpoint held it in), and
+        the cached pointer tables dropped (the load replaces every state tensor)."""
+        super().load_state_dict(state_dict)
+        self._tables.clear()
+        for group in self.param_groups:
+            group["capturable"] = True
+            legacy = group.pop("step", None)          # one counter per group: the form an earlier version of this class wrote
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                if "step" not in st and legacy is not None:
+                    st["step"] = float(legacy)
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st and (st[k].device != p.device or st[k].dtype != torch.float32 or not st[k].is_contiguous()):
+                        st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+                self._init_state(p)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -85,22 +123,16 @@ class Adam(torch.optim.Optimizer):
                     raise RuntimeError("gan_amd.optim.Adam: parameters and gradients must be dense float32 tensors on the GPU")
                 if not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("gan_amd.optim.Adam: parameters and gradients must be contiguous")
-                st = self.state[p]
-                if not st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            if "step" not in group:
-                group["step"] = torch.zeros((), dtype=torch.float32, device=params[0].device)
-            n, pp, gp, mp, vp, ne, ep = self._table(gi, params)
+                self._init_state(p)
+            n, pp, gp, mp, vp, ne, sp, ep = self._table(gi, params)
             b1, b2 = group["betas"]
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             if ep is None:
-                _lib.check(_lib.lib().gc_adam_step(n, pp, gp, mp, vp, ne, ctypes.c_void_p(group["step"].data_ptr()), float(group["lr"]),
-                                                   float(b1), float(b2), float(group["eps"]), stream), "gc_adam_step")
+                _lib.check(_lib.lib().gc_adam_step(n, pp, gp, mp, vp, ne, sp, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                   stream), "gc_adam_step")
             else:
-                _lib.check(_lib.lib().gc_adam_ema_step(n, pp, gp, mp, vp, ep, self._ema_weight, ne, ctypes.c_void_p(group["step"].data_ptr()),
-                                                       float(group["lr"]), float(b1), float(b2), float(group["eps"]), stream),
-                           "gc_adam_ema_step")
+                _lib.check(_lib.lib().gc_adam_ema_step(n, pp, gp, mp, vp, ep, self._ema_weight, ne, sp, float(group["lr"]), float(b1),
+                                                       float(b2), float(group["eps"]), stream), "gc_adam_ema_step")
                 for p in params:
                     e = self._ema.get(id(p))
                     if e is not None:

@@ -232,10 +232,11 @@ int gc_batchnorm_update_running(float* running_mean, float* running_var, int64_t
 /* One torch.optim.Adam step (amsgrad = false, weight_decay = 0) for n fp32 tensors in two launches.  Replaces the
  * per-tensor / foreach kernels behind optimizer_D.step() / optimizer_G.step() of the reference's training loops (the
  * optimizers are built at BasicGANs/train.py:79-80).  The arrays are host arrays of device
- * pointers; *step (device float, the number of steps taken so far) is incremented first, so the call can be part of
- * a HIP graph.  Same operation order as torch's single-tensor Adam. */
+ * pointers; steps[i] points to tensor i's own step count (one device float, the number of steps that tensor has taken
+ * so far, as torch.optim.Adam keeps it per parameter); it is incremented first, so the call can be part of a HIP
+ * graph.  Same operation order as torch's single-tensor Adam. */
 int gc_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                 const int64_t* numel, float* step, float lr, float beta1, float beta2, float eps, void* stream);
+                 const int64_t* numel, float* const* steps, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* The same step that also keeps the exponential moving average of the parameters in the same launch:
  *   ema[i] = ema_weight * ema[i] + (1 - ema_weight) * params[i]   (with the updated params)
@@ -243,8 +244,8 @@ int gc_adam_step(int32_t n, float* const* params, const float* const* grads, flo
  * after each generator step), which reads and writes both parameter sets once more.  ema: host array of device
  * pointers, entries may be null (no average kept for that tensor); ema_weight in [0, 1]. */
 int gc_adam_ema_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                     float* const* ema, float ema_weight, const int64_t* numel, float* step, float lr, float beta1, float beta2,
-                     float eps, void* stream);
+                     float* const* ema, float ema_weight, const int64_t* numel, float* const* steps, float lr, float beta1,
+                     float beta2, float eps, void* stream);
 
 /* StyleGAN's chain behind every synthesis convolution as one kernel per direction (StyleGAN/model.py:179-208,249-261:
  * NoiseInput, LeakyReLU(0.2), InstanceNorm2d, style affine):

@@ -1079,7 +1079,7 @@ def test_fused_adam_matches_torch_adam(gan, betas):
     for step in range(6):
         for i, (a, b) in enumerate(zip(pa, pb)):
             if i == 2 and step < 2:
-                a.grad = b.grad = None            # joins later: its own moments start then, the group's counter is shared
+                a.grad = b.grad = None            # joins later: its moments AND its step count start then, as in torch
                 continue
             g = torch.randn_like(a) * (10.0 ** (step - 3))
             a.grad, b.grad = g.clone(), g.clone()
@@ -1087,11 +1087,59 @@ def test_fused_adam_matches_torch_adam(gan, betas):
         oa.step(); ob.step()
         assert pa[0]._version > va          # in-place update is visible to version-keyed caches
     for i, (a, b) in enumerate(zip(pa, pb)):
-        if i == 2:
-            continue      # torch counts steps per parameter, the fused optimizer per group: they differ for a late joiner
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), i
+    assert float(oa.state[pa[2]]["step"]) == 4.0 and float(oa.state[pa[0]]["step"]) == 6.0      # one count per parameter
     with pytest.raises(ValueError):
         gan.optim.Adam(pa, weight_decay=0.1)
+
+
+@pytest.mark.parametrize("source", ["fused", "torch_cpu_checkpoint"])
+def test_fused_adam_state_dict_round_trip(gan, source, tmp_path):
+    """step, save, load (checkpoint read with map_location='cpu', as StyleGAN/train.py:145-151 does), step again: the
+    fused optimizer continues exactly like torch.optim.Adam, from its own checkpoint and from one torch.optim.Adam wrote
+    (whose `step` entries are CPU tensors); the loaded moments are the ones that get used."""
+    torch.manual_seed(11)
+    shapes = [(32, 3, 4, 4), (77,), (9, 5)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    betas = (0.0, 0.99)
+    oa = gan.optim.Adam(pa, lr=1e-3, betas=betas)
+    ob = torch.optim.Adam(pb, lr=1e-3, betas=betas)
+
+    def steps(opts, n, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        for _ in range(n):
+            for a, b in zip(pa, pb):
+                gr = torch.randn(a.shape, device="cuda", generator=g)
+                a.grad, b.grad = gr.clone(), gr.clone()
+            for o in opts:
+                o.step()
+
+    steps([oa, ob], 3, 1)
+    path = str(tmp_path / "opt.pt")
+    torch.save((oa if source == "fused" else ob).state_dict(), path)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    oa2 = gan.optim.Adam(pa, lr=1e-3, betas=betas)
+    oa2.load_state_dict(sd)
+    for p in pa:
+        st = oa2.state[p]
+        assert st["step"].is_cuda and st["step"].dtype == torch.float32 and float(st["step"]) == 3.0
+        assert st["exp_avg"].is_cuda and st["exp_avg_sq"].is_cuda
+    # a load AFTER a step must not leave the kernel writing through the old moment buffers
+    oa.load_state_dict(sd)
+    steps([oa2, ob], 2, 2)
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    for a, b in zip(pa, pb):
+        assert torch.allclose(oa2.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    # oa was re-loaded after stepping: its next step uses the loaded moments (it lags oa2 by the two steps above)
+    before = [oa.state[p]["exp_avg_sq"].clone() for p in pa]
+    for a in pa:
+        a.grad = torch.ones_like(a)
+    oa.step()
+    for p, b0 in zip(pa, before):
+        assert float(oa.state[p]["step"]) == 4.0
+        assert torch.allclose(oa.state[p]["exp_avg_sq"], b0 * betas[1] + (1 - betas[1]), rtol=1e-6)
 
 
 def test_fused_adam_keeps_the_moving_average(gan):
