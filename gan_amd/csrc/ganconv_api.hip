@@ -590,6 +590,47 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   return GC_OK;
 }
 
+// ---- the entry point that allocates nothing -----------------------------------------------------------------------
+// The scratch array lives in the code object: every GPU the library runs on holds its own copy at its own address.  In
+// host code the array's NAME is only a handle for hipGetSymbolAddress; the address that kernels, memsets and copies may
+// use is the one that call returns, looked up once per device with that device current.
+static __device__ __align__(256) unsigned char scratch[GC_NOALLOC_SCRATCH_BYTES];
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[kMaxDevices];
+
+static int scratch_of_current_device(void** out) {
+  int dev = -1;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return GC_HIP_ERROR;
+  if (dev < 0 || dev >= kMaxDevices) { set_error("device index %d out of range", dev); return GC_BAD_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* ptr = nullptr;
+    if (check_hip(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)")) return GC_HIP_ERROR;
+    if (ptr == nullptr) { set_error("hipGetSymbolAddress returned a null scratch address"); return GC_HIP_ERROR; }
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return GC_OK;
+}
+
+int gc_conv2d_wgrad_noalloc(const gc_conv_desc* d, const void* x, const void* gy, float* gw, const int64_t gw_strides[4], float alpha,
+                            int accumulate, float* gbias, void* stream) {
+  int rc = validate(d);
+  if (rc != GC_OK) return rc;
+  const size_t need = gc_wgrad_workspace_bytes(d);
+  if (need > (size_t)GC_NOALLOC_SCRATCH_BYTES) {
+    set_error("gc_conv2d_wgrad_noalloc: the partial sums of this problem need %zu bytes, the built-in scratch holds %u; use "
+              "gc_conv2d_wgrad with a workspace", need, (unsigned)GC_NOALLOC_SCRATCH_BYTES);
+    return GC_WORKSPACE_TOO_SMALL;
+  }
+  void* ptr = nullptr;
+  if ((rc = scratch_of_current_device(&ptr)) != GC_OK) return rc;
+  // (nothing in the scratch has to start at zero: every partial slab that the reduction reads is written in full by
+  // the weight-gradient kernel of the same call)
+  return gc_conv2d_wgrad(d, x, gy, gw, gw_strides, alpha, accumulate, gbias, ptr, (size_t)GC_NOALLOC_SCRATCH_BYTES, stream);
+}
+
 int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || C <= 0) { set_error("gc_dwblur3x3: bad shape"); return GC_BAD_ARGUMENT; }
   if (dtype != GC_F32 && dtype != GC_BF16) { set_error("gc_dwblur3x3: unknown dtype"); return GC_BAD_ARGUMENT; }

@@ -133,6 +133,18 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* desc);
 int gc_conv2d_wgrad(const gc_conv_desc* desc, const void* x, const void* gy, float* gw, const int64_t gw_strides[4],
                     float alpha, int accumulate, float* gbias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* gc_conv2d_wgrad for callers that cannot allocate: code under HIP-graph capture, tight serving / training loops and
+ * harnesses that forbid hipMalloc (and so cannot provide a workspace of a size known only at call time).  No counterpart
+ * in the reference.  Same arguments and results as gc_conv2d_wgrad without the workspace pair: the split-K partial sums
+ * go to a scratch array that is part of the library's device image (GC_NOALLOC_SCRATCH_BYTES per GPU, held until the
+ * process ends), so the call allocates nothing on the host or the device.  A problem whose partial sums need more than
+ * that (gc_wgrad_workspace_bytes(desc) > GC_NOALLOC_SCRATCH_BYTES) is rejected with GC_WORKSPACE_TOO_SMALL.  All calls on
+ * one GPU share that GPU's array: calls that overlap in time on one GPU (two streams) race; calls on one stream, or on
+ * different GPUs, are fine.  The device of the call is the calling thread's current device, which must be the stream's. */
+#define GC_NOALLOC_SCRATCH_BYTES (32u << 20)
+int gc_conv2d_wgrad_noalloc(const gc_conv_desc* desc, const void* x, const void* gy, float* gw, const int64_t gw_strides[4],
+                            float alpha, int accumulate, float* gbias, void* stream);
+
 /* Depthwise 3x3 binomial blur ([1 2 1] x [1 2 1]) / 16, zero padding 1, NHWC, dtype gc_dtype.  The kernel is
  * symmetric, so the same call serves forward and backward (StyleGAN/model.py:82-150: BlurFunction,
  * BlurFunctionBackward; F.conv2d(x, kernel, padding=1, groups=C)). */

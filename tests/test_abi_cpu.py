@@ -54,6 +54,12 @@ def test_sizes_and_descriptor_validation():
     assert L.gc_conv2d_wgrad(ctypes.byref(_desc()), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
                              (ctypes.c_int64 * 4)(1, 1, 1, 1), 1.0, 0, None, None, 0, None) == -3  # workspace too small
     assert L.gc_dwblur3x3(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 4, 4, 6, _lib.GC_F32, None) == -2
+    # the entry point with the built-in scratch rejects problems whose partial sums exceed it, before touching a GPU
+    big = _desc(N=64, H=64, W=64, Cin=1024, Ho=32, Wo=32, Cout=1024)
+    assert L.gc_wgrad_workspace_bytes(ctypes.byref(big)) > (32 << 20)
+    assert L.gc_conv2d_wgrad_noalloc(ctypes.byref(big), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                     (ctypes.c_int64 * 4)(1, 1, 1, 1), 1.0, 0, None, None) == -3
+    assert b"built-in scratch" in L.gc_last_error()
 
 
 def test_argument_validation_of_the_layer_kernels():
