@@ -27,8 +27,6 @@ def _single(v, name):
 def _check_input(x, w):
     if x.dim() != 4 or w.dim() != 4:
         raise RuntimeError(f"ganconv: expected 4-D input and weight, got {tuple(x.shape)} and {tuple(w.shape)}")
-    if w.shape[2] != w.shape[3] and False:
-        raise RuntimeError("unreachable")
 
 
 _ACT_CODES = {None: 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
@@ -51,10 +49,12 @@ def _out_code(out_dtype):
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, *, _wkey=0, precision=None, activation=None,
-           negative_slope=0.2, out_dtype=None):
+           negative_slope=0.2, out_dtype=None, weight_scale=1.0):
     """`activation` (None, "relu", "leaky_relu", "tanh", "sigmoid") is applied in the kernel's epilogue: the result
     equals activation(conv2d(...)) of the unfused pair.  `out_dtype` (None = the input's, torch.float32 or
-    torch.bfloat16) is the storage type of the result; accumulation is always fp32."""
+    torch.bfloat16) is the storage type of the result; accumulation is always fp32.  `weight_scale`: a Python scalar c;
+    the result is conv2d(input, c * weight, ...) with c folded into the kernel's weight image instead of a separate
+    multiplication of the weight on every call."""
     _check_input(input, weight)
     if _single(dilation, "dilation") != 1:
         raise RuntimeError("ganconv: dilation > 1 is not supported")
@@ -62,13 +62,13 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
         raise RuntimeError("ganconv: groups > 1 is not supported by conv2d (the StyleGAN depthwise blur is ops.blur3x3)")
     prec = ops.get_precision() if precision is None else precision
     return ops.conv_fprop(input, weight, bias, _single(stride, "stride"), _single(padding, "padding"), prec, _wkey,
-                          _act_code(activation), float(negative_slope), _out_code(out_dtype))
+                          _act_code(activation), float(negative_slope), _out_code(out_dtype), float(weight_scale))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, *, _wkey=0,
-                     precision=None, activation=None, negative_slope=0.2, out_dtype=None):
+                     precision=None, activation=None, negative_slope=0.2, out_dtype=None, weight_scale=1.0):
     """weight is [Cin, Cout, kh, kw] as in torch.  Runs as the data-gradient of the mirrored convolution.
-    `activation`: as for conv2d."""
+    `activation`, `weight_scale`: as for conv2d."""
     _check_input(input, weight)
     if _single(dilation, "dilation") != 1 or groups != 1:
         raise RuntimeError("ganconv: dilation > 1 / groups > 1 are not supported")
@@ -82,7 +82,7 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     W = (input.shape[3] - 1) * s - 2 * p + kw + op
     prec = ops.get_precision() if precision is None else precision
     return ops.conv_dgrad(input, weight, bias, H, W, s, p, prec, _wkey, _act_code(activation), float(negative_slope),
-                          _out_code(out_dtype))
+                          _out_code(out_dtype), float(weight_scale))
 
 
 def blur3x3(input):

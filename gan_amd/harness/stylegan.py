@@ -1,26 +1,31 @@
-"""StyleGAN-v1 (progressive growing, AdaIN) generator and discriminator of the reference on the gan_amd modules.
+"""StyleGAN-v1 (progressive growing, AdaIN) on the gan_amd kernels: the generator and discriminator that
+StyleGAN/model.py builds, assembled here from two layer tables.
 
-Graphs, construction order (so that a seeded initialisation reproduces the reference's weights) and parameter
-names follow StyleGAN/model.py: EqualizedLR :13-50, EqualizedLinearLayer :53-62, EqualizedConv2d :65-79, BlurLayer
-:132-150, NoiseInput :179-185, AdaptiveInstanceNormalization :188-208, SynthesisNetworkBlock :211-268,
-MappingNetwork :271-293, SynthesisNetwork :296-355, StyleBasedGenerator :358-376, FusedUpsample :380-406,
-DownsampleBlock :409-450, Discriminator :453-514.  The training phases follow StyleGAN/train.py:211-248 with the
-Wasserstein-GP loss of BasicGANs/loss_functions.py:4-38.
+What is kept from the reference, because checkpoints and seeded runs depend on it:
+  * state_dict keys and tensor shapes (`...convolution_2.conv2d.weight_orig`, `...noise_injection_1.scaling_factor_orig`,
+    `...adaIN_1.affine_transformation_layer.linear_layer.bias`, `to_RGB_layers.3.conv2d.bias`, the blur buffers, ...), so
+    a checkpoint of StyleGAN/train.py:79-93 loads unchanged;
+  * the order in which layers are created and therefore the order of the random draws of a seeded initialisation
+    (mapping MLP, then per synthesis block: first convolution, second convolution, the two style layers; then the
+    to-image convolutions; the discriminator likewise);
+  * the arithmetic, including two quirks: both noise injections of a block use the same noise image
+    (StyleGAN/model.py:251-257), and with `use_activations` the discriminator's fade-in blends the block output with its
+    own LeakyReLU instead of the down-scaled image (StyleGAN/model.py:492-498).
 
-What runs where: every Conv2d goes through gan_amd.nn.Conv2d (the EqualizedLR pre-hook's scaled, non-leaf weight is
-read at call time), FusedUpsample through gan_amd.functional.conv_transpose2d, the depthwise blur through
-gan_amd.functional.blur3x3 (self-adjoint, so it needs no custom backward Function), the InstanceNorm inside AdaIN
-through the fused instance-norm kernel; the LeakyReLU that follows a discriminator convolution runs in that
-convolution's epilogue (same arithmetic as the separate module); the generator's noise injection -> LeakyReLU ->
-InstanceNorm -> style chain is one kernel per direction (gan_amd.ops.noise_lrelu_adain).  The mapping MLP, the style
-affine layers, minibatch standard deviation and the fade-in blends stay on stock torch ops.
+What is different:
+  * the equalized-learning-rate constant sqrt(2 / fan_in) (StyleGAN/model.py:33-37) is not multiplied into a copy of
+    the weight by a forward pre-hook on every call; convolutions take the stored parameter `weight_orig` plus the
+    constant, which the library folds into its cached weight image (`weight_scale`), and the gradient kernels scale by
+    the same constant;
+  * the noise -> LeakyReLU -> InstanceNorm -> style chain behind every synthesis convolution is one kernel per direction
+    (ops.noise_lrelu_adain); the LeakyReLU behind a discriminator convolution runs in that convolution's epilogue;
+    the depthwise blur is the stencil kernel (self-adjoint, so no custom backward);
+  * randomness drawn inside the reference's forward (noise images, style-mixing crossover) can be passed in, so that a
+    step is repeatable.
 
-set_activation_dtype(torch.bfloat16) makes every convolution store bf16 outputs (fp32 accumulation; images, styles,
-the minibatch statistic, the final projection and the losses stay fp32); the default keeps fp32 storage.
-
-Randomness the reference draws inside forward (per-block noise images, style-mixing crossover) can be passed in so
-that a step is repeatable across devices.  Reference quirks kept: the same noise image is used for both injections
-of a block; the discriminator's fade-in with use_activations applies the activation to `output` instead of `x`.
+set_activation_dtype(torch.bfloat16) stores the activations between the convolutions in bf16 (fp32 accumulation;
+images, styles, the minibatch statistic, the final projection and the losses stay fp32).
+Training phases: StyleGAN/train.py:211-248 with the loss of BasicGANs/loss_functions.py:4-38.
 """
 import math
 import random
@@ -31,384 +36,382 @@ from .. import functional as GF
 from .. import nn as gnn
 from .. import ops
 
-_act_dtype = None          # None: every layer follows its input (fp32 storage)
+LRELU = 0.2
+
+# (input channels, output channels, how the block gets its input): StyleGAN/model.py:304-314
+#   "const": learned 4x4 constant; "nearest": nearest x2 -> 3x3 conv -> blur; "transposed": the 3x3 weight averaged into a
+#   4x4 stride-2 transposed conv -> blur when the network is built with fused=True, else as "nearest"
+SYNTHESIS_PLAN = ((512, 512, "const"), (512, 512, "nearest"), (512, 512, "nearest"), (512, 512, "nearest"), (512, 256, "nearest"),
+                  (256, 128, "transposed"), (128, 64, "transposed"), (64, 32, "transposed"), (32, 16, "transposed"))
+# (input channels, output channels, may use the 4x4 stride-2 convolution when fused=True): StyleGAN/model.py:456-466; the last
+# block (after the minibatch statistic: 513 channels, 3x3 then 4x4 without padding) is appended by the builder
+CRITIC_PLAN = ((16, 32, True), (32, 64, True), (64, 128, True), (128, 256, True), (256, 512, False), (512, 512, False),
+               (512, 512, False), (512, 512, False))
+
+_store = {"dtype": None, "fused_chain": True}
 
 
 def set_activation_dtype(dtype):
-    global _act_dtype
-    _act_dtype = None if dtype in (None, torch.float32) else dtype
-
-
-def _like(t, ref):
-    return t if t.dtype == ref.dtype else t.to(ref.dtype)
-
-
-_fused_chain = True
+    _store["dtype"] = None if dtype in (None, torch.float32) else dtype
 
 
 def set_fused_chain(on):
-    """The generator's noise -> LeakyReLU -> InstanceNorm -> style chain on the fused kernel (default) or as modules."""
-    global _fused_chain
-    _fused_chain = bool(on)
+    """Noise -> LeakyReLU -> InstanceNorm -> style as one kernel (default) or as separate torch / library ops."""
+    _store["fused_chain"] = bool(on)
 
 
-class EqualizedLR:
-    def __init__(self, name):
-        self.name = name
-
-    def compute_weight(self, module):
-        weight = getattr(module, self.name + "_orig")
-        fan_in = weight.data.shape[1] * weight.data[0][0].numel()
-        return weight * math.sqrt(2 / fan_in)
-
-    @staticmethod
-    def apply(module, name):
-        fn = EqualizedLR(name)
-        weight = getattr(module, name)
-        del module._parameters[name]
-        module.register_parameter(name + "_orig", torch.nn.Parameter(weight.data))
-        module.register_forward_pre_hook(fn)
-
-    def __call__(self, module, input):
-        setattr(module, self.name, self.compute_weight(module))
+def _he_constant(weight):
+    """sqrt(2 / fan_in) with the reference's fan_in: every dimension of the weight but the first."""
+    return math.sqrt(2.0 / (weight[0].numel()))
 
 
-def equalized_lr(module, name="weight"):
-    EqualizedLR.apply(module, name)
-    return module
+# ---- parameters stored under `<name>_orig` ---------------------------------------------------------------------------
+class _EqConvCore(gnn.Conv2d):
+    """Conv2d whose stored parameter is `weight_orig` ~ N(0, 1); the effective weight is weight_orig * sqrt(2 / fan_in)."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0):
+        super().__init__(cin, cout, kernel_size, stride=stride, padding=padding)      # (draws torch's default init first)
+        w = self.weight.data.normal_(0.0, 1.0)
+        self.bias.data.zero_()
+        del self._parameters["weight"]
+        self.register_parameter("weight_orig", torch.nn.Parameter(w))
+        self.scale = _he_constant(w)
+
+    def effective_weight(self):          # what the reference's forward pre-hook would store in `.weight`
+        return self.weight_orig * self.scale
+
+    def forward(self, x, out_dtype=None):
+        return GF.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, _wkey=self._wkey_for(self.weight_orig),
+                         activation=self.activation, negative_slope=self.negative_slope, out_dtype=out_dtype, weight_scale=self.scale)
+
+
+class EqualizedConv2d(torch.nn.Module):
+    """Holder that gives the convolution the reference's key prefix (`conv2d.`)."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, lrelu=False, keep_fp32=False):
+        super().__init__()
+        self.conv2d = _EqConvCore(cin, cout, kernel_size, stride, padding)
+        if lrelu:
+            self.conv2d.activation, self.conv2d.negative_slope = "leaky_relu", LRELU
+        self.keep_fp32 = keep_fp32
+
+    def forward(self, x, out_dtype=None):
+        return self.conv2d(x, torch.float32 if self.keep_fp32 else (out_dtype or _store["dtype"]))
+
+
+class _EqLinearCore(torch.nn.Linear):
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout)
+        w = self.weight.data.normal_(0.0, 1.0)
+        self.bias.data.zero_()
+        del self._parameters["weight"]
+        self.register_parameter("weight_orig", torch.nn.Parameter(w))
+        self.scale = _he_constant(w)
+
+    def effective_weight(self):
+        return self.weight_orig * self.scale
+
+    def forward(self, x):
+        # (x W^T) * c + b: the constant multiplies the small product instead of the weight matrix
+        return torch.addmm(self.bias, x, self.weight_orig.t(), alpha=self.scale)
 
 
 class EqualizedLinearLayer(torch.nn.Module):
-    def __init__(self, channels_in, channels_out):
+    def __init__(self, cin, cout):
         super().__init__()
-        linear_layer = torch.nn.Linear(channels_in, channels_out)
-        linear_layer.weight.data.normal_(mean=0, std=1)
-        linear_layer.bias.data.zero_()
-        self.linear_layer = equalized_lr(linear_layer)
+        self.linear_layer = _EqLinearCore(cin, cout)
 
     def forward(self, x):
         return self.linear_layer(x)
 
 
-class EqualizedConv2d(torch.nn.Module):
-    def __init__(self, *args, out_dtype=None, **kwargs):
+class NoiseScale(torch.nn.Module):
+    """Per-channel noise gain, zero at the start, equalized with fan_in = channels (StyleGAN/model.py:179-185, :219-220)."""
+
+    def __init__(self, channels):
         super().__init__()
-        conv2d = gnn.Conv2d(*args, **kwargs)
-        conv2d.weight.data.normal_(mean=0, std=1)
-        conv2d.bias.data.zero_()
-        self.conv2d = equalized_lr(conv2d)
-        self.out_dtype = out_dtype        # a fixed storage type for this layer's output (image layers: fp32)
+        self.scaling_factor_orig = torch.nn.Parameter(torch.zeros(1, channels, 1, 1))
+        self.scale = math.sqrt(2.0 / channels)
 
-    def fuse_leaky_relu(self, negative_slope):
-        self.conv2d.activation, self.conv2d.negative_slope = "leaky_relu", negative_slope
-        return self
-
-    def forward(self, x, out_dtype=None):
-        self.conv2d.out_dtype = out_dtype or self.out_dtype or _act_dtype
-        return self.conv2d(x)
+    def gain(self):
+        return self.scaling_factor_orig * self.scale
 
 
-class BlurLayer(torch.nn.Module):
-    """Keeps the reference's two buffers (state_dict compatibility); the arithmetic is the fused stencil."""
+class StyleAffine(torch.nn.Module):
+    """The style layer of AdaIN: w -> (gain, bias) per channel, bias initialised to (1, 0) (StyleGAN/model.py:193-200).
+    Keeps the reference's child names; the InstanceNorm2d it also held there has no state."""
 
-    def __init__(self, channel):
+    def __init__(self, channels, w_dim):
         super().__init__()
-        weight = torch.tensor([[1, 2, 1], [2, 4, 2], [1, 2, 1]], dtype=torch.float32).unsqueeze(0).unsqueeze(0)
-        weight /= weight.sum()
-        self.register_buffer("weight", weight.repeat(channel, 1, 1, 1))
-        self.register_buffer("weight_flip", torch.flip(weight, [2, 3]).repeat(channel, 1, 1, 1))
+        self.affine_transformation_layer = EqualizedLinearLayer(w_dim, 2 * channels)
+        with torch.no_grad():
+            self.affine_transformation_layer.linear_layer.bias[:channels] = 1.0
+        self.channels, self.eps = channels, 1e-5
+
+    def forward(self, w):
+        return self.affine_transformation_layer(w).split(self.channels, dim=1)
+
+
+class Blur(torch.nn.Module):
+    """[1 2 1] x [1 2 1] / 16 per channel.  The two buffers exist only because the reference's state_dict has them."""
+
+    def __init__(self, channels):
+        super().__init__()
+        k = torch.tensor([1.0, 2.0, 1.0])
+        k = (k[:, None] * k[None, :] / 16.0).expand(channels, 1, 3, 3).contiguous()
+        self.register_buffer("weight", k)
+        self.register_buffer("weight_flip", k.clone())      # the kernel is symmetric: its flip is itself
 
     def forward(self, x):
         return GF.blur3x3(x)
 
 
-class PixelWiseNormalization(torch.nn.Module):
-    def __init__(self):
+class LearnedConstant(torch.nn.Module):
+    def __init__(self, channels, size=4):
         super().__init__()
-        self.epsilon = 1e-8
+        self.constant_input = torch.nn.Parameter(torch.randn(1, channels, size, size))
+
+    def forward(self, batch):
+        c = self.constant_input if _store["dtype"] is None else self.constant_input.to(_store["dtype"])
+        return c.expand(batch, -1, -1, -1)
+
+
+class UpsampleConvT(torch.nn.Module):
+    """Nearest x2 followed by a 3x3 conv, computed as ONE 4x4 stride-2 transposed conv: each 4x4 tap is the mean of the
+    (up to four) 3x3 taps that the x2 replication maps onto it (StyleGAN/model.py:380-406).  `weight` is the 3x3
+    parameter [Cin, Cout, 3, 3]."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(cin, cout, 3, 3))
+        self.bias = torch.nn.Parameter(torch.zeros(cout))
+        self.scale = math.sqrt(2.0 / (cin * 9))
 
     def forward(self, x):
-        return x / torch.sqrt(torch.mean(x ** 2, dim=1, keepdim=True) + self.epsilon)
+        w4 = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(self.weight, [1, 1, 1, 1]), 2, stride=1)     # [Cin, Cout, 4, 4]
+        return GF.conv_transpose2d(x, w4, self.bias, stride=2, padding=1, out_dtype=_store["dtype"], weight_scale=self.scale)
 
 
-class ConstantInput(torch.nn.Module):
-    def __init__(self, n_channels, size=4):
+def _numbered(*modules):
+    """Children named "0", "1", ... (the reference wraps these groups in Sequential; here they are called one by one)."""
+    holder = torch.nn.Module()
+    for i, m in enumerate(modules):
+        holder.add_module(str(i), m)
+    return holder
+
+
+def _children(holder):
+    return list(holder._modules.values())
+
+
+# ---- generator -------------------------------------------------------------------------------------------------------
+def _styled(x, noise, gain_module, styles, style_vector):
+    """ys * InstanceNorm(lrelu(x + gain * noise)) + yb."""
+    ys, yb = styles(style_vector)
+    gain = gain_module.gain()
+    if _store["fused_chain"] and x.is_cuda and x.shape[1] % 4 == 0:
+        return ops.noise_lrelu_adain(x, noise, gain, ys, yb, styles.eps, LRELU)[0]
+    h = torch.nn.functional.leaky_relu(x + gain.to(x.dtype) * noise.to(x.dtype), LRELU)
+    h = ops.instnorm_act(h, styles.eps, 0, 0.0) if h.is_cuda else torch.nn.functional.instance_norm(h, eps=styles.eps)
+    return ys.to(h.dtype)[:, :, None, None] * h + yb.to(h.dtype)[:, :, None, None]
+
+
+class SynthesisBlock(torch.nn.Module):
+    def __init__(self, cin, cout, kind, w_dim):
         super().__init__()
-        self.constant_input = torch.nn.Parameter(torch.randn(1, n_channels, size, size))
-
-    def forward(self, x):
-        c = self.constant_input if _act_dtype is None else self.constant_input.to(_act_dtype)
-        return c.repeat(x.shape[0], 1, 1, 1)
-
-
-class NoiseInput(torch.nn.Module):
-    def __init__(self, n_channels):
-        super().__init__()
-        self.scaling_factor = torch.nn.Parameter(torch.zeros(1, n_channels, 1, 1))
-
-    def forward(self, x, noise):
-        return torch.addcmul(x, _like(self.scaling_factor, x), _like(noise, x))     # x + scaling_factor * noise, one pass
-
-
-class AdaptiveInstanceNormalization(torch.nn.Module):
-    def __init__(self, input_ch, w_dim=512):
-        super().__init__()
-        self.instance_normalization = gnn.InstanceNormAct2d(input_ch, negative_slope=None)
-        self.affine_transformation_layer = EqualizedLinearLayer(w_dim, input_ch * 2)
-        self.affine_transformation_layer.linear_layer.bias.data[:input_ch] = 1
-        self.affine_transformation_layer.linear_layer.bias.data[input_ch:] = 0
-
-    def forward(self, x, style):
-        styles = _like(self.affine_transformation_layer(style), x)
-        y_s, y_b = torch.chunk(styles, 2, dim=1)
-        return torch.addcmul(y_b.unsqueeze(2).unsqueeze(3), y_s.unsqueeze(2).unsqueeze(3), self.instance_normalization(x))
-
-
-class FusedUpsample(torch.nn.Module):
-    def __init__(self, in_channel, out_channel, kernel_size, padding=0):
-        super().__init__()
-        weight = torch.randn(in_channel, out_channel, kernel_size, kernel_size)
-        bias = torch.zeros(out_channel)
-        self.multiplier = math.sqrt(2 / (in_channel * kernel_size * kernel_size))
-        self.weight = torch.nn.Parameter(weight)
-        self.bias = torch.nn.Parameter(bias)
-        self.pad = padding
-
-    def forward(self, input):
-        weight = torch.nn.functional.pad(self.weight * self.multiplier, [1, 1, 1, 1])
-        weight = (weight[:, :, 1:, 1:] + weight[:, :, :-1, 1:] + weight[:, :, 1:, :-1] + weight[:, :, :-1, :-1]) / 4
-        return GF.conv_transpose2d(input, weight, self.bias, stride=2, padding=self.pad, out_dtype=_act_dtype)
-
-
-class SynthesisNetworkBlock(torch.nn.Module):
-    def __init__(self, input_channels, output_channels, kernel_size=3, padding=1, w_dim=512, first=False, fused=False):
-        super().__init__()
-        self.noise_injection_1 = equalized_lr(NoiseInput(output_channels), name="scaling_factor")
-        self.noise_injection_2 = equalized_lr(NoiseInput(output_channels), name="scaling_factor")
-        if first:
-            self.convolution_1 = ConstantInput(input_channels, size=4)
-            self.convolution_2 = EqualizedConv2d(input_channels, output_channels, kernel_size=kernel_size, padding=padding)
+        self.kind = kind
+        self.noise_injection_1 = NoiseScale(cout)
+        self.noise_injection_2 = NoiseScale(cout)
+        if kind == "const":
+            self.convolution_1 = LearnedConstant(cin)
+            self.convolution_2 = EqualizedConv2d(cin, cout, 3, padding=1)
         else:
-            if fused:
-                self.convolution_1 = torch.nn.Sequential(
-                    FusedUpsample(input_channels, output_channels, kernel_size=3, padding=1), BlurLayer(output_channels))
+            if kind == "transposed":
+                self.convolution_1 = _numbered(UpsampleConvT(cin, cout), Blur(cout))
             else:
-                self.convolution_1 = torch.nn.Sequential(
-                    gnn.UpsampleNearest2x(),
-                    EqualizedConv2d(input_channels, output_channels, kernel_size=kernel_size, padding=padding),
-                    BlurLayer(output_channels))
-            self.convolution_2 = EqualizedConv2d(output_channels, output_channels, kernel_size=kernel_size, padding=padding)
-        self.adaIN_1 = AdaptiveInstanceNormalization(output_channels, w_dim=w_dim)
-        self.adaIN_2 = AdaptiveInstanceNormalization(output_channels, w_dim=w_dim)
-        self.leaky_relu_1 = torch.nn.LeakyReLU(0.2)
-        self.leaky_relu_2 = torch.nn.LeakyReLU(0.2)
+                self.convolution_1 = _numbered(gnn.UpsampleNearest2x(), EqualizedConv2d(cin, cout, 3, padding=1), Blur(cout))
+            self.convolution_2 = EqualizedConv2d(cout, cout, 3, padding=1)
+        self.adaIN_1 = StyleAffine(cout, w_dim)
+        self.adaIN_2 = StyleAffine(cout, w_dim)
 
-    def forward(self, x, style, noise=None):
-        output = self.convolution_1(x)
+    def forward(self, x, style_vector, noise=None):
+        if self.kind == "const":
+            h = self.convolution_1(style_vector.shape[0])
+        else:
+            h = x
+            for stage in _children(self.convolution_1):
+                h = stage(h)
         if noise is None:
-            b, _, w, h = output.shape
-            noise = torch.randn(b, 1, w, h, device=output.device)
-        output = self._styled(output, noise, style, self.noise_injection_1, self.leaky_relu_1, self.adaIN_1)
-        output = self.convolution_2(output)
-        output = self._styled(output, noise, style, self.noise_injection_2, self.leaky_relu_2, self.adaIN_2)
-        return output
+            noise = torch.randn(h.shape[0], 1, h.shape[2], h.shape[3], device=h.device)
+        h = _styled(h, noise, self.noise_injection_1, self.adaIN_1, style_vector)
+        h = self.convolution_2(h)
+        return _styled(h, noise, self.noise_injection_2, self.adaIN_2, style_vector)
 
-    @staticmethod
-    def _styled(x, noise, style, injection, activation, adain):
-        """noise injection -> LeakyReLU -> AdaIN: one fused kernel per direction when it applies (GPU tensor, channels a
-        multiple of 4, no second-order graph being built), else the three modules as the reference chains them."""
-        if _fused_chain and x.is_cuda and x.shape[1] % 4 == 0:
-            w = injection.scaling_factor_orig                      # EqualizedLR: the scaled factor the pre-hook would set
-            sf = w * math.sqrt(2 / (w.shape[1] * w[0][0].numel()))
-            y_s, y_b = torch.chunk(adain.affine_transformation_layer(style), 2, dim=1)
-            return ops.noise_lrelu_adain(x, noise, sf, y_s, y_b, float(adain.instance_normalization.eps),
-                                         float(activation.negative_slope))[0]
-        return adain(activation(injection(x, noise)), style)
+
+class SynthesisNetwork(torch.nn.Module):
+    def __init__(self, image_dim=3, fused=True, w_dim=512):
+        super().__init__()
+        self.synthesis_network = torch.nn.ModuleList(
+            SynthesisBlock(cin, cout, kind if (fused or kind != "transposed") else "nearest", w_dim) for cin, cout, kind in SYNTHESIS_PLAN)
+        self.to_RGB_layers = torch.nn.ModuleList(EqualizedConv2d(cout, image_dim, 1, keep_fp32=True) for _, cout, _ in SYNTHESIS_PLAN)
+
+    def forward(self, w_vectors, pg_step=8, alpha=1, noises=None, crossover_point=None):
+        if len(w_vectors) > 2:
+            raise ValueError("style mixing takes at most two latent codes")
+        if len(w_vectors) == 2:
+            switch = random.randint(1, pg_step) if crossover_point is None else crossover_point
+        else:
+            switch = pg_step + 1        # never
+        h, below = None, None           # features at the current / the previous resolution
+        for level in range(pg_step + 1):
+            below = h
+            w = w_vectors[1] if level >= switch else w_vectors[0]
+            h = self.synthesis_network[level](below, w, None if noises is None else noises[level])
+        image = self.to_RGB_layers[pg_step](h)
+        if 0 <= alpha < 1:              # fade the new resolution in over the up-scaled image of the previous one
+            previous = self.to_RGB_layers[pg_step - 1](below)
+            previous = torch.nn.functional.interpolate(previous, scale_factor=2, mode="nearest")
+            image = torch.lerp(previous, image, alpha)
+        return image
 
 
 class MappingNetwork(torch.nn.Module):
     def __init__(self, z_dim=512, w_dim=512, n_layers=8, normalize=True):
         super().__init__()
-        self.normalization_layer = PixelWiseNormalization() if normalize else torch.nn.Identity()
+        self.normalize = normalize
         layers = []
         for i in range(n_layers):
-            layers += [EqualizedLinearLayer(z_dim if i == 0 else w_dim, w_dim), torch.nn.LeakyReLU(0.2)]
+            layers += [EqualizedLinearLayer(z_dim if i == 0 else w_dim, w_dim), torch.nn.LeakyReLU(LRELU)]
         self.mapping_network_layers = torch.nn.Sequential(*layers)
 
-    def forward(self, latent_code):
-        return self.mapping_network_layers(self.normalization_layer(latent_code))
-
-
-class SynthesisNetwork(torch.nn.Module):
-    def __init__(self, image_dim=3, fused=True):
-        super().__init__()
-        self.synthesis_network = torch.nn.Sequential(
-            SynthesisNetworkBlock(512, 512, first=True), SynthesisNetworkBlock(512, 512), SynthesisNetworkBlock(512, 512),
-            SynthesisNetworkBlock(512, 512), SynthesisNetworkBlock(512, 256), SynthesisNetworkBlock(256, 128, fused=fused),
-            SynthesisNetworkBlock(128, 64, fused=fused), SynthesisNetworkBlock(64, 32, fused=fused),
-            SynthesisNetworkBlock(32, 16, fused=fused))
-        self.to_RGB_layers = torch.nn.Sequential(*[EqualizedConv2d(c, image_dim, kernel_size=1, stride=1, padding=0, out_dtype=torch.float32)
-                                                   for c in (512, 512, 512, 512, 256, 128, 64, 32, 16)])
-
-    def forward(self, w_vectors, pg_step=8, alpha=1, noises=None, crossover_point=None):
-        assert len(w_vectors) < 3
-        output_last = w_vectors[0]
-        w_vector = w_vectors[0]
-        if len(w_vectors) > 1:
-            if crossover_point is None:
-                crossover_point = random.randint(1, pg_step)
-        else:
-            crossover_point = pg_step + 1
-        for index, block in enumerate(self.synthesis_network):
-            if index >= crossover_point:
-                w_vector = w_vectors[1]
-            output_cur = block(output_last, w_vector, None if noises is None else noises[index])
-            if index == pg_step:
-                break
-            output_last = output_cur
-        output = self.to_RGB_layers[index](output_cur)
-        if 0 <= alpha < 1:
-            image_last = self.to_RGB_layers[index - 1](output_last)
-            image_last = torch.nn.functional.interpolate(image_last, scale_factor=2, mode="nearest")
-            output = (1 - alpha) * image_last + alpha * output
-        return output
+    def forward(self, z):
+        if self.normalize:          # pixel-wise normalisation of the latent code (eps 1e-8)
+            z = z * torch.rsqrt(z.square().mean(dim=1, keepdim=True) + 1e-8)
+        return self.mapping_network_layers(z)
 
 
 class StyleBasedGenerator(torch.nn.Module):
     def __init__(self, z_dim=512, w_dim=512, n_layers=8, normalize=True, image_dim=3, fused=True):
         super().__init__()
-        self.mapping_network = MappingNetwork(z_dim=z_dim, w_dim=w_dim, n_layers=n_layers, normalize=normalize)
-        self.synthesis_network = SynthesisNetwork(image_dim=image_dim, fused=fused)
+        self.mapping_network = MappingNetwork(z_dim, w_dim, n_layers, normalize)
+        self.synthesis_network = SynthesisNetwork(image_dim, fused, w_dim)
 
     def forward(self, noise_vectors, progressive_growing_phase=8, alpha=1, noises=None, crossover_point=None):
-        if not isinstance(noise_vectors, (tuple, list)):
-            noise_vectors = (noise_vectors,)
-        w_vectors = [self.mapping_network(z) for z in noise_vectors]
-        return self.synthesis_network(w_vectors, progressive_growing_phase, alpha, noises, crossover_point)
+        codes = noise_vectors if isinstance(noise_vectors, (tuple, list)) else [noise_vectors]
+        return self.synthesis_network([self.mapping_network(z) for z in codes], progressive_growing_phase, alpha, noises,
+                                      crossover_point)
 
 
-class DownsampleBlock(torch.nn.Module):
-    def __init__(self, input_channels, output_channels, kernel_size_1, padding_1, kernel_size_2=None, padding_2=None,
-                 fused=False, downsample=True):
+# ---- discriminator ---------------------------------------------------------------------------------------------------
+class CriticBlock(torch.nn.Module):
+    """conv 3x3 + LeakyReLU, then one of: blur + 4x4 stride-2 conv + LeakyReLU ("strided"), blur + 3x3 conv + average pool +
+    LeakyReLU ("pooled"), or a k x k conv + LeakyReLU ("plain", the last block).  The LeakyReLU runs in the epilogue of the
+    convolution in front of it, except behind the average pool."""
+
+    def __init__(self, cin, cout, mode, k2=3, p2=1):
         super().__init__()
-        kernel_size_2 = kernel_size_1 if kernel_size_2 is None else kernel_size_2
-        padding_2 = padding_1 if padding_2 is None else padding_2
-        self.convolution_1 = torch.nn.Sequential(
-            EqualizedConv2d(input_channels, output_channels, kernel_size=kernel_size_1, padding=padding_1))
-        self.activation_1 = torch.nn.LeakyReLU(0.2)
-        if downsample:
-            if fused:
-                self.convolution_2 = torch.nn.Sequential(
-                    BlurLayer(output_channels),
-                    EqualizedConv2d(output_channels, output_channels, kernel_size=4, stride=2, padding=padding_2))
-            else:
-                self.convolution_2 = torch.nn.Sequential(
-                    BlurLayer(output_channels),
-                    EqualizedConv2d(output_channels, output_channels, kernel_size=kernel_size_2, padding=padding_2),
-                    gnn.AvgPool2x2())
+        self.mode = mode
+        self.convolution_1 = _numbered(EqualizedConv2d(cin, cout, 3, padding=1, lrelu=True))
+        if mode == "strided":
+            self.convolution_2 = _numbered(Blur(cout), EqualizedConv2d(cout, cout, 4, stride=2, padding=1, lrelu=True))
+        elif mode == "pooled":
+            self.convolution_2 = _numbered(Blur(cout), EqualizedConv2d(cout, cout, 3, padding=1), gnn.AvgPool2x2())
         else:
-            self.convolution_2 = EqualizedConv2d(output_channels, output_channels, kernel_size=kernel_size_2, padding=padding_2)
-        self.activation_2 = torch.nn.LeakyReLU(0.2)
-        # LeakyReLU in the epilogue of the convolution it follows (not after the AvgPool2d of the unfused downsample)
-        self.convolution_1[0].fuse_leaky_relu(0.2)
-        self._fused_2 = not (downsample and not fused)
-        if self._fused_2:
-            (self.convolution_2[-1] if downsample else self.convolution_2).fuse_leaky_relu(0.2)
+            self.convolution_2 = EqualizedConv2d(cout, cout, k2, padding=p2, lrelu=True)
 
     def forward(self, x, out_dtype=None):
-        """`out_dtype`: storage type of this block's result (None: the harness's activation type)."""
-        output = self.convolution_1(x)
-        if isinstance(self.convolution_2, torch.nn.Sequential):
-            for layer in self.convolution_2:
-                output = layer(output, out_dtype) if isinstance(layer, EqualizedConv2d) else layer(output)
-        else:
-            output = self.convolution_2(output, out_dtype)
-        return output if self._fused_2 else self.activation_2(output)
+        h = _children(self.convolution_1)[0](x)
+        if self.mode == "plain":
+            return self.convolution_2(h, out_dtype)
+        blur, conv = _children(self.convolution_2)[:2]
+        h = conv(blur(h), out_dtype)
+        if self.mode == "pooled":
+            h = torch.nn.functional.leaky_relu(_children(self.convolution_2)[2](h), LRELU)
+        return h
 
 
 class Discriminator(torch.nn.Module):
     def __init__(self, fused=True, use_activations=False):
         super().__init__()
-        self.downsampling_blocks = torch.nn.Sequential(
-            DownsampleBlock(16, 32, 3, 1, fused=fused), DownsampleBlock(32, 64, 3, 1, fused=fused),
-            DownsampleBlock(64, 128, 3, 1, fused=fused), DownsampleBlock(128, 256, 3, 1, fused=fused),
-            DownsampleBlock(256, 512, 3, 1), DownsampleBlock(512, 512, 3, 1), DownsampleBlock(512, 512, 3, 1),
-            DownsampleBlock(512, 512, 3, 1), DownsampleBlock(513, 512, 3, 1, 4, 0, downsample=False))
-        layers = []
-        for oc in (16, 32, 64, 128, 256, 512, 512, 512, 512):
-            layers.append(EqualizedConv2d(3, oc, kernel_size=1))
+        blocks = [CriticBlock(cin, cout, "strided" if (fused and may_stride) else "pooled") for cin, cout, may_stride in CRITIC_PLAN]
+        blocks.append(CriticBlock(513, 512, "plain", k2=4, p2=0))
+        self.downsampling_blocks = torch.nn.ModuleList(blocks)
+        # one 1x1 from-image convolution per resolution; with use_activations the reference interleaves LeakyReLU modules,
+        # which shifts the convolutions to the even indices of this list (state_dict keys from_RGB_layers.{0,2,4,...})
+        entry = []
+        for cin, _, _ in CRITIC_PLAN + ((512, 512, False),):
+            entry.append(EqualizedConv2d(3, cin, 1, lrelu=use_activations))
             if use_activations:
-                layers.append(torch.nn.LeakyReLU(0.2))
-        self.from_RGB_layers = torch.nn.Sequential(*layers)
+                entry.append(torch.nn.Identity())        # the LeakyReLU's slot: it runs in the convolution's epilogue
+        self.from_RGB_layers = torch.nn.ModuleList(entry)
         self.final_projection = EqualizedLinearLayer(512, 1)
         self.use_activations = use_activations
 
     def forward(self, x, progressive_growing_phase=8, alpha=1):
-        output = x
-        for index in range(progressive_growing_phase + 1):
-            cur_idx = -progressive_growing_phase - 1 + index
-            cur_layer = self.downsampling_blocks[cur_idx]
-            # The minibatch standard deviation divides by a per-position spread over the batch, which bf16 rounding can
-            # collapse to exactly zero: the features it is taken of are produced and kept in fp32.
-            feeds_std = index == progressive_growing_phase - 1
-            if index == 0:
-                cur_idx_rgb = cur_idx if not self.use_activations else cur_idx * 2
-                output = self.from_RGB_layers[cur_idx_rgb](output, torch.float32 if progressive_growing_phase == 0 else None)
+        pg = progressive_growing_phase
+        n = len(self.downsampling_blocks)
+        first = n - 1 - pg                          # the block that takes the image's resolution
+        entry = self.from_RGB_layers[first * (2 if self.use_activations else 1)]
+        # The minibatch statistic divides by a spread over the batch that bf16 rounding can collapse to exactly zero: the
+        # features it is taken of (the output of the last block but one) are produced and kept in fp32.
+        h = entry(x, torch.float32 if pg == 0 else None)
+        for level in range(first, n):
+            last = level == n - 1
+            if last:                                # minibatch standard deviation as one more feature map
+                spread = h.std(dim=0, unbiased=False).mean()
+                h = torch.cat([h, spread.expand(h.shape[0], 1, h.shape[2], h.shape[3])], dim=1)
+            h = self.downsampling_blocks[level](h, torch.float32 if level == n - 2 else None)
+            if level == first and 0 <= alpha < 1 and not last:
                 if self.use_activations:
-                    output = self.from_RGB_layers[cur_idx_rgb + 1](output)
-            if index == progressive_growing_phase:
-                averaged_std = output.std(dim=0, unbiased=False).mean()
-                averaged_std = averaged_std.expand(output.shape[0], 1, output.shape[2], output.shape[3])
-                output = torch.cat([output, averaged_std], dim=1)
-            output = cur_layer(output, torch.float32 if feeds_std else None)
-            if 0 <= alpha < 1 and index == 0 and cur_idx != -1:
-                x = torch.nn.functional.avg_pool2d(x, 2)
-                cur_idx_rgb = cur_idx if not self.use_activations else cur_idx * 2
-                x = self.from_RGB_layers[cur_idx_rgb](x)
-                if self.use_activations:
-                    x = self.from_RGB_layers[cur_idx_rgb + 1](output)
-                output = (1 - alpha) * x + alpha * output
-        return self.final_projection(output.squeeze(2).squeeze(2).float())
+                    # the reference down-scales the image and converts it, then overwrites the result with LeakyReLU(h):
+                    # the blend partner is h's own activation (and the converted image is never used)
+                    partner = torch.nn.functional.leaky_relu(h, LRELU)
+                else:
+                    partner = entry(torch.nn.functional.avg_pool2d(x, 2))
+                h = torch.lerp(partner, h, alpha)
+        return self.final_projection(h.flatten(1).float())
 
 
+# ---- training phases (StyleGAN/train.py:211-248) -----------------------------------------------------------------------
 def requires_grad(model, flag=True):
     for p in model.parameters():
-        p.requires_grad = flag
+        p.requires_grad_(flag)
 
 
 def critic_phase(net_G, net_D, real, z, epsilon, pg_step, alpha=1, c_lambda=10.0, noises=None, crossover_point=None,
                  on_last_backward=None):
-    """StyleGAN/train.py:211-216: generator frozen, three backward passes into the discriminator."""
+    """Generator frozen; three backward passes accumulate into the discriminator's gradients: real images (with the
+    0.001 drift term), generated images, gradient penalty on their mix (double backward).  Returns
+    (D(x) term, D(G(z)), penalty, generated images), all detached."""
     requires_grad(net_G, False)
     requires_grad(net_D, True)
-    kw = dict(progressive_growing_phase=pg_step, alpha=alpha)
-    d_real = net_D(real, **kw).view(-1)
-    d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
-    (-d_real).backward()
-    fake = net_G(z, noises=noises, crossover_point=crossover_point, **kw)
-    d_fake = net_D(fake.detach(), **kw).view(-1).mean()
+    at = dict(progressive_growing_phase=pg_step, alpha=alpha)
+    score_real = net_D(real, **at).flatten()
+    d_real = score_real.mean() - 0.001 * score_real.square().mean()
+    d_real.neg().backward()
+    fake = net_G(z, noises=noises, crossover_point=crossover_point, **at).detach()
+    d_fake = net_D(fake, **at).mean()
     d_fake.backward()
-    eps = epsilon.detach().clone().requires_grad_(True)
-    mixed = real.detach() * eps + fake.detach() * (1 - eps)
-    scores = net_D(mixed, **kw)
-    gradient = torch.autograd.grad(inputs=mixed, outputs=scores.sum(), create_graph=True)[0]
-    penalty = c_lambda * ((gradient.reshape(gradient.shape[0], -1).norm(2, dim=1) - 1) ** 2).mean()
+    t = epsilon.detach().clone().requires_grad_(True)
+    mixed = real.detach() * t + fake * (1 - t)
+    (slope,) = torch.autograd.grad(net_D(mixed, **at).sum(), mixed, create_graph=True)
+    penalty = c_lambda * (slope.flatten(1).norm(2, dim=1) - 1).square().mean()
     if on_last_backward is not None:
         on_last_backward()
     penalty.backward()
-    return d_real.detach(), d_fake.detach(), penalty.detach(), fake.detach()
+    return d_real.detach(), d_fake.detach(), penalty.detach(), fake
 
 
 def generator_phase(net_G, net_D, z, pg_step, alpha=1, noises=None, crossover_point=None, on_last_backward=None):
-    """StyleGAN/train.py:228-234: discriminator frozen."""
+    """Discriminator frozen; the generator's loss is -mean D(G(z)).  Returns (loss, generated images), detached."""
     requires_grad(net_G, True)
     requires_grad(net_D, False)
-    kw = dict(progressive_growing_phase=pg_step, alpha=alpha)
-    fake = net_G(z, noises=noises, crossover_point=crossover_point, **kw)
-    g_error = -net_D(fake, **kw).view(-1).mean()
+    at = dict(progressive_growing_phase=pg_step, alpha=alpha)
+    fake = net_G(z, noises=noises, crossover_point=crossover_point, **at)
+    loss = net_D(fake, **at).mean().neg()
     if on_last_backward is not None:
         on_last_backward()
-    g_error.backward()
+    loss.backward()
     requires_grad(net_G, False)
     requires_grad(net_D, True)
-    return g_error.detach(), fake.detach()
+    return loss.detach(), fake.detach()

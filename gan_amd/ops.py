@@ -389,9 +389,11 @@ def _act_backward(g, y, act, slope):
 # ---- op implementations (run below autograd) -------------------------------------------------------------------
 @torch.library.custom_op("ganconv::conv_fprop", mutates_args=())
 def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, padding: int, precision: int, wkey: int,
-               act: int = 0, slope: float = 0.0, out_dtype: int = -1) -> Tensor:
-    """act(conv2d(x, w) + bias); act is a gc_act code fused into the kernel's epilogue.  out_dtype: -1 the input's
-    dtype, 0 float32, 1 bfloat16 (activations may be stored in either; accumulation is fp32)."""
+               act: int = 0, slope: float = 0.0, out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
+    """act(conv2d(x, alpha * w) + bias); act is a gc_act code fused into the kernel's epilogue.  out_dtype: -1 the
+    input's dtype, 0 float32, 1 bfloat16 (activations may be stored in either; accumulation is fp32).  alpha: a per-layer
+    scalar folded into the packed weight image (EqualizedLR's sqrt(2 / fan_in), StyleGAN/model.py:33-37): the weight the
+    op sees stays the stored parameter, so its cached image is reused until the parameter itself changes."""
     _check_cuda(x, w, bias)
     N, Cin, H, W = x.shape
     Cout, Cin_w, kh, kw = w.shape
@@ -407,7 +409,7 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     if _dma_ok(x, Cin, Cout, precision):
         x = _to_bf16(x)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(y))
-    wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey)
+    wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey, alpha)
     ep, keep = _epilogue(bias, act, slope, y if (act != 0 and y.dtype == torch.float32) else None)
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
@@ -416,7 +418,7 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
 
 
 @conv_fprop.register_fake
-def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1):
+def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1, alpha=1.0):
     N, _, H, W = x.shape
     Cout, _, kh, kw = w.shape
     return x.new_empty((N, Cout, (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1),
@@ -425,8 +427,8 @@ def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=
 
 @torch.library.custom_op("ganconv::conv_dgrad", mutates_args=())
 def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, stride: int, padding: int, precision: int,
-               wkey: int, act: int = 0, slope: float = 0.0, out_dtype: int = -1) -> Tensor:
-    """gx [N, Cin, H, W] of the conv x -> y described by (w [Cout,Cin,kh,kw], stride, padding), given gy.
+               wkey: int, act: int = 0, slope: float = 0.0, out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
+    """gx [N, Cin, H, W] of the conv x -> y described by (alpha * w [Cout,Cin,kh,kw], stride, padding), given gy.
     `bias` ([Cin]) is added to gx: the bias of a transposed convolution whose forward pass this is.
     out_dtype as for conv_fprop."""
     _check_cuda(gy, w, bias)
@@ -443,7 +445,7 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
     if _dma_ok(gy, Cout, Cin, precision):
         gy = _to_bf16(gy)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gx), precision, _dtype_code(gy))
-    wp = _packed(d, w, _lib.GC_PASS_DGRAD, wkey)
+    wp = _packed(d, w, _lib.GC_PASS_DGRAD, wkey, alpha)
     ep, keep = _epilogue(bias, act, slope, gx if (act != 0 and gx.dtype == torch.float32) else None)
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(gx.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
@@ -452,13 +454,14 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
 
 
 @conv_dgrad.register_fake
-def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1):
+def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1, alpha=1.0):
     return gy.new_empty((gy.shape[0], w.shape[1], H, W), dtype=_out_dtype(gy, out_dtype))
 
 
 @torch.library.custom_op("ganconv::conv_wgrad", mutates_args=())
-def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: int, precision: int) -> Tensor:
-    """gw [Cout, Cin, kh, kw] (fp32) of the conv x -> y, given x and gy."""
+def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: int, precision: int, alpha: float = 1.0) -> Tensor:
+    """alpha * gw, gw [Cout, Cin, kh, kw] (fp32) being the weight gradient of the conv x -> y given x and gy (alpha: the
+    scalar that multiplied the weight in the forward pass, see conv_fprop)."""
     _check_cuda(x, gy)
     N, Cin, H, W = x.shape
     N2, Cout, Ho, Wo = gy.shape
@@ -481,13 +484,13 @@ def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: in
     side = _SideLaunch.active
     stream = side.fork(ws, x, gy, gw) if side is not None else _stream()
     _lib.check(L.gc_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(gy.data_ptr()),
-                                 ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), 1.0, 0, None,
+                                 ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), float(alpha), 0, None,
                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream), "gc_conv2d_wgrad")
     return gw
 
 
 @conv_wgrad.register_fake
-def _(x, gy, kh, kw, stride, padding, precision):
+def _(x, gy, kh, kw, stride, padding, precision, alpha=1.0):
     return x.new_empty((gy.shape[1], x.shape[1], kh, kw), dtype=torch.float32)
 
 
@@ -553,16 +556,16 @@ torch.library.register_autograd("ganconv::channel_sum", _channel_sum_backward, s
 
 # ---- autograd: each formula uses only the three ops above -------------------------------------------------------
 def _fprop_setup(ctx, inputs, output):
-    x, w, bias, stride, padding, precision, wkey, act, slope, _ = inputs
+    x, w, bias, stride, padding, precision, wkey, act, slope, _, alpha = inputs
     if act != 0:
         ctx.save_for_backward(x, w, output)
     else:
         ctx.save_for_backward(x, w)
-    ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope)
+    ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope, alpha)
 
 
 def _fprop_backward(ctx, gy):
-    stride, padding, precision, wkey, has_bias, act, slope = ctx.cfg
+    stride, padding, precision, wkey, has_bias, act, slope, alpha = ctx.cfg
     gb = None
     if act != 0:
         x, w, y = ctx.saved_tensors
@@ -575,34 +578,34 @@ def _fprop_backward(ctx, gy):
     gx = gw = None
     if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and gy.is_cuda:
         with _SideLaunch(gy.device) as side:
-            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision)
-        gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype))
+            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
+        gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
         side.join()
         gw = gw.to(w.dtype)
     else:
         if ctx.needs_input_grad[0]:
-            gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype))
+            gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
         if ctx.needs_input_grad[1]:
-            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
+            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2] and gb is None:
         gb = channel_sum(gy)
-    return gx, gw, gb, None, None, None, None, None, None, None
+    return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_fprop", _fprop_backward, setup_context=_fprop_setup)
 
 
 def _dgrad_setup(ctx, inputs, output):
-    gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, _ = inputs
+    gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, _, alpha = inputs
     if act != 0:
         ctx.save_for_backward(gy, w, output)
     else:
         ctx.save_for_backward(gy, w)
-    ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope)
+    ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope, alpha)
 
 
 def _dgrad_backward(ctx, u):
-    stride, padding, precision, wkey, has_bias, act, slope = ctx.cfg
+    stride, padding, precision, wkey, has_bias, act, slope, alpha = ctx.cfg
     g_b = None
     if act != 0:
         gy, w, out = ctx.saved_tensors
@@ -615,38 +618,38 @@ def _dgrad_backward(ctx, u):
     g_gy = g_w = None
     if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and u.is_cuda:
         with _SideLaunch(u.device) as side:
-            g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision)
-        g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype))
+            g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
+        g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
         side.join()
         g_w = g_w.to(w.dtype)
     else:
         if ctx.needs_input_grad[0]:
-            g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype))
+            g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
         if ctx.needs_input_grad[1]:
-            g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision).to(w.dtype)
+            g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
     if has_bias and ctx.needs_input_grad[2] and g_b is None:
         g_b = channel_sum(u)
-    return g_gy, g_w, g_b, None, None, None, None, None, None, None, None, None
+    return g_gy, g_w, g_b, None, None, None, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_dgrad", _dgrad_backward, setup_context=_dgrad_setup)
 
 
 def _wgrad_setup(ctx, inputs, output):
-    x, gy, kh, kw, stride, padding, precision = inputs
+    x, gy, kh, kw, stride, padding, precision, alpha = inputs
     ctx.save_for_backward(x, gy)
-    ctx.cfg = (stride, padding, precision)
+    ctx.cfg = (stride, padding, precision, alpha)
 
 
 def _wgrad_backward(ctx, v):
     x, gy = ctx.saved_tensors
-    stride, padding, precision = ctx.cfg
+    stride, padding, precision, alpha = ctx.cfg
     g_x = g_gy = None
     if ctx.needs_input_grad[0]:
-        g_x = conv_dgrad(gy, v, None, x.shape[2], x.shape[3], stride, padding, precision, 0, 0, 0.0, _code_of(x.dtype))
+        g_x = conv_dgrad(gy, v, None, x.shape[2], x.shape[3], stride, padding, precision, 0, 0, 0.0, _code_of(x.dtype), alpha)
     if ctx.needs_input_grad[1]:
-        g_gy = conv_fprop(x, v, None, stride, padding, precision, 0, 0, 0.0, _code_of(gy.dtype))
-    return g_x, g_gy, None, None, None, None, None
+        g_gy = conv_fprop(x, v, None, stride, padding, precision, 0, 0, 0.0, _code_of(gy.dtype), alpha)
+    return g_x, g_gy, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_wgrad", _wgrad_backward, setup_context=_wgrad_setup)
