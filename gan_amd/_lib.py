@@ -22,6 +22,7 @@ EXPORTS = (
     "gc_instnorm_act_fwd", "gc_instnorm_act_bwd", "gc_instnorm_act_bwd_bwd",
     "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_channel_sum_workspace_bytes", "gc_channel_sum", "gc_act_backward_channel_sum", "gc_batchnorm_stats", "gc_batchnorm_act_bwd_sums", "gc_batchnorm_act_bwd_apply", "gc_adam_step", "gc_adam_ema_step", "gc_set_split_reduction", "gc_set_patch_kernel", "gc_pack_weights", "gc_attention_fwd", "gc_attention_bwd", "gc_pool2x2", "gc_replicate2x", "gc_reflect_pad", "gc_reflect_pad_adjoint",
     "gc_cond_batchnorm_workspace_bytes", "gc_cond_batchnorm_act_fwd", "gc_cond_batchnorm_act_bwd", "gc_noise_lrelu_adain_workspace_bytes", "gc_noise_lrelu_adain_fwd", "gc_noise_lrelu_adain_bwd",
+    "gc_wgan_mix", "gc_gradient_penalty_workspace_bytes", "gc_gradient_penalty_fwd", "gc_gradient_penalty_bwd", "gc_wgan_critic_loss",
 )
 
 
@@ -88,6 +89,12 @@ def lib():
     L.gc_cond_batchnorm_act_bwd.argtypes = [vp] * 10 + [sz, i32, i32, i32, i32, i32, f32, vp]
     L.gc_batchnorm_update_running.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp]
     L.gc_batchnorm_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, i32, f32, vp]
+    L.gc_wgan_mix.argtypes = [vp, vp, vp, vp, i32, i64, vp]
+    L.gc_gradient_penalty_workspace_bytes.argtypes = [i32, i64]
+    L.gc_gradient_penalty_workspace_bytes.restype = sz
+    L.gc_gradient_penalty_fwd.argtypes = [vp, i32, i32, i64, f32, vp, vp, vp, vp, sz, vp]
+    L.gc_gradient_penalty_bwd.argtypes = [vp, i32, i32, i64, vp, vp, vp, vp]
+    L.gc_wgan_critic_loss.argtypes = [vp, i32, f32, vp, vp, vp]
     L.gc_channel_sum_workspace_bytes.argtypes = [i64, i32]
     L.gc_channel_sum_workspace_bytes.restype = sz
     L.gc_channel_sum.argtypes = [vp, vp, vp, sz, i64, i32, i32, vp]

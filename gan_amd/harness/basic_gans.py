@@ -90,6 +90,54 @@ def _side_stream(device, i):
     return st
 
 
+# Which scalar parts of a critic iteration run as single launches of the library on a GPU (the others, and everything
+# on the CPU, as the reference's tensor expressions; narrowing the set is an A/B aid).
+fused_scalars = {"mix", "ones", "penalty", "loss"}
+_ones = {}
+
+
+def _ones_like(t):
+    """A cached tensor of ones (the seed of d scores.sum() / d scores): no fill launch per iteration."""
+    key = (tuple(t.shape), t.dtype, t.device)
+    o = _ones.get(key)
+    if o is None:
+        o = _ones[key] = torch.ones_like(t)
+    return o
+
+
+def _penalty(net_D, real, fake, epsilon, c_lambda):
+    """c_lambda * mean((||d D(mixed) / d mixed||_2 - 1)^2) with the graph of the double backward attached
+    (BasicGANs/loss_functions.py:18-27).  Nothing reads the gradient with respect to epsilon that the reference's
+    requires_grad=True asks for, so the fused interpolation does not provide it."""
+    on = fused_scalars if real.is_cuda else ()
+    if "mix" in on:
+        mixed = gops.wgan_mix(real, fake, epsilon).requires_grad_(True)
+    else:
+        eps = epsilon.detach().clone().requires_grad_(True)
+        mixed = real.detach() * eps + fake.detach() * (1 - eps)
+    scores = net_D(mixed)
+    with gops.input_gradients_only():       # the weight gradients of this pass would be thrown away
+        if "ones" in on:
+            gradient = torch.autograd.grad(scores, mixed, grad_outputs=_ones_like(scores), create_graph=True)[0]
+        else:
+            gradient = torch.autograd.grad(inputs=mixed, outputs=scores.sum(), create_graph=True)[0]
+    if "penalty" in on:
+        return gops.gradient_penalty(gradient, c_lambda)[0]
+    return c_lambda * ((gradient.reshape(gradient.shape[0], -1).norm(2, dim=1) - 1) ** 2).mean()
+
+
+def _real_fake_loss(d_both, B):
+    """For the scores of B real samples followed by B generated ones: (D_x with its drift term, D_G_z1, the tensor to
+    differentiate, its seed gradient or None): the two backward passes of BasicGANs/loss_functions.py:7-15 as one."""
+    if d_both.is_cuda and "loss" in fused_scalars:
+        stats, seed = gops.wgan_critic_loss(d_both.detach(), 0.001)
+        return stats[0], stats[1], d_both, seed
+    flat = d_both.view(-1)
+    d_real = flat[:B].mean() - 0.001 * (flat[:B] ** 2).mean()
+    d_fake = flat[B:].mean()
+    return d_real.detach(), d_fake.detach(), d_fake - d_real, None
+
+
 def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
     """The independent parts of a critic iteration on streams of their own: the gradient-penalty pass beside the real +
     fake pass (or beside the real pass and the fake pass, `split_real_fake`).  The mid-size layers of these networks
@@ -101,11 +149,7 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
     B = real.shape[0]
 
     def penalty_chain():
-        eps = epsilon.detach().clone().requires_grad_(True)
-        mixed = real.detach() * eps + fake * (1 - eps)
-        scores = net_D(mixed)
-        gradient = torch.autograd.grad(inputs=mixed, outputs=scores.sum(), create_graph=True)[0]
-        penalty = c_lambda * ((gradient.reshape(gradient.shape[0], -1).norm(2, dim=1) - 1) ** 2).mean()
+        penalty = _penalty(net_D, real, fake, epsilon, c_lambda)
         return torch.autograd.grad(penalty, params), penalty.detach()
 
     def real_chain():
@@ -118,11 +162,8 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
         return torch.autograd.grad(d_fake, params), d_fake.detach()
 
     def both_chain():
-        d_both = net_D(torch.cat([real, fake])).view(-1)
-        d_real, d_fake = d_both[:B], d_both[B:]
-        d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
-        d_fake = d_fake.mean()
-        return torch.autograd.grad(d_fake - d_real, params), (d_real.detach(), d_fake.detach())
+        d_real, d_fake, out, seed = _real_fake_loss(net_D(torch.cat([real, fake])), B)
+        return torch.autograd.grad(out, params, grad_outputs=seed), (d_real, d_fake)
 
     side_chains = [penalty_chain, fake_chain] if split_real_fake else [penalty_chain]
     results = []
@@ -165,29 +206,21 @@ def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_bac
     convolution then runs once at twice the size instead of twice."""
     if fake is None:         # (a caller may have run the generator ahead of time: its weights do not move in this phase)
         fake = net_G(z)
+    fake = fake.detach()
     if two_streams and real.is_cuda:
         if on_last_backward is not None:
             raise RuntimeError("two_streams computes the gradients explicitly: no hook-driven reducer")
-        return _critic_streams(net_D, real, fake.detach(), epsilon, c_lambda, not batch_real_fake)
+        return _critic_streams(net_D, real, fake, epsilon, c_lambda, not batch_real_fake)
     if batch_real_fake:
-        B = real.shape[0]
-        d_both = net_D(torch.cat([real, fake.detach()])).view(-1)
-        d_real, d_fake = d_both[:B], d_both[B:]
-        d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
-        d_fake = d_fake.mean()
-        (d_fake - d_real).backward()
+        d_real, d_fake, out, seed = _real_fake_loss(net_D(torch.cat([real, fake])), real.shape[0])
+        torch.autograd.backward(out, seed)
     else:
         d_real = net_D(real).view(-1)
         d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
         (-d_real).backward()
-        d_fake = net_D(fake.detach()).view(-1).mean()
+        d_fake = net_D(fake).view(-1).mean()
         d_fake.backward()
-
-    eps = epsilon.detach().clone().requires_grad_(True)
-    mixed = real.detach() * eps + fake.detach() * (1 - eps)
-    scores = net_D(mixed)
-    gradient = torch.autograd.grad(inputs=mixed, outputs=scores.sum(), create_graph=True)[0]
-    penalty = c_lambda * ((gradient.reshape(gradient.shape[0], -1).norm(2, dim=1) - 1) ** 2).mean()
+    penalty = _penalty(net_D, real, fake, epsilon, c_lambda)
     if on_last_backward is not None:
         on_last_backward()
     penalty.backward()

@@ -1,298 +1,279 @@
-"""BigGAN (128x128, class-conditional, spectral norm, conditional BatchNorm, self-attention, projection
-discriminator) of the reference on the gan_amd convolution modules.
+"""BigGAN at 128x128 (class-conditional; spectral normalisation, conditional BatchNorm, one self-attention block per
+network, projection discriminator) on the gan_amd kernels, assembled from two block tables.
 
-Graphs, construction order and parameter names follow BigGAN/model.py: SpectralNorm :4-35, Linear :38-45, Conv2d
-:48-58, BatchNorm (conditional) :61-77, SelfAttentionBlock :80-107, GeneratorBlock :110-138, Generator :141-178,
-DiscriminatorBlock :181-205, Discriminator :208-235; the phases follow BasicGANs/loss_functions.py:79-99 (hinge) and
-BigGAN/train.py:108-127,187-226 (orthogonal init / regularisation, step order).
+Kept from BigGAN/model.py, because checkpoints and seeded runs depend on it: the state_dict keys and shapes
+(`main_sequence.1.conv_2.U_vector`, `main_sequence.0.batch_norm_1.linear.weight`, `bn.running_var`, ...), the order in
+which modules with parameters are created and registered (so a seeded construction followed by the reference's
+orthogonal_init, BigGAN/train.py:108-112, draws the same numbers), and the arithmetic including its quirks: the spectral
+norm sigma is a constant in the backward pass (:27-35), the conditional gain has no "+1" (:68-77), the attention product
+[B, positions, C] is reinterpreted as [B, C, H, W] without a transpose (:103), and the projection term multiplies the
+class embedding with the [B, 1] score (:233).
 
-Every Conv2d (3x3, 1x1, incl. the attention projections) runs on the gan_amd kernels through
-gan_amd.functional.conv2d with the spectrally normalised weight W / sigma, as the reference calls F.conv2d.  The
-conditional BatchNorm + ReLU runs on the fused normalisation kernels, pooling / nearest upsampling on the resampling
-kernels; the power iteration, the SN Linear layers, the attention product (unless switched to the fused kernel, below)
-and the embeddings stay on stock torch ops.  Reference quirks kept: sigma is not differentiated; the conditional
-BN gain has no +1; the projection term broadcasts `output` ([B,1]) against the class embedding.
+What runs where: every convolution (3x3, 1x1, the attention projections) on the gan_amd convolution kernels; conditional
+BatchNorm + ReLU on the fused normalisation kernels; 2x2 average pooling and nearest x2 up-scaling on the resampling
+kernels; the ReLU between a discriminator block's two convolutions in the first one's epilogue; the power iteration, the
+spectrally normalised Linear layers, the embeddings and (by default) the attention product on torch ops.  A
+discriminator block's 1x1 shortcut runs behind the pooling instead of in front of it (both are linear: same result, a
+quarter of the pixels).
 
-Two storage / arithmetic options, both off by default (set_activation_dtype, set_fused_attention):
-  * activations between layers stored in bf16 (convolutions accumulate in fp32, the normalisation statistics, the
-    Linear layers, the losses and the images stay fp32);
-  * in the bf16 precision mode, softmax(K Q) V of the attention blocks on gan_amd.ops.attention (bf16 operands, fp32
-    accumulation), which never materialises the [B, 4096, 4096] weights the reference's bmm + softmax + bmm writes
-    and re-reads (17 GB at batch 256).
+Options (off by default): set_activation_dtype(torch.bfloat16) stores activations in bf16 between layers;
+set_fused_attention(True) computes softmax(K Q) V with ops.attention, which never materialises the [B, 4096, 4096]
+weights.  Phases: hinge loss of BasicGANs/loss_functions.py:79-99, step order and orthogonal regularisation of
+BigGAN/train.py:115-127, 187-226.
 """
 import torch
+import torch.nn.functional as TF
 
 from .. import functional as GF
 from .. import nn as gnn
 from .. import ops
 
-_act_dtype = None          # None: every layer follows its input (fp32 images -> fp32 activations)
-_fused_attention = False
+# channel multipliers (of `ch`) per residual block; "attention" marks where the self-attention block sits
+GENERATOR_PLAN = ((16, 16), (16, 8), (8, 4), (4, 2), "attention", (2, 1))                  # BigGAN/model.py:147-154
+CRITIC_PLAN = ((None, 1, True), "attention", (1, 2, True), (2, 4, True), (4, 8, True), (8, 16, True), (16, 16, False))   # :212-220
+
+_opt = {"dtype": None, "fused_attention": False, "fused_norm": True}
 
 
 def set_activation_dtype(dtype):
     """torch.bfloat16: convolutions store bf16 outputs; None or torch.float32: fp32 storage (the reference's)."""
-    global _act_dtype
-    _act_dtype = None if dtype in (None, torch.float32) else dtype
+    _opt["dtype"] = None if dtype in (None, torch.float32) else dtype
 
 
 def set_fused_attention(on):
-    global _fused_attention
-    _fused_attention = bool(on)
-
-
-def _like(t, ref):
-    return t if t.dtype == ref.dtype else t.to(ref.dtype)
-
-
-_fused_norm = True
+    _opt["fused_attention"] = bool(on)
 
 
 def set_fused_norm(on):
     """Training-mode (conditional) BatchNorm + ReLU on the fused normalisation kernels (default) or on torch ops."""
-    global _fused_norm
-    _fused_norm = bool(on)
+    _opt["fused_norm"] = bool(on)
 
 
-def _fused_bn(bn, x, weight, bias, activation):
-    """bn: a torch.nn.BatchNorm2d in training mode (its running statistics are updated as torch does); weight / bias:
-    its own [C] parameters or per-sample [N, C] gains and biases."""
-    y, mean, _, var = ops.batchnorm_act(x, weight, bias, bn.running_mean, bn.running_var, True, float(bn.eps),
-                                        1 if activation == "relu" else 0, 0.0)
-    if bn.track_running_stats:
-        with torch.no_grad():
-            ops.batchnorm_update_running_(bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, var, float(bn.momentum))
-    return y
+# ---- spectral normalisation --------------------------------------------------------------------------------------------
+def _sigma(layer):
+    """Largest singular value of layer.weight (as a [out, rest] matrix) by power iteration from the stored left vector
+    U_vector [1, out], which is advanced in place.  No gradient flows through it."""
+    with torch.no_grad():
+        w = layer.weight.flatten(1)
+        for _ in range(layer.n_iterations):
+            v = TF.normalize(layer.U_vector @ w, p=layer.norm)
+            u = TF.normalize(v @ w.t(), p=layer.norm)
+            s = (u @ w @ v.t()).reshape(())
+            layer.U_vector.copy_(u)        # in place: the buffer keeps its storage, which a recorded step relies on
+    return s
 
 
-class SpectralNorm(object):
-    def __init__(self, n_outputs, n_iterations=1, norm=2):
-        self.n_iterations = n_iterations
-        self.norm = norm
-        self.register_buffer("U_vector", torch.rand(1, n_outputs))
+class Conv2d(gnn.Conv2d):
+    """Convolution with the weight W / sigma(W)."""
 
-    def compute_weight(self):
-        W_matrix = self.weight.view(self.weight.shape[0], -1)
-        for _ in range(self.n_iterations):
-            spectral_norm, _ = self._power_iterations(W_matrix)
-        return self.weight / spectral_norm
-
-    def _power_iterations(self, W_matrix):
-        with torch.no_grad():
-            V_vector = torch.nn.functional.normalize(torch.matmul(self.U_vector, W_matrix), p=self.norm)
-            U_vector = torch.nn.functional.normalize(torch.matmul(V_vector, W_matrix.T), p=self.norm)
-            spectral_norm = torch.matmul(torch.matmul(U_vector, W_matrix), V_vector.T).squeeze()
-            self.U_vector.copy_(U_vector)     # written in place (the reference rebinds .data): same values, and the
-            #                                   buffer keeps its storage, which a recorded step relies on
-            return spectral_norm, U_vector
-
-
-class Linear(SpectralNorm, torch.nn.Linear):
-    def __init__(self, in_features, out_features, bias=True, n_iterations=1, norm=2):
-        torch.nn.Linear.__init__(self, in_features, out_features, bias=bias)
-        SpectralNorm.__init__(self, out_features, n_iterations=n_iterations, norm=norm)
-
-    def forward(self, x):
-        return torch.nn.functional.linear(x, self.compute_weight(), bias=self.bias)
-
-
-class Conv2d(SpectralNorm, gnn.Conv2d):
     def __init__(self, input_channels, output_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  n_iterations=1, norm=2):
-        gnn.Conv2d.__init__(self, input_channels, output_channels, kernel_size=kernel_size, stride=stride, padding=padding,
-                            dilation=dilation, groups=groups, bias=bias)
-        SpectralNorm.__init__(self, output_channels, n_iterations=n_iterations, norm=norm)
+        super().__init__(input_channels, output_channels, kernel_size, stride=stride, padding=padding, dilation=dilation,
+                         groups=groups, bias=bias)
+        self.n_iterations, self.norm = n_iterations, norm
+        self.register_buffer("U_vector", torch.rand(1, output_channels))
 
     def forward(self, x, activation=None, out_dtype=None):
-        return GF.conv2d(x, self.compute_weight(), bias=self.bias, stride=self.stride, padding=self.padding,
-                         dilation=self.dilation, groups=self.groups, activation=activation,
-                         out_dtype=out_dtype if out_dtype is not None else _act_dtype)
+        return GF.conv2d(x, self.weight / _sigma(self), self.bias, self.stride, self.padding, self.dilation, self.groups,
+                         activation=activation, out_dtype=out_dtype if out_dtype is not None else _opt["dtype"])
 
 
-class BatchNorm(torch.nn.Module):
-    def __init__(self, channels, y_dim=148):
+class Linear(torch.nn.Linear):
+    def __init__(self, in_features, out_features, bias=True, n_iterations=1, norm=2):
+        super().__init__(in_features, out_features, bias=bias)
+        self.n_iterations, self.norm = n_iterations, norm
+        self.register_buffer("U_vector", torch.rand(1, out_features))
+
+    def forward(self, x):
+        return TF.linear(x, self.weight / _sigma(self), self.bias)
+
+
+# ---- normalisation -----------------------------------------------------------------------------------------------------
+def _batchnorm_relu(bn, x, gain, shift):
+    """relu(gain * BatchNorm(x) + shift); gain / shift: [C] parameters or per-sample [N, C] tensors."""
+    if _opt["fused_norm"] and bn.training and x.shape[1] % 4 == 0:
+        y, mean, _, var = ops.batchnorm_act(x, gain, shift, bn.running_mean, bn.running_var, True, float(bn.eps), 1, 0.0)
+        if bn.track_running_stats:
+            with torch.no_grad():
+                ops.batchnorm_update_running_(bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, var, float(bn.momentum))
+        return y
+    if gain.dim() == 2:
+        gain, shift = gain[:, :, None, None], shift[:, :, None, None]
+        return torch.relu(gain.to(x.dtype) * bn(x) + shift.to(x.dtype))
+    return torch.relu(bn(x))          # (bn is affine itself here)
+
+
+class ConditionalNorm(torch.nn.Module):
+    """BatchNorm2d(affine=False) whose gain and shift are linear in the conditioning vector (noise chunk + class embedding)."""
+
+    def __init__(self, channels, y_dim):
         super().__init__()
         self.batch_norm = torch.nn.BatchNorm2d(channels, affine=False)
-        self.linear = Linear(y_dim, channels * 2)
+        self.linear = Linear(y_dim, 2 * channels)
 
-    def forward(self, x, y, activation=None):
-        """gamma(y) * BatchNorm(x) + beta(y), then the optional ReLU, as one fused normalisation (statistics, finalize,
-        apply) in training mode; the unfused torch composition otherwise."""
-        gamma, beta = self.linear(y).chunk(2, dim=1)
-        bn = self.batch_norm
-        if _fused_norm and bn.training and x.shape[1] % 4 == 0:
-            return _fused_bn(bn, x, gamma, beta, activation)
-        gamma, beta = _like(gamma, x), _like(beta, x)
-        out = gamma.unsqueeze(2).unsqueeze(2) * bn(x) + beta.unsqueeze(2).unsqueeze(2)
-        return torch.relu(out) if activation == "relu" else out
+    def forward(self, x, y):
+        gain, shift = self.linear(y).chunk(2, dim=1)
+        return _batchnorm_relu(self.batch_norm, x, gain, shift)
 
 
+# ---- blocks ------------------------------------------------------------------------------------------------------------
 class SelfAttentionBlock(torch.nn.Module):
-    def __init__(self, input_channels, k=8):
+    def __init__(self, channels, k=8):
         super().__init__()
-        self.f_layer = Conv2d(input_channels, input_channels // k, kernel_size=1, stride=1)
-        self.g_layer = Conv2d(input_channels, input_channels // k, kernel_size=1, stride=1)
-        self.h_layer = Conv2d(input_channels, input_channels, kernel_size=1, stride=1)
+        self.f_layer = Conv2d(channels, channels // k, 1)
+        self.g_layer = Conv2d(channels, channels // k, 1)
+        self.h_layer = Conv2d(channels, channels, 1)
         self.gamma = torch.nn.Parameter(torch.zeros(1, 1))
-        self.softmax = torch.nn.Softmax(dim=-1)
 
     def forward(self, x):
         b, c, h, w = x.shape
-        key = self.f_layer(x).reshape(b, -1, h * w).permute(0, 2, 1)      # [b, positions, c / k]
-        query = self.g_layer(x).reshape(b, -1, h * w)                      # [b, c / k, positions]
-        value = self.h_layer(x).reshape(b, -1, h * w)                      # [b, c, positions]
-        if _fused_attention and ops.get_precision() == ops._lib.GC_PREC_BF16 and (h * w) % 128 == 0 and c in (64, 128):
-            output = self._fused(key, query.permute(0, 2, 1), value.permute(0, 2, 1), x.dtype)
+        n = h * w
+        rows = self.f_layer(x).reshape(b, -1, n).transpose(1, 2)       # [b, n, c / k]: softmax rows
+        cols = self.g_layer(x).reshape(b, -1, n).transpose(1, 2)       # [b, n, c / k]: softmax columns
+        vals = self.h_layer(x).reshape(b, -1, n).transpose(1, 2)       # [b, n, c]
+        if _opt["fused_attention"] and ops.get_precision() == ops._lib.GC_PREC_BF16 and n % 128 == 0 and c in (64, 128):
+            mixed = ops.attention(rows.bfloat16(), cols.bfloat16(), vals.bfloat16())[0].to(x.dtype)
         else:
-            attention_weights = self.softmax(torch.bmm(key, query))
-            output = torch.bmm(attention_weights, value.permute(0, 2, 1))
-        # the reference reinterprets the [b, positions, c] product as [b, c, h, w] without a transpose
-        output = output.reshape(b, -1, h, w)
-        # gamma * output + x in one pass whose result takes x's (channels-last) layout
-        return torch.addcmul(x, output, _like(self.gamma, output))
-
-    @staticmethod
-    def _fused(key, query, value, out_dtype):
-        """softmax(key query^T) value on the fused kernel; key, query: [b, positions, c / k], value: [b, positions, c].
-        With bf16 channels-last storage the three operands are views of the projections' outputs (no copies)."""
-        o, _ = ops.attention(key.to(torch.bfloat16), query.to(torch.bfloat16), value.to(torch.bfloat16))
-        return o.to(out_dtype)
+            mixed = torch.softmax(rows @ cols.transpose(1, 2), dim=-1) @ vals
+        mixed = mixed.reshape(b, -1, h, w)          # [b, n, c] read as [b, c, h, w], as the reference does
+        return torch.addcmul(x, mixed, self.gamma.to(mixed.dtype))
 
 
 class GeneratorBlock(torch.nn.Module):
-    def __init__(self, input_channels, output_channels, kernel_size=3, stride=1, padding=1, y_dim=148):
+    """norm-relu-upsample-conv3x3-norm-relu-conv3x3 plus a 1x1 shortcut on the up-scaled input."""
+
+    def __init__(self, cin, cout, y_dim=148):
         super().__init__()
-        self.conv_1 = Conv2d(input_channels, output_channels, kernel_size=kernel_size, stride=stride, padding=padding)
-        self.conv_2 = Conv2d(output_channels, output_channels, kernel_size=kernel_size, stride=stride, padding=padding)
-        self.relu_1 = torch.nn.ReLU()
-        self.relu_2 = torch.nn.ReLU()
-        self.upsample = gnn.UpsampleNearest2x()
-        self.batch_norm_1 = BatchNorm(input_channels, y_dim=y_dim)
-        self.batch_norm_2 = BatchNorm(output_channels, y_dim=y_dim)
-        self.residual_conv = Conv2d(input_channels, output_channels, kernel_size=1, stride=1, padding=0)
+        self.conv_1 = Conv2d(cin, cout, 3, padding=1)
+        self.conv_2 = Conv2d(cout, cout, 3, padding=1)
+        self.batch_norm_1 = ConditionalNorm(cin, y_dim)
+        self.batch_norm_2 = ConditionalNorm(cout, y_dim)
+        self.residual_conv = Conv2d(cin, cout, 1)
 
     def forward(self, x, y):
-        output = self.conv_1(self.upsample(self.batch_norm_1(x, y, activation="relu")))     # relu_1 / relu_2 inside the norm
-        output = self.conv_2(self.batch_norm_2(output, y, activation="relu"))
-        return output + self.residual_conv(self.upsample(x))
+        h = self.conv_1(GF.upsample_nearest2x(self.batch_norm_1(x, y)))
+        h = self.conv_2(self.batch_norm_2(h, y))
+        return h + self.residual_conv(GF.upsample_nearest2x(x))
+
+
+class DiscriminatorBlock(torch.nn.Module):
+    """relu-conv3x3-relu-conv3x3(-pool) plus a 1x1 shortcut."""
+
+    def __init__(self, cin, cout, downsample=True):
+        super().__init__()
+        self.conv_1 = Conv2d(cin, cout, 3, padding=1)
+        self.conv_2 = Conv2d(cout, cout, 3, padding=1)
+        self.residual_conv = Conv2d(cin, cout, 1)
+        self.pool = downsample
+
+    def forward(self, x):
+        h = self.conv_2(self.conv_1(torch.relu(x), activation="relu"))
+        if self.pool:
+            return GF.avg_pool2x2(h) + self.residual_conv(GF.avg_pool2x2(x))
+        return h + self.residual_conv(x)
 
 
 class Generator(torch.nn.Module):
     def __init__(self, n_classes=1000, ch=96):
         super().__init__()
         self.linear_y = torch.nn.Embedding(n_classes, 128)
-        self.linear_z = Linear(20, 4 * 4 * ch * 16)
-        self.main_sequence = torch.nn.Sequential(
-            GeneratorBlock(16 * ch, 16 * ch), GeneratorBlock(16 * ch, 8 * ch), GeneratorBlock(8 * ch, 4 * ch),
-            GeneratorBlock(4 * ch, 2 * ch), SelfAttentionBlock(2 * ch), GeneratorBlock(2 * ch, 1 * ch))
-        self.bn = torch.nn.BatchNorm2d(1 * ch)
-        self.to_RGB_layer = Conv2d(1 * ch, 3, kernel_size=1, stride=1)
-        self.tanh = torch.nn.Tanh()
+        self.linear_z = Linear(20, 4 * 4 * 16 * ch)
+        self.main_sequence = torch.nn.ModuleList(
+            SelfAttentionBlock(2 * ch) if spec == "attention" else GeneratorBlock(spec[0] * ch, spec[1] * ch) for spec in GENERATOR_PLAN)
+        self.bn = torch.nn.BatchNorm2d(ch)
+        self.to_RGB_layer = Conv2d(ch, 3, 1)
 
     def forward(self, latent_vector, y):
-        latent_vectors = torch.split(latent_vector, 20, dim=1)
-        y_embedding = self.linear_y(y)
-        output = self.linear_z(latent_vectors[0]).view(latent_vector.shape[0], -1, 4, 4)
-        if _act_dtype is not None:
-            output = output.to(_act_dtype)
-        index = 1
-        for layer in self.main_sequence:
-            if isinstance(layer, GeneratorBlock):
-                output = layer(output, torch.cat((latent_vectors[index], y_embedding), dim=1))
-                index += 1
+        chunks = latent_vector.split(20, dim=1)            # the first feeds the 4x4 seed, one more per residual block
+        klass = self.linear_y(y)
+        h = self.linear_z(chunks[0]).reshape(latent_vector.shape[0], -1, 4, 4)
+        if _opt["dtype"] is not None:
+            h = h.to(_opt["dtype"])
+        used = 1
+        for block in self.main_sequence:
+            if isinstance(block, GeneratorBlock):
+                h = block(h, torch.cat((chunks[used], klass), dim=1))
+                used += 1
             else:
-                output = layer(output)
-        if _fused_norm and self.bn.training and output.shape[1] % 4 == 0:
-            output = _fused_bn(self.bn, output, self.bn.weight, self.bn.bias, "relu")
-        else:
-            output = torch.nn.functional.relu(self.bn(output))
-        return self.tanh(self.to_RGB_layer(output, out_dtype=torch.float32))
-
-
-class DiscriminatorBlock(torch.nn.Module):
-    def __init__(self, input_channels, output_channels, kernel_size=3, stride=1, padding=1, downsample=True):
-        super().__init__()
-        self.conv_1 = Conv2d(input_channels, output_channels, kernel_size=kernel_size, stride=stride, padding=padding)
-        self.conv_2 = Conv2d(output_channels, output_channels, kernel_size=kernel_size, stride=stride, padding=padding)
-        self.relu_1 = torch.nn.ReLU()
-        self.relu_2 = torch.nn.ReLU()
-        self.downsample = gnn.AvgPool2x2() if downsample else torch.nn.Identity()
-        self.residual_conv = Conv2d(input_channels, output_channels, kernel_size=1, stride=1)
-
-    def forward(self, x):
-        output = self.downsample(self.conv_2(self.conv_1(self.relu_1(x), activation="relu")))    # relu_2 in conv_1's epilogue
-        return output + self.residual_conv(self.downsample(x))     # = downsample(residual_conv(x)): both are linear, the
-        #                                                            1x1 convolution then runs on a quarter of the pixels
+                h = block(h)
+        h = _batchnorm_relu(self.bn, h, self.bn.weight, self.bn.bias)
+        return torch.tanh(self.to_RGB_layer(h, out_dtype=torch.float32))
 
 
 class Discriminator(torch.nn.Module):
     def __init__(self, n_classes=1000, ch=64, image_dim=3):
         super().__init__()
-        self.main_sequence = torch.nn.Sequential(
-            DiscriminatorBlock(image_dim, 1 * ch), SelfAttentionBlock(1 * ch), DiscriminatorBlock(1 * ch, 2 * ch),
-            DiscriminatorBlock(2 * ch, 4 * ch), DiscriminatorBlock(4 * ch, 8 * ch), DiscriminatorBlock(8 * ch, 16 * ch),
-            DiscriminatorBlock(16 * ch, 16 * ch, downsample=False))
-        self.relu = torch.nn.ReLU()
-        self.embedding_layer = torch.nn.Embedding(n_classes, 16 * ch)
+        blocks = []
+        for spec in CRITIC_PLAN:
+            if spec == "attention":
+                blocks.append(SelfAttentionBlock(ch))
+            else:
+                blocks.append(DiscriminatorBlock(image_dim if spec[0] is None else spec[0] * ch, spec[1] * ch, spec[2]))
+        self.main_sequence = torch.nn.ModuleList(blocks)
+        self.embedding_layer = torch.nn.Embedding(n_classes, 16 * ch)      # (not spectrally normalised)
         self.projection_layer = Linear(16 * ch, 1)
 
     def forward(self, x, y):
-        h = torch.sum(self.relu(self.main_sequence(x)).float(), dim=[2, 3])
-        output = self.projection_layer(h)
-        y_embedding = self.embedding_layer(y)
-        return output + torch.sum(y_embedding * output, dim=1).unsqueeze(1)
+        h = x
+        for block in self.main_sequence:
+            h = block(h)
+        pooled = torch.relu(h).float().sum(dim=(2, 3))
+        score = self.projection_layer(pooled)                                # [B, 1]
+        return score + (self.embedding_layer(y) * score).sum(dim=1, keepdim=True)
 
 
+# ---- training phases -----------------------------------------------------------------------------------------------------
 def requires_grad(model, flag=True):
     for p in model.parameters():
-        p.requires_grad = flag
+        p.requires_grad_(flag)
 
 
 def orthogonal_init(model):
-    """BigGAN/train.py:108-112."""
-    for module in model.modules():
-        if isinstance(module, (torch.nn.Conv2d, torch.nn.Linear, torch.nn.Embedding)):
-            torch.nn.init.orthogonal_(module.weight)
+    """BigGAN/train.py:108-112: orthogonal weights for every convolution, Linear layer and embedding, in module order."""
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear, torch.nn.Embedding)):
+            torch.nn.init.orthogonal_(m.weight)
 
 
-def orthogonal_regularization(module, beta=1e-4):
-    """BigGAN/train.py:115-127: adds beta * 2 (W W^T * (1 - I)) W to the gradient of every parameter with > 2 dims."""
-    with torch.no_grad():
-        for parameter in module.parameters():
-            if len(parameter.shape) > 2 and parameter.grad is not None:
-                weight = parameter.view(parameter.shape[0], -1)
-                eye = torch.eye(weight.shape[0], device=weight.device)
-                gradient = 2 * torch.mm(torch.mm(weight, weight.t()) * (1. - eye), weight)
-                parameter.grad.data += beta * gradient.view(parameter.shape)
+@torch.no_grad()
+def orthogonal_regularization(model, beta=1e-4):
+    """BigGAN/train.py:115-127: grad += beta * 2 (W W^T with its diagonal removed) W for every weight with more than two
+    dimensions, W flattened to [out, rest]."""
+    for p in model.parameters():
+        if p.dim() > 2 and p.grad is not None:
+            w = p.flatten(1)
+            gram = w @ w.t()
+            gram.fill_diagonal_(0.0)
+            p.grad.add_((gram @ w).view_as(p), alpha=2.0 * beta)
 
 
 def discriminator_phase(net_G, net_D, real, real_label, z, fake_label, orth_reg=True, on_last_backward=None):
-    """Hinge loss, generator frozen (BigGAN/train.py:187-199); two backward passes."""
-    relu = torch.nn.functional.relu
+    """Hinge loss with the generator frozen (BigGAN/train.py:187-199): one backward pass for the real batch, one for the
+    generated batch.  Returns the two loss terms, detached."""
     requires_grad(net_G, False)
     requires_grad(net_D, True)
-    d_x = relu(1.0 - net_D(real, real_label).view(-1)).mean()
-    d_x.backward()
-    fake = net_G(z, fake_label)
-    d_g_z1 = relu(1.0 + net_D(fake.detach(), fake_label).view(-1)).mean()
+    loss_real = torch.relu(1.0 - net_D(real, real_label)).mean()
+    loss_real.backward()
+    fake = net_G(z, fake_label).detach()
+    loss_fake = torch.relu(1.0 + net_D(fake, fake_label)).mean()
     if on_last_backward is not None:
         on_last_backward()
-    d_g_z1.backward()
+    loss_fake.backward()
     if orth_reg:
         orthogonal_regularization(net_D)
-    return d_x.detach(), d_g_z1.detach()
+    return loss_real.detach(), loss_fake.detach()
 
 
 def generator_phase(net_G, net_D, z, fake_label, orth_reg=True, on_last_backward=None):
-    """BigGAN/train.py:206-217: discriminator frozen."""
+    """BigGAN/train.py:206-217: discriminator frozen, loss -mean D(G(z))."""
     requires_grad(net_G, True)
     requires_grad(net_D, False)
-    g_error = -net_D(net_G(z, fake_label), fake_label).view(-1).mean()
+    loss = net_D(net_G(z, fake_label), fake_label).mean().neg()
     if on_last_backward is not None:
         on_last_backward()
-    g_error.backward()
+    loss.backward()
     if orth_reg:
         orthogonal_regularization(net_G)
     requires_grad(net_G, False)
     requires_grad(net_D, True)
-    return g_error.detach()
+    return loss.detach()

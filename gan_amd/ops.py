@@ -555,8 +555,52 @@ torch.library.register_autograd("ganconv::channel_sum", _channel_sum_backward, s
 
 
 # ---- autograd: each formula uses only the three ops above -------------------------------------------------------
+def _edges(*ts):
+    """The autograd node each tensor's gradient is handed to (None for a leaf or a tensor that takes no gradient)."""
+    return tuple(t.grad_fn if (t is not None and t.requires_grad) else None for t in ts)
+
+
+_inputs_only = False
+
+
+class input_gradients_only:
+    """While active, the convolution backward formulas compute gradients with respect to activations only (weights and
+    biases get None).  For a backward pass that is restricted to a network's input, such as the first pass of a gradient
+    penalty: torch.autograd.grad(scores, images, create_graph=True) runs every node on the way, and needs_input_grad,
+    fixed when the forward pass ran, still asks each of them for its weight gradient, a fifth of a critic iteration's
+    kernel time that nothing reads.  Process-wide, not per thread: the formulas run on the autograd engine's own thread
+    while the caller waits inside torch.autograd.grad."""
+
+    def __enter__(self):
+        global _inputs_only
+        self.prev, _inputs_only = _inputs_only, True
+        return self
+
+    def __exit__(self, *exc):
+        global _inputs_only
+        _inputs_only = self.prev
+        return False
+
+
+def _wanted(ctx, i):
+    """Whether the running backward pass uses the gradient of input i (0: the activation operand, 1: the weight, 2: the
+    bias).  Beyond needs_input_grad: nothing for parameters inside input_gradients_only, and for an interior tensor the
+    engine's own answer (torch.autograd.grad(..., inputs=[...]) executes only the nodes that lead to those inputs; the
+    engine does not answer for leaves)."""
+    if not ctx.needs_input_grad[i] or (_inputs_only and i > 0):
+        return False
+    node = ctx.edges[i]
+    if node is None:
+        return True
+    try:
+        return torch._C._will_engine_execute_node(node)
+    except RuntimeError:          # no information
+        return True
+
+
 def _fprop_setup(ctx, inputs, output):
     x, w, bias, stride, padding, precision, wkey, act, slope, _, alpha = inputs
+    ctx.edges = _edges(x, w, bias)
     if act != 0:
         ctx.save_for_backward(x, w, output)
     else:
@@ -566,28 +610,29 @@ def _fprop_setup(ctx, inputs, output):
 
 def _fprop_backward(ctx, gy):
     stride, padding, precision, wkey, has_bias, act, slope, alpha = ctx.cfg
+    need_x, need_w, need_b = _wanted(ctx, 0), _wanted(ctx, 1), has_bias and _wanted(ctx, 2)
     gb = None
     if act != 0:
         x, w, y = ctx.saved_tensors
-        if has_bias and ctx.needs_input_grad[2] and _act_sum_fusable(gy, y):
+        if need_b and _act_sum_fusable(gy, y):
             gy, gb = act_backward_sum(gy, y, act, slope)
         else:
             gy = _act_backward(gy, y, act, slope)
     else:
         x, w = ctx.saved_tensors
     gx = gw = None
-    if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and gy.is_cuda:
+    if _overlap and need_x and need_w and gy.is_cuda:
         with _SideLaunch(gy.device) as side:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
         gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
         side.join()
         gw = gw.to(w.dtype)
     else:
-        if ctx.needs_input_grad[0]:
+        if need_x:
             gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
-        if ctx.needs_input_grad[1]:
+        if need_w:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
-    if has_bias and ctx.needs_input_grad[2] and gb is None:
+    if need_b and gb is None:
         gb = channel_sum(gy)
     return gx, gw, gb, None, None, None, None, None, None, None, None
 
@@ -597,6 +642,7 @@ torch.library.register_autograd("ganconv::conv_fprop", _fprop_backward, setup_co
 
 def _dgrad_setup(ctx, inputs, output):
     gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, _, alpha = inputs
+    ctx.edges = _edges(gy, w, bias)
     if act != 0:
         ctx.save_for_backward(gy, w, output)
     else:
@@ -606,28 +652,29 @@ def _dgrad_setup(ctx, inputs, output):
 
 def _dgrad_backward(ctx, u):
     stride, padding, precision, wkey, has_bias, act, slope, alpha = ctx.cfg
+    need_gy, need_w, need_b = _wanted(ctx, 0), _wanted(ctx, 1), has_bias and _wanted(ctx, 2)
     g_b = None
     if act != 0:
         gy, w, out = ctx.saved_tensors
-        if has_bias and ctx.needs_input_grad[2] and _act_sum_fusable(u, out):
+        if need_b and _act_sum_fusable(u, out):
             u, g_b = act_backward_sum(u, out, act, slope)
         else:
             u = _act_backward(u, out, act, slope)
     else:
         gy, w = ctx.saved_tensors
     g_gy = g_w = None
-    if _overlap and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and u.is_cuda:
+    if _overlap and need_gy and need_w and u.is_cuda:
         with _SideLaunch(u.device) as side:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
         g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
         side.join()
         g_w = g_w.to(w.dtype)
     else:
-        if ctx.needs_input_grad[0]:
+        if need_gy:
             g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
-        if ctx.needs_input_grad[1]:
+        if need_w:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
-    if has_bias and ctx.needs_input_grad[2] and g_b is None:
+    if need_b and g_b is None:
         g_b = channel_sum(u)
     return g_gy, g_w, g_b, None, None, None, None, None, None, None, None, None, None
 
@@ -637,6 +684,7 @@ torch.library.register_autograd("ganconv::conv_dgrad", _dgrad_backward, setup_co
 
 def _wgrad_setup(ctx, inputs, output):
     x, gy, kh, kw, stride, padding, precision, alpha = inputs
+    ctx.edges = _edges(x, gy)
     ctx.save_for_backward(x, gy)
     ctx.cfg = (stride, padding, precision, alpha)
 
@@ -645,9 +693,9 @@ def _wgrad_backward(ctx, v):
     x, gy = ctx.saved_tensors
     stride, padding, precision, alpha = ctx.cfg
     g_x = g_gy = None
-    if ctx.needs_input_grad[0]:
+    if _wanted(ctx, 0):
         g_x = conv_dgrad(gy, v, None, x.shape[2], x.shape[3], stride, padding, precision, 0, 0, 0.0, _code_of(x.dtype), alpha)
-    if ctx.needs_input_grad[1]:
+    if _wanted(ctx, 1):
         g_gy = conv_fprop(x, v, None, stride, padding, precision, 0, 0, 0.0, _code_of(gy.dtype), alpha)
     return g_x, g_gy, None, None, None, None, None, None
 
@@ -1194,3 +1242,113 @@ def _adain_backward(ctx, gout, g_mu, g_r):
 
 
 torch.library.register_autograd("ganconv::noise_lrelu_adain", _adain_backward, setup_context=_adain_setup)
+
+
+# ---- the scalar parts of a WGAN-GP critic iteration (BasicGANs/loss_functions.py:7-27) ---------------------------
+def _same_layout(*ts):
+    a = ts[0]
+    return all(t.shape == a.shape and t.stride() == a.stride() and t.dtype == a.dtype for t in ts)
+
+
+def _dense(t):
+    """t if its elements fill its storage range without gaps in some dimension order, else a contiguous copy."""
+    return t if (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)) else t.contiguous()
+
+
+@torch.library.custom_op("ganconv::wgan_mix", mutates_args=())
+def wgan_mix(real: Tensor, fake: Tensor, eps: Tensor) -> Tensor:
+    """real * eps + fake * (1 - eps), eps one value per sample, in one launch.  The result is a fresh tensor that takes no
+    gradient from its operands (the reference mixes `.data`); mark it requires_grad to differentiate a critic by it."""
+    _check_cuda(real, fake, eps)
+    real, fake = _dense(real.float()), fake.float()
+    if not _same_layout(real, fake):
+        fake = fake.contiguous(memory_format=torch.channels_last if real.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format)
+        if not _same_layout(real, fake):
+            real = real.contiguous()
+            fake = fake.contiguous()
+    N = real.shape[0]
+    if eps.numel() != N:
+        raise RuntimeError(f"ganconv: eps must hold one value per sample ({N}), got {tuple(eps.shape)}")
+    e = eps.detach().reshape(N).float().contiguous()
+    out = torch.empty_like(real)
+    _lib.check(_lib.lib().gc_wgan_mix(_ptr(real), _ptr(fake), _ptr(e), _ptr(out), N, real.numel() // N, _stream()), "gc_wgan_mix")
+    return out
+
+
+@wgan_mix.register_fake
+def _(real, fake, eps):
+    return torch.empty_like(real, dtype=torch.float32)
+
+
+@torch.library.custom_op("ganconv::gradient_penalty", mutates_args=())
+def gradient_penalty(gradient: Tensor, c_lambda: float) -> tuple[Tensor, Tensor, Tensor]:
+    """(c_lambda * mean_n (||gradient_n||_2 - 1)^2 as a 0-dim tensor, the per-sample norms, the per-sample factor of
+    gradient_n in the penalty's derivative).  Only the first output is differentiable."""
+    _check_cuda(gradient)
+    g = _dense(gradient)
+    N = g.shape[0]
+    per = g.numel() // N
+    L = _lib.lib()
+    penalty = torch.empty((), dtype=torch.float32, device=g.device)
+    norms = torch.empty(N, dtype=torch.float32, device=g.device)
+    coef = torch.empty(N, dtype=torch.float32, device=g.device)
+    nws = L.gc_gradient_penalty_workspace_bytes(N, per)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=g.device)
+    _lib.check(L.gc_gradient_penalty_fwd(_ptr(g), _dtype_code(g), N, per, float(c_lambda), _ptr(norms), _ptr(coef), _ptr(penalty),
+                                         _ptr(ws), ws.numel(), _stream()), "gc_gradient_penalty_fwd")
+    return penalty, norms, coef
+
+
+@gradient_penalty.register_fake
+def _(gradient, c_lambda):
+    N = gradient.shape[0]
+    return gradient.new_empty((), dtype=torch.float32), gradient.new_empty(N, dtype=torch.float32), gradient.new_empty(N, dtype=torch.float32)
+
+
+@torch.library.custom_op("ganconv::gradient_penalty_bwd", mutates_args=())
+def gradient_penalty_bwd(gradient: Tensor, coef: Tensor, g_penalty: Tensor) -> Tensor:
+    """g_penalty * coef[n] * gradient_n, in gradient's layout and dtype."""
+    _check_cuda(gradient, coef, g_penalty)
+    g = _dense(gradient)
+    N = g.shape[0]
+    out = torch.empty_like(g)
+    _lib.check(_lib.lib().gc_gradient_penalty_bwd(_ptr(g), _dtype_code(g), N, g.numel() // N, _ptr(coef.contiguous()),
+                                                  _ptr(g_penalty.float().reshape(1)), _ptr(out), _stream()), "gc_gradient_penalty_bwd")
+    return out
+
+
+@gradient_penalty_bwd.register_fake
+def _(gradient, coef, g_penalty):
+    return torch.empty_like(gradient)
+
+
+def _gp_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], output[2])
+
+
+def _gp_backward(ctx, g_penalty, g_norms, g_coef):
+    gradient, coef = ctx.saved_tensors
+    return gradient_penalty_bwd(gradient, coef, g_penalty), None
+
+
+torch.library.register_autograd("ganconv::gradient_penalty", _gp_backward, setup_context=_gp_setup)
+
+
+@torch.library.custom_op("ganconv::wgan_critic_loss", mutates_args=())
+def wgan_critic_loss(scores: Tensor, drift: float) -> tuple[Tensor, Tensor]:
+    """scores: the critic's outputs for B real samples followed by B generated ones.  Returns ([mean(real) - drift *
+    mean(real^2), mean(generated)], the gradient of (second - first) with respect to the scores): what the two backward
+    passes of BasicGANs/loss_functions.py:7-15 start from.  Not differentiable itself."""
+    _check_cuda(scores)
+    s = scores.detach().reshape(-1).float().contiguous()
+    if s.numel() % 2:
+        raise RuntimeError("ganconv: wgan_critic_loss expects B real scores followed by B generated scores")
+    out = torch.empty(2, dtype=torch.float32, device=s.device)
+    grad = torch.empty_like(s)
+    _lib.check(_lib.lib().gc_wgan_critic_loss(_ptr(s), s.numel() // 2, float(drift), _ptr(out), _ptr(grad), _stream()), "gc_wgan_critic_loss")
+    return out, grad.view(scores.shape)
+
+
+@wgan_critic_loss.register_fake
+def _(scores, drift):
+    return scores.new_empty(2, dtype=torch.float32), torch.empty_like(scores, dtype=torch.float32)

@@ -293,6 +293,26 @@ int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32_t H, int32
 int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream);
 int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream);
 
+/* The scalar parts of a WGAN-GP critic iteration, each one or two launches; they replace the chains of elementwise and
+ * reduction tensor operations behind BasicGANs/loss_functions.py:7-27.  fp32 unless `dtype` says otherwise; tensors of
+ * N samples with `per_sample` (a multiple of 4) contiguous-or-NHWC elements each, 16-byte aligned, any element order
+ * (the operations are order-free within a sample as long as all tensors of a call share it).
+ *   gc_wgan_mix              out = real * eps[n] + fake * (1 - eps[n])   (:19; two rounded products and a rounded sum)
+ *   gc_gradient_penalty_fwd  norms[n] = ||gradient_n||_2, penalty[0] = lambda * mean_n (norms[n] - 1)^2   (:26-27), and
+ *                            coef[n] = lambda * 2 (norms[n] - 1) / (N norms[n]) (0 where the norm is 0), the factor of
+ *                            gradient_n in d penalty / d gradient; workspace: gc_gradient_penalty_workspace_bytes
+ *   gc_gradient_penalty_bwd  out = g_penalty[0] * coef[n] * gradient_n (same dtype as gradient)
+ *   gc_wgan_critic_loss      scores: B real-batch scores then B generated-batch scores.  out[0] = mean(real) - drift *
+ *                            mean(real^2) (:7-8, drift 0.001), out[1] = mean(generated) (:13-14), grad [2B] = gradient of
+ *                            (out[1] - out[0]) with respect to the scores, i.e. of the two backward passes :9 and :15 */
+int gc_wgan_mix(const float* real, const float* fake, const float* eps, float* out, int32_t N, int64_t per_sample, void* stream);
+size_t gc_gradient_penalty_workspace_bytes(int32_t N, int64_t per_sample);
+int gc_gradient_penalty_fwd(const void* gradient, int32_t dtype, int32_t N, int64_t per_sample, float lambda, float* norms, float* coef,
+                            float* penalty, void* workspace, size_t workspace_bytes, void* stream);
+int gc_gradient_penalty_bwd(const void* gradient, int32_t dtype, int32_t N, int64_t per_sample, const float* coef, const float* g_penalty,
+                            void* out, void* stream);
+int gc_wgan_critic_loss(const float* scores, int32_t B, float drift, float* out, float* grad, void* stream);
+
 /* Self-attention over image positions without the [N, N] weight matrix in memory: out = softmax(k q^T) v per sample,
  * softmax over the last index, unit scale.  Replaces the bmm + Softmax + bmm of SelfAttentionBlock.forward
  * (BigGAN/model.py:97-103; the reference calls the [B, N, C / 8] operand of the first bmm "key" and the other

@@ -545,6 +545,83 @@ def test_double_backward_closure_against_torch_cpu(gan):
         assert rel(a, b) < TOL_X3
 
 
+@pytest.mark.parametrize("shape,channels_last", [((256, 3, 64, 64), True), ((5, 3, 8, 4), False), ((3, 8, 6, 6), True)])
+def test_wgan_scalar_kernels_against_torch_expressions(gan, shape, channels_last):
+    """The fused interpolation, gradient-penalty and critic-loss kernels against the tensor expressions of
+    BasicGANs/loss_functions.py:7-27 (fp32; sums differ by summation order only)."""
+    torch.manual_seed(3)
+    mf = torch.channels_last if channels_last else torch.contiguous_format
+    real = torch.randn(shape, device="cuda").contiguous(memory_format=mf)
+    fake = torch.randn(shape, device="cuda").contiguous(memory_format=mf)
+    eps = torch.rand(shape[0], 1, 1, 1, device="cuda")
+    mixed = gan.ops.wgan_mix(real, fake, eps)
+    assert torch.equal(mixed, real * eps + fake * (1 - eps)) and not mixed.requires_grad
+    assert mixed.stride() == real.stride()
+
+    for dt, tol in ((torch.float32, 2e-6), (torch.bfloat16, 1e-2)):
+        g = (torch.randn(shape, device="cuda") * 0.05).to(dt).contiguous(memory_format=mf)
+        g[1] = 0                                              # a zero gradient: norm 0, subgradient 0
+        g_ref = g.detach().float().clone().requires_grad_(True)
+        want = 10.0 * ((g_ref.reshape(shape[0], -1).norm(2, dim=1) - 1) ** 2).mean()
+        (3.0 * want).backward()
+        g_in = g.clone().requires_grad_(True)
+        pen, norms, coef = gan.ops.gradient_penalty(g_in, 10.0)
+        (3.0 * pen).backward()
+        assert abs(pen.item() - want.item()) <= 2e-6 * abs(want.item())
+        assert torch.allclose(norms, g_ref.detach().reshape(shape[0], -1).norm(2, dim=1), rtol=2e-6, atol=0)
+        assert g_in.grad.dtype == dt and g_in.grad.stride() == g.stride()
+        assert rel(g_in.grad.float(), g_ref.grad) < tol and torch.count_nonzero(g_in.grad[1]) == 0
+
+    B = shape[0]
+    scores = torch.randn(2 * B, 1, 1, 1, device="cuda", requires_grad=True)
+    d_real = scores.view(-1)[:B].mean() - 0.001 * (scores.view(-1)[:B] ** 2).mean()
+    d_fake = scores.view(-1)[B:].mean()
+    (d_fake - d_real).backward()
+    stats, seed = gan.ops.wgan_critic_loss(scores.detach(), 0.001)
+    assert torch.allclose(stats, torch.stack([d_real, d_fake]).detach(), rtol=1e-5, atol=1e-7)
+    assert seed.shape == scores.shape and torch.allclose(seed, scores.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_unwanted_weight_gradients_are_skipped_not_changed(gan):
+    """A backward pass restricted to the critic's input (the first pass of the gradient penalty) launches no weight-gradient
+    kernel, and every gradient that is asked for is the one an unrestricted pass computes."""
+    torch.manual_seed(4)
+    conv1 = gan.nn.Conv2d(8, 16, 4, 2, 1, bias=True, activation="leaky_relu").cuda()
+    conv2 = gan.nn.ConvTranspose2d(16, 8, 4, 2, 1, bias=False).cuda()
+    x = torch.randn(4, 8, 16, 16, device="cuda", requires_grad=True)
+
+    def run(inputs):
+        y = conv2(conv1(x))
+        gan._lib.profile_enable(True)
+        try:
+            grads = torch.autograd.grad((y ** 2).sum(), inputs)
+            torch.cuda.synchronize()
+            prof = gan._lib.profile_collect()
+        finally:
+            gan._lib.profile_enable(False)
+        return grads, sum(v["launches"] for k, v in prof.items() if "wgrad" in k)
+
+    params = [conv1.weight, conv1.bias, conv2.weight]
+    with gan.ops.input_gradients_only():
+        (gx_only,), n_wgrad = run([x])
+    assert n_wgrad == 0
+    full, n_wgrad_full = run([x] + params)
+    assert n_wgrad_full > 0 and torch.equal(gx_only, full[0])
+    (gw1,), _ = run([conv1.weight])
+    assert torch.equal(gw1, full[1])
+    # second order: the penalty pass asks for the parameters only
+    y = conv2(conv1(x))
+    with gan.ops.input_gradients_only():
+        g = torch.autograd.grad(y.sum(), x, create_graph=True)[0]
+    second = torch.autograd.grad((g ** 2).sum(), params)
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = conv2(conv1(x2))
+    g2 = torch.autograd.grad(y2.sum(), x2, create_graph=True)[0]
+    (g2 ** 2).sum().backward()
+    for a, p_ in zip(second, params):
+        assert torch.equal(a, p_.grad)
+
+
 def test_full_size_properties(gan):
     """Benchmark-size layers (WGAN-GP-64 at batch 256), checked through properties that need no oracle run:
     adjointness <conv(x), gy> = <x, dgrad(gy)> = <w, wgrad(x, gy)> and linearity in x."""

@@ -1,0 +1,48 @@
+"""Lists, in launch order, every device kernel of one eager critic iteration and one generator iteration of the
+benchmark's WGAN-GP cycle (one stream), with the aten / ganconv op that launched it and its input shapes: the map
+used to find framework glue between the library's kernels."""
+import os
+import sys
+
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gan_amd  # noqa: E402
+from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs  # noqa: E402
+
+gan_amd.set_precision("bf16")
+tr = WganGpTrainer(256, 64, 100, 64, device="cuda:0", batch_real_fake=True, fused_adam=True, activation_dtype=torch.bfloat16,
+                   two_streams=False)
+tr.reps = int(os.environ.get("REPS", "1"))
+gen = torch.Generator().manual_seed(5001)
+real, zs = synth_inputs(gen, 256, 100, 64, 6)
+tr.set_inputs(real, zs, torch.rand(5, 256, 1, 1, 1, generator=gen))
+for _ in range(2):
+    tr.cycle_eager()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    tr.cycle_eager()
+    torch.cuda.synchronize()
+evs = prof.events()
+kernels = [e for e in evs if e.device_type == torch.autograd.DeviceType.CUDA]
+cpu = [e for e in evs if e.device_type == torch.autograd.DeviceType.CPU]
+# launching op of a kernel: the innermost CPU op whose time range contains the kernel's launch (linked by correlation id)
+by_corr = {}
+for e in cpu:
+    for k in getattr(e, "kernels", []) or []:
+        by_corr.setdefault(k.name + str(k.duration), e)
+tot = {}
+for e in cpu:
+    if not e.kernels:
+        continue
+    for k in e.kernels:
+        shapes = str(e.input_shapes)[:90] if e.input_shapes else ""
+        print(f"{k.duration:8.1f} us  {k.name[:70]:70s} <- {e.name[:40]:40s} {shapes}")
+        key = k.name[:90]
+        t = tot.setdefault(key, [0, 0.0])
+        t[0] += 1
+        t[1] += k.duration
+print("---- totals")
+for k, (n, d) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+    print(f"{d:9.1f} us {n:4d}  {k}")
