@@ -506,7 +506,7 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
 #define WS_CASE(TO_, ST_)                                                                                       \
   if (l.to == TO_ && stages == ST_)                                                                             \
     return out_f32 ? launch_one<float, TO_, ST_>(p, grid, l.flops, stream) : launch_one<uint16_t, TO_, ST_>(p, grid, l.flops, stream);
-  WS_CASE(64, 2) WS_CASE(64, 3) WS_CASE(128, 2) WS_CASE(128, 3)
+  WS_CASE(64, 2) WS_CASE(64, 3) WS_CASE(64, 4) WS_CASE(128, 2) WS_CASE(128, 3) WS_CASE(128, 4)
 #undef WS_CASE
   set_error("internal: no wave-specialised variant for this tile");
   return GC_UNSUPPORTED_GEOMETRY;

@@ -93,6 +93,15 @@ def _side_stream(device, i):
 # Which scalar parts of a critic iteration run as single launches of the library on a GPU (the others, and everything
 # on the CPU, as the reference's tensor expressions; narrowing the set is an A/B aid).
 fused_scalars = {"mix", "ones", "penalty", "loss"}
+# The streamed critic iteration collects weight gradients through gan_amd.ops.weight_gradient_sink (those of the penalty
+# chain on a stream of their own); False: autograd returns and accumulates them (A/B aid).
+weight_gradient_sink = True
+# Measured on the recorded benchmark cycle (tools/ab_bench.py --what flag): the sink itself is neutral (10.36 against
+# 10.44 ms); the penalty chain's weight-gradient kernels on a stream of their own cost 0.4 ms (a fork and an event wait
+# per launch inside the graph outweigh the overlap), so both switches below are off.
+side_chains_first = True            # launch (and record) the forked chains before the calling stream's own chain
+sink_fork = False                   # the penalty chain's weight-gradient kernels on a stream of their own
+penalty_on_calling_stream = False   # True: the penalty chain on the calling stream (needed for sink_fork), the others fork
 _ones = {}
 
 
@@ -148,9 +157,27 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
     main = torch.cuda.current_stream(real.device)
     B = real.shape[0]
 
+    def grads_of(out, seed, fork):
+        """d out / d params with the weight-gradient kernels writing into fresh buffers through a sink (`fork`: on a stream
+        of their own beside the calling one), or through autograd's own accumulation when the sink is switched off."""
+        if not weight_gradient_sink:
+            return torch.autograd.grad(out, params, grad_outputs=seed)
+        bufs = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params]
+        with gops.weight_gradient_sink(params, bufs, fork=fork) as sink:
+            rest = torch.autograd.grad(out, params, grad_outputs=seed, allow_unused=True)
+        grads = []
+        for p, b, r in zip(params, bufs, rest):
+            if p.data_ptr() in sink.touched:
+                grads.append(b if r is None else b.add_(r))
+            elif r is None:
+                raise RuntimeError("a critic parameter received no gradient")
+            else:
+                grads.append(r)
+        return grads
+
     def penalty_chain():
         penalty = _penalty(net_D, real, fake, epsilon, c_lambda)
-        return torch.autograd.grad(penalty, params), penalty.detach()
+        return grads_of(penalty, None, sink_fork and penalty_on_calling_stream), penalty.detach()
 
     def real_chain():
         d_real = net_D(real).view(-1)
@@ -163,21 +190,40 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
 
     def both_chain():
         d_real, d_fake, out, seed = _real_fake_loss(net_D(torch.cat([real, fake])), B)
-        return torch.autograd.grad(out, params, grad_outputs=seed), (d_real, d_fake)
+        return grads_of(out, seed, False), (d_real, d_fake)
 
-    side_chains = [penalty_chain, fake_chain] if split_real_fake else [penalty_chain]
+    # Only a chain on the calling stream can fork its weight-gradient kernels to a stream of their own: a chain that is
+    # itself on a forked stream cannot fork again inside a graph capture.
+    rf_chains = [real_chain, fake_chain] if split_real_fake else [both_chain]
+    side_chains = rf_chains if penalty_on_calling_stream else [penalty_chain] + rf_chains[1:]
     results = []
-    with gops.suspended_backward_overlap():
-        for i, chain in enumerate(side_chains):
-            st = _side_stream(real.device, i)
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                results.append(chain())
-        if split_real_fake:
-            g_main, d_real = real_chain()
-            d_fake = results[1][1]
-        else:
-            g_main, (d_real, d_fake) = both_chain()
+    fork = torch.cuda.Event()
+    fork.record(main)
+
+    def run_side_chains():
+        with gops.suspended_backward_overlap():
+            for i, chain in enumerate(side_chains):
+                st = _side_stream(real.device, i)
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    results.append(chain())
+
+    if side_chains_first:
+        run_side_chains()
+    if penalty_on_calling_stream:
+        head = penalty_chain()
+    else:
+        with gops.suspended_backward_overlap():
+            head = rf_chains[0]()
+    if not side_chains_first:
+        run_side_chains()
+    results.insert(0 if penalty_on_calling_stream else 1, head)
+    # results: penalty chain, then the real (+ fake) chain, then the fake chain if it is separate
+    g_main, penalty = results.pop(0)
+    if split_real_fake:
+        d_real, d_fake = results[0][1], results[1][1]
+    else:
+        d_real, d_fake = results[0][1]
     for i in range(len(side_chains)):      # (each fork waits for the main stream again, so a side stream does not reuse
         main.wait_stream(_side_stream(real.device, i))          # its blocks before the additions below have run)
     g_main = list(g_main)
@@ -191,7 +237,7 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         torch._foreach_add_([p.grad for p in params], g_main)
-    return d_real, d_fake, results[0][1]
+    return d_real, d_fake, penalty
 
 
 def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_backward=None, batch_real_fake=False,

@@ -172,6 +172,74 @@ class _SideLaunch:
         self.keep.clear()
 
 
+class weight_gradient_sink:
+    """Context: the convolution backward formulas hand the weight gradients of the given parameters to this object
+    instead of returning them to autograd (which receives None for them: call torch.autograd.grad with allow_unused=True,
+    or read the buffers instead of .grad).  Each weight-gradient kernel writes into (first contribution) or adds to (later
+    ones, e.g. the two a double backward produces per weight) the parameter's buffer, so autograd's own accumulation
+    kernels disappear; with `fork=True` all of them run on one stream beside the calling one, in launch order, and the
+    calling stream waits for them only when the context closes.  The data-gradient chain of a backward pass, the part
+    with the dependencies, then never queues behind a weight-gradient kernel.
+
+    Buffers are written, never read, before their first contribution: they need no zeroing.  `touched` tells afterwards
+    which buffers received one.  Not for passes that record a graph for further differentiation (create_graph=True):
+    those take the ordinary path.  Process-wide like the other switches: one sink at a time."""
+    active = None
+
+    def __init__(self, params, buffers, fork=False):
+        self.buffers = {p.data_ptr(): (p, b) for p, b in zip(params, buffers)}
+        self.touched = set()
+        self.fork = fork
+        self.keep = []
+        self.forked = False
+
+    def __enter__(self):
+        if weight_gradient_sink.active is not None:
+            raise RuntimeError("ganconv: a weight_gradient_sink is already active")
+        dev = next(iter(self.buffers.values()))[1].device if self.buffers else None
+        self.main = torch.cuda.current_stream(dev)
+        self.side = None
+        if self.fork and dev is not None:
+            # under a capture, fork only from the stream the capture started on
+            if not (torch.cuda.is_current_stream_capturing() and _capture_origin[0] != self.main.cuda_stream):
+                with _lock:
+                    self.side = _sink_streams.get(dev)
+                    if self.side is None:
+                        self.side = _sink_streams[dev] = torch.cuda.Stream(dev)
+        weight_gradient_sink.active = self
+        return self
+
+    def __exit__(self, *exc):
+        weight_gradient_sink.active = None
+        if self.forked:
+            self.main.wait_stream(self.side)
+        self.keep.clear()
+        return False
+
+    def buffer_for(self, w):
+        """(buffer, accumulate flag) when w is one of the sink's parameters and nothing differentiates this pass."""
+        if torch.is_grad_enabled():
+            return None
+        ent = self.buffers.get(w.data_ptr())
+        if ent is None or ent[0].shape != w.shape:
+            return None
+        return ent[1], (w.data_ptr() in self.touched)
+
+    def stream_for(self, w, *keep):
+        """The stream of the next launch for w; everything enqueued on the calling stream so far is waited for."""
+        self.touched.add(w.data_ptr())
+        if self.side is None:
+            return _stream()
+        # the formulas run on the autograd engine's thread, on the stream their forward pass ran on
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.forked = True
+        self.keep.extend(keep)          # operands and workspaces stay allocated until the join
+        return ctypes.c_void_p(self.side.cuda_stream)
+
+
+_sink_streams = {}
+
+
 def _check_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -458,35 +526,61 @@ def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0, out
     return gy.new_empty((gy.shape[0], w.shape[1], H, W), dtype=_out_dtype(gy, out_dtype))
 
 
-@torch.library.custom_op("ganconv::conv_wgrad", mutates_args=())
-def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: int, precision: int, alpha: float = 1.0) -> Tensor:
-    """alpha * gw, gw [Cout, Cin, kh, kw] (fp32) being the weight gradient of the conv x -> y given x and gy (alpha: the
-    scalar that multiplied the weight in the forward pass, see conv_fprop)."""
-    _check_cuda(x, gy)
-    N, Cin, H, W = x.shape
-    N2, Cout, Ho, Wo = gy.shape
-    if N2 != N or (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
-        raise RuntimeError("ganconv: x and gy shapes are inconsistent with the convolution geometry")
+def _wgrad_operands(x, gy, precision):
     x, gy = _nhwc(x), _nhwc(gy)
     if x.dtype != gy.dtype:      # mixed storage (e.g. an fp32 image feeding bf16 activations): the operands are bf16 anyway
         x = x if x.dtype == torch.bfloat16 else _to_bf16(x)
         gy = gy if gy.dtype == torch.bfloat16 else _to_bf16(gy)
     # bf16 copies only where the LDS-DMA weight-gradient kernel can use them; the other kernels convert fp32 operands
     # in registers (narrow layers are bound by reading these tensors once, a copy would only add traffic)
+    Cin, Cout = x.shape[1], gy.shape[1]
     if (precision == _lib.GC_PREC_BF16 and x.dtype == torch.float32 and Cin % 8 == 0 and Cout % 8 == 0 and Cin > 32
             and max(x.numel(), gy.numel()) * 2 < (1 << 31) - (1 << 21)):
         x, gy = _to_bf16(x), _to_bf16(gy)
+    return x, gy
+
+
+def _wgrad_launch(x, gy, gw, kh, kw, stride, padding, precision, alpha, accumulate, stream_of):
+    """gw (+)= alpha * weight gradient.  stream_of(*tensors to keep alive) names the launch stream once the operands exist."""
+    N, Cin, H, W = x.shape
+    N2, Cout, Ho, Wo = gy.shape
+    if N2 != N or (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
+        raise RuntimeError("ganconv: x and gy shapes are inconsistent with the convolution geometry")
+    x, gy = _wgrad_operands(x, gy, precision)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
     L = _lib.lib()
-    gw = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
     ws_bytes = L.gc_wgrad_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    side = _SideLaunch.active
-    stream = side.fork(ws, x, gy, gw) if side is not None else _stream()
+    stream = stream_of(ws, x, gy, gw)
     _lib.check(L.gc_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(gy.data_ptr()),
-                                 ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), float(alpha), 0, None,
+                                 ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), float(alpha), 1 if accumulate else 0, None,
                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream), "gc_conv2d_wgrad")
+
+
+@torch.library.custom_op("ganconv::conv_wgrad", mutates_args=())
+def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: int, precision: int, alpha: float = 1.0) -> Tensor:
+    """alpha * gw, gw [Cout, Cin, kh, kw] (fp32) being the weight gradient of the conv x -> y given x and gy (alpha: the
+    scalar that multiplied the weight in the forward pass, see conv_fprop)."""
+    _check_cuda(x, gy)
+    gw = torch.empty((gy.shape[1], x.shape[1], kh, kw), dtype=torch.float32, device=x.device)
+    side = _SideLaunch.active
+    _wgrad_launch(x, gy, gw, kh, kw, stride, padding, precision, alpha, False, side.fork if side is not None else (lambda *keep: _stream()))
     return gw
+
+
+def _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
+    """Hands the weight gradient of w to the active sink; False when there is none for it (the caller computes it)."""
+    sink = weight_gradient_sink.active
+    if sink is None or not x.is_cuda:
+        return False
+    ent = sink.buffer_for(w)
+    if ent is None:
+        return False
+    buf, accumulate = ent
+    if buf.dtype != torch.float32 or not buf.is_contiguous():
+        raise RuntimeError("ganconv: weight_gradient_sink buffers must be contiguous float32 tensors")
+    _wgrad_launch(x, gy, buf, w.shape[2], w.shape[3], stride, padding, precision, alpha, accumulate, lambda *keep: sink.stream_for(w, *keep))
+    return True
 
 
 @conv_wgrad.register_fake
@@ -621,6 +715,8 @@ def _fprop_backward(ctx, gy):
     else:
         x, w = ctx.saved_tensors
     gx = gw = None
+    if need_w and _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
+        need_w = False
     if _overlap and need_x and need_w and gy.is_cuda:
         with _SideLaunch(gy.device) as side:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
@@ -663,6 +759,8 @@ def _dgrad_backward(ctx, u):
     else:
         gy, w = ctx.saved_tensors
     g_gy = g_w = None
+    if need_w and _wgrad_to_sink(w, u, gy, stride, padding, precision, alpha):
+        need_w = False
     if _overlap and need_gy and need_w and u.is_cuda:
         with _SideLaunch(u.device) as side:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)

@@ -10,16 +10,20 @@ import gan_amd
 from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="two_streams", choices=["two_streams", "three_chains", "repack", "gen_ahead"])
+ap.add_argument("--what", default="two_streams", choices=["two_streams", "three_chains", "repack", "gen_ahead", "flag"])
+ap.add_argument("--flag", default="weight_gradient_sink", help="with --what flag: the boolean switch of gan_amd.harness.basic_gans under test")
 ap.add_argument("--batch", type=int, default=256)
 args = ap.parse_args()
 
 
 def make(on):
+    if args.what == "flag":
+        from gan_amd.harness import basic_gans
+        setattr(basic_gans, args.flag, bool(on))
     # three_chains: real, fake and penalty passes on three streams against real + fake batched beside the penalty pass
     tr = WganGpTrainer(args.batch, 64, 100, 64, device="cuda:0", capturable=True, batch_real_fake=not (on and args.what == "three_chains"),
                        fused_adam=True, activation_dtype=torch.bfloat16,
-                       two_streams=(on and args.what == "two_streams") or args.what in ("three_chains", "gen_ahead"))
+                       two_streams=(on and args.what == "two_streams") or args.what in ("three_chains", "gen_ahead", "flag"))
     tr.gen_ahead = tr.two_streams and (on or args.what != "gen_ahead")
     if args.what == "repack" and not on:
         tr.opt_D.repack_after_step()
@@ -44,6 +48,6 @@ def timed(tr, n=20):
 
 a, b = make(True), make(False)
 for rnd in range(3):
-    print(f"round {rnd}: {args.what} on {timed(a):.3f} ms   off {timed(b):.3f} ms", flush=True)
+    print(f"round {rnd}: {args.what if args.what != 'flag' else args.flag} on {timed(a):.3f} ms   off {timed(b):.3f} ms", flush=True)
 print("losses on :", a.static_out.cpu().numpy().round(4).tolist())
 print("losses off:", b.static_out.cpu().numpy().round(4).tolist())
