@@ -34,7 +34,7 @@ class ConvDesc(ctypes.Structure):
 
 class Epilogue(ctypes.Structure):
     _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("bias", ctypes.c_void_p), ("ch_sum", ctypes.c_void_p),
-                ("ch_sumsq", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("reserved", ctypes.c_int32 * 2)]
+                ("ch_sumsq", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("grad_mask", ctypes.c_void_p)]
 
 
 _lib = None

@@ -26,12 +26,14 @@ struct GatherParams {
   float* ch_sum;       // [OC] or null
   float* ch_sumsq;     // [OC] or null
   uint16_t* out_bf16;  // null, or a bf16 copy of the fp32 output (same indexing)
+  const void* mask;    // null, or a tensor indexed like `out` (same element type): out *= mask > 0 ? 1 : slope
   int32_t N, IH, IW, IC, ICp, OH, OW, OC, T;
   int32_t row_pitch;   // elements per packed weight row
   int32_t a, b;        // input-coordinate multiplier, output class stride
   int32_t in_cstride, in_coff, out_cstride, out_coff;
   int32_t act;
   float slope;
+  float mask_slope;    // the factor applied where mask <= 0
   int32_t out_vec;     // 1: 16-byte (fp32) / 8-byte (bf16) stores of 4 channels are aligned
   int32_t out_vec8;    // 1: 16-byte stores of 8 bf16 channels are aligned as well, and so are 16-byte loads of the bias
   int32_t out_f32;     // element type of `out`: 1 fp32, 0 bf16 (independent of the input's type)

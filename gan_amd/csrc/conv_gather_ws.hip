@@ -54,13 +54,14 @@ struct WsParams {
   float* ch_sum;
   float* ch_sumsq;
   uint16_t* out_bf16;
+  const void* mask;                 // null, or indexed like `out`: the stored value is scaled by (mask > 0 ? 1 : mask_slope)
   unsigned long long* diag_buf;
   int32_t in_bytes, w_bytes, a_bias;
   int32_t IH, IW, IC, csteps, OH, OW, row_pitch, ICp;
   int32_t a, b;
   int32_t in_cstride, in_coff, out_cstride, out_coff;
   int32_t act;
-  float slope;
+  float slope, mask_slope;
   int32_t n_tiles, n_oc_tiles, n_classes, cls_interleave;
   uint32_t oct_mul, oct_shift;      // division by n_oc_tiles
   uint32_t ncls_mul, ncls_shift;    // division by n_classes
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
   const int wo = wave / WP, wp_ = wave % WP;
   const int g = lane >> 4, c16 = lane & 15;
   TOut* out = reinterpret_cast<TOut*>(p.out);
+  const TOut* mask = reinterpret_cast<const TOut*>(p.mask);
   const bool stats = p.ch_sum != nullptr;
   const float sl = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);   // v > 0 ? v : v * sl
   unsigned long long epi_cycles = 0, wait_cycles = 0;
@@ -355,6 +357,23 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
         for (int r = 0; r < 4; r++) {
           va[r] = va[r] > 0.f ? va[r] : va[r] * sl;
           vb[r] = vb[r] > 0.f ? vb[r] : vb[r] * sl;
+        }
+        if (mask != nullptr) {          // (uniform branch) derivative of the activation whose output is `mask`
+          f32x4 ma, mb;
+          const size_t moff = mok ? eoff + (i >> 1) * 32 : 0;
+          if (sizeof(TOut) == 2) {
+            const u32x4 mv = *reinterpret_cast<const u32x4*>(mask + moff);
+            ma = widen_bf16x4(u32x2{mv[0], mv[1]});
+            mb = widen_bf16x4(u32x2{mv[2], mv[3]});
+          } else {
+            ma = *reinterpret_cast<const f32x4*>(mask + moff);
+            mb = *reinterpret_cast<const f32x4*>(mask + moff + 4);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            va[r] = ma[r] > 0.f ? va[r] : va[r] * p.mask_slope;
+            vb[r] = mb[r] > 0.f ? vb[r] : vb[r] * p.mask_slope;
+          }
         }
         const u32x2 pa = cvt_bf16x4(va), pb = cvt_bf16x4(vb);
         if (mok) {
@@ -474,7 +493,7 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
   p.IH = g.IH; p.IW = g.IW; p.IC = g.IC; p.ICp = g.ICp; p.csteps = g.ICp / kBK; p.OH = g.OH; p.OW = g.OW; p.row_pitch = g.row_pitch;
   p.a = g.a; p.b = g.b;
   p.in_cstride = g.in_cstride; p.in_coff = g.in_coff; p.out_cstride = g.out_cstride; p.out_coff = g.out_coff;
-  p.act = g.act; p.slope = g.slope;
+  p.act = g.act; p.slope = g.slope; p.mask = g.mask; p.mask_slope = g.mask_slope;
   p.n_oc_tiles = g.n_oc_tiles; p.n_tiles = g.n_pix_tiles * g.n_oc_tiles; p.n_classes = g.tt.n_classes; p.cls_interleave = g.cls_interleave;
   ws_div((uint32_t)p.n_oc_tiles, &p.oct_mul, &p.oct_shift);
   ws_div((uint32_t)p.n_classes, &p.ncls_mul, &p.ncls_shift);

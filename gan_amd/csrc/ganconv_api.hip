@@ -258,7 +258,48 @@ static int pass_dtypes(const gc_conv_desc* d, int pass, int* in_dt, int* out_dt)
   return GC_OK;
 }
 
+// out *= mask > 0 ? 1 : slope over the channel slice of every pixel: the grad_mask stage for the kernels that do not
+// apply it in their own epilogue.  One thread per 4 channels.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mask_scale_kernel(void* out, const void* mask, size_t total4, uint32_t oc4, int cstride, int coff,
+                                                               float slope) {
+  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total4; e += (size_t)gridDim.x * kThreads) {
+    const size_t pix = e / oc4;
+    const size_t idx = pix * cstride + coff + (e - pix * oc4) * 4;
+    f32x4 v = load4<T>(out, idx);
+    const f32x4 m = load4<T>(mask, idx);
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = m[r] > 0.f ? v[r] : v[r] * slope;
+    store4<T>(out, idx, v);
+  }
+}
+
+static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream);
+
 static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream) {
+  if (p.mask == nullptr) return run_gather_unmasked(p, l, out_dt, stream);
+  if (!p.out_vec || p.OC % 4 != 0) {
+    set_error("grad_mask needs an output channel slice of a multiple of 4 channels at an aligned offset");
+    return GC_UNSUPPORTED_GEOMETRY;
+  }
+  const void* mask = p.mask;
+  const float slope = p.mask_slope;
+  int rc = run_gather_unmasked(p, l, out_dt, stream);     // clears p.mask when its kernel applied the mask itself
+  if (rc != GC_OK || p.mask == nullptr) return rc;
+  const size_t total4 = (size_t)p.N * p.OH * p.OW * (p.OC / 4);
+  size_t blocks = (total4 + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  ProfScope ps("gc::mask_scale_kernel", 0.0, stream);
+  if (out_dt == GC_F32)
+    hipLaunchKernelGGL(mask_scale_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p.out, mask, total4, (uint32_t)(p.OC / 4),
+                       p.out_cstride, p.out_coff, slope);
+  else
+    hipLaunchKernelGGL(mask_scale_kernel<uint16_t>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p.out, mask, total4,
+                       (uint32_t)(p.OC / 4), p.out_cstride, p.out_coff, slope);
+  return check_hip(hipGetLastError(), "mask_scale launch");
+}
+
+static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t stream) {
   p.out_f32 = out_dt == GC_F32;
   if (p.out_bf16 != nullptr && (out_dt != GC_F32 || !p.out_vec || p.OC % 4 != 0)) {
     set_error("out_bf16 needs an fp32 output whose channel slice is a multiple of 4 channels at a multiple of 4");
@@ -287,7 +328,11 @@ static int run_gather(GatherParams& p, GatherLaunch& l, int out_dt, hipStream_t 
   const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 256 || l.to == 128 || l.to == 64) &&
                    p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
   if (dma && patch_kernel_allowed() && plan_patch(p, l)) return launch_patch(p, l, out_dt == GC_F32, stream);
-  if (dma && plan_ws(p, l)) return launch_ws(p, l, out_dt == GC_F32, stream);
+  if (dma && plan_ws(p, l)) {
+    const int rc = launch_ws(p, l, out_dt == GC_F32, stream);    // applies grad_mask in its epilogue
+    p.mask = nullptr;
+    return rc;
+  }
   if (dma) return launch_gather_dma(p, l, out_dt == GC_F32, stream);
   return launch_gather(p, l, stream);
 }
@@ -310,18 +355,24 @@ int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 }
 
 static void fill_epilogue(GatherParams& p, const gc_epilogue* ep) {
-  p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.out_bf16 = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
+  p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.out_bf16 = nullptr; p.mask = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
   if (ep != nullptr) {
     p.bias = ep->bias; p.ch_sum = ep->ch_sum; p.ch_sumsq = ep->ch_sumsq; p.act = ep->act; p.slope = ep->slope;
-    p.out_bf16 = (uint16_t*)ep->out_bf16;
+    p.out_bf16 = (uint16_t*)ep->out_bf16; p.mask = ep->grad_mask;
+    if (p.mask != nullptr) { p.mask_slope = ep->slope; p.slope = 0.f; }
   }
 }
 
 static int check_epilogue(const gc_epilogue* ep) {
   if (ep == nullptr) return GC_OK;
   if (ep->act < GC_ACT_NONE || ep->act > GC_ACT_SIGMOID) { set_error("unknown activation %d", ep->act); return GC_BAD_ARGUMENT; }
-  for (int i = 0; i < 2; i++)
-    if (ep->reserved[i] != 0) { set_error("reserved epilogue fields must be zero"); return GC_BAD_ARGUMENT; }
+  if (ep->grad_mask != nullptr) {
+    if (ep->act != GC_ACT_NONE || ep->ch_sum != nullptr || ep->out_bf16 != nullptr) {
+      set_error("grad_mask needs act == GC_ACT_NONE, no statistics and no out_bf16");
+      return GC_BAD_ARGUMENT;
+    }
+    if (reinterpret_cast<uintptr_t>(ep->grad_mask) & 15u) { set_error("grad_mask must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
+  }
   if (reinterpret_cast<uintptr_t>(ep->out_bf16) & 7u) { set_error("out_bf16 must be 8-byte aligned"); return GC_BAD_ARGUMENT; }
   if (ep->ch_sumsq != nullptr && ep->ch_sum == nullptr) { set_error("ch_sumsq needs ch_sum"); return GC_BAD_ARGUMENT; }
   return GC_OK;

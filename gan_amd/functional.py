@@ -49,12 +49,16 @@ def _out_code(out_dtype):
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, *, _wkey=0, precision=None, activation=None,
-           negative_slope=0.2, out_dtype=None, weight_scale=1.0):
+           negative_slope=0.2, out_dtype=None, weight_scale=1.0, defer_activation_grad=False, input_activation_slope=None):
     """`activation` (None, "relu", "leaky_relu", "tanh", "sigmoid") is applied in the kernel's epilogue: the result
     equals activation(conv2d(...)) of the unfused pair.  `out_dtype` (None = the input's, torch.float32 or
     torch.bfloat16) is the storage type of the result; accumulation is always fp32.  `weight_scale`: a Python scalar c;
     the result is conv2d(input, c * weight, ...) with c folded into the kernel's weight image instead of a separate
-    multiplication of the weight on every call."""
+    multiplication of the weight on every call.
+    `defer_activation_grad` / `input_activation_slope` move the derivative of a ReLU / LeakyReLU epilogue into the
+    data-gradient kernel of the next convolution (ops.conv_fprop): the producer is called with defer_activation_grad=True,
+    its one consumer with input_activation_slope = the producer's negative slope (0 for ReLU).  Results are those of the
+    plain pair; one elementwise sweep over the activated tensor per backward pass goes away."""
     _check_input(input, weight)
     if _single(dilation, "dilation") != 1:
         raise RuntimeError("ganconv: dilation > 1 is not supported")
@@ -62,7 +66,8 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
         raise RuntimeError("ganconv: groups > 1 is not supported by conv2d (the StyleGAN depthwise blur is ops.blur3x3)")
     prec = ops.get_precision() if precision is None else precision
     return ops.conv_fprop(input, weight, bias, _single(stride, "stride"), _single(padding, "padding"), prec, _wkey,
-                          _act_code(activation), float(negative_slope), _out_code(out_dtype), float(weight_scale))
+                          _act_code(activation), float(negative_slope), _out_code(out_dtype), float(weight_scale),
+                          bool(defer_activation_grad), -1.0 if input_activation_slope is None else float(input_activation_slope))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, *, _wkey=0,

@@ -46,7 +46,7 @@ class Generator(torch.nn.Module):
 
 
 class Discriminator(torch.nn.Module):
-    def __init__(self, image_dim, hidden_dim, resolution=128, is_wgan=False, activation_dtype=torch.float32):
+    def __init__(self, image_dim, hidden_dim, resolution=128, is_wgan=False, activation_dtype=torch.float32, fuse_activation_grad=True):
         super().__init__()
         n_layers = int(math.log2(resolution)) - 1
         layers = []
@@ -55,8 +55,11 @@ class Discriminator(torch.nn.Module):
             cin = image_dim if first else int(hidden_dim * 2 ** (i - 1))
             cout = 1 if last else int(hidden_dim * 2 ** i)
             fused = "leaky_relu" if first else ("sigmoid" if last and not is_wgan else None)
+            # the first LeakyReLU's derivative is applied by the second convolution's data-gradient kernel
             ops = [gnn.Conv2d(cin, cout, 4, 1 if last else 2, 0 if last else 1, bias=False, activation=fused, negative_slope=0.2,
-                              out_dtype=torch.float32 if last else (activation_dtype if first else None))]
+                              out_dtype=torch.float32 if last else (activation_dtype if first else None),
+                              defer_activation_grad=first and fuse_activation_grad,
+                              input_activation_slope=0.2 if (i == 1 and fuse_activation_grad) else None)]
             if first:
                 pass
             elif not last and is_wgan:   # InstanceNorm2d + LeakyReLU(0.2) of the reference as one fused op (no parameters)

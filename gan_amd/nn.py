@@ -49,16 +49,22 @@ class _FusedActivation:
 
 
 class Conv2d(_FusedActivation, _KeyedWeight, torch.nn.Conv2d):
-    def __init__(self, *args, activation=None, negative_slope=0.2, out_dtype=None, **kwargs):
+    """defer_activation_grad / input_activation_slope: see functional.conv2d (a producer / consumer pair of convolutions
+    with a ReLU or LeakyReLU between them, the consumer being the activated tensor's only reader)."""
+
+    def __init__(self, *args, activation=None, negative_slope=0.2, out_dtype=None, defer_activation_grad=False,
+                 input_activation_slope=None, **kwargs):
         super().__init__(*args, **kwargs)
         self._init_activation(activation, negative_slope, out_dtype)
+        self.defer_activation_grad, self.input_activation_slope = defer_activation_grad, input_activation_slope
 
     def _conv_forward(self, input, weight, bias):
         if self.padding_mode != "zeros":
             raise RuntimeError("ganconv: only zero padding is supported")
         key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
         return F.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key,
-                        activation=self.activation, negative_slope=self.negative_slope, out_dtype=self.out_dtype)
+                        activation=self.activation, negative_slope=self.negative_slope, out_dtype=self.out_dtype,
+                        defer_activation_grad=self.defer_activation_grad, input_activation_slope=self.input_activation_slope)
 
 
 class ConvTranspose2d(_FusedActivation, _KeyedWeight, torch.nn.ConvTranspose2d):

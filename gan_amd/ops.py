@@ -457,8 +457,14 @@ def _act_backward(g, y, act, slope):
 # ---- op implementations (run below autograd) -------------------------------------------------------------------
 @torch.library.custom_op("ganconv::conv_fprop", mutates_args=())
 def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, padding: int, precision: int, wkey: int,
-               act: int = 0, slope: float = 0.0, out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
-    """act(conv2d(x, alpha * w) + bias); act is a gc_act code fused into the kernel's epilogue.  out_dtype: -1 the
+               act: int = 0, slope: float = 0.0, out_dtype: int = -1, alpha: float = 1.0, defer_act_grad: bool = False,
+               x_act_slope: float = -1.0) -> Tensor:
+    """act(conv2d(x, alpha * w) + bias); act is a gc_act code fused into the kernel's epilogue.  The last two arguments
+    change nothing in the forward pass; they move the derivative of a ReLU / LeakyReLU epilogue out of a sweep of its own
+    and into the data-gradient kernel of the convolution that consumes the activated tensor.  defer_act_grad: the backward
+    formula treats the incoming gradient as the gradient with respect to the PRE-activation value; valid when the output's
+    only consumer is a convolution called with x_act_slope >= 0.  x_act_slope >= 0: x is the output of such an epilogue
+    (slope 0: ReLU), and the gradient returned for x is already multiplied by the activation's derivative.  out_dtype: -1 the
     input's dtype, 0 float32, 1 bfloat16 (activations may be stored in either; accumulation is fp32).  alpha: a per-layer
     scalar folded into the packed weight image (EqualizedLR's sqrt(2 / fan_in), StyleGAN/model.py:33-37): the weight the
     op sees stays the stored parameter, so its cached image is reused until the parameter itself changes."""
@@ -486,20 +492,15 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
 
 
 @conv_fprop.register_fake
-def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1, alpha=1.0):
+def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1, alpha=1.0, defer_act_grad=False, x_act_slope=-1.0):
     N, _, H, W = x.shape
     Cout, _, kh, kw = w.shape
     return x.new_empty((N, Cout, (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1),
                        dtype=_out_dtype(x, out_dtype))
 
 
-@torch.library.custom_op("ganconv::conv_dgrad", mutates_args=())
-def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, stride: int, padding: int, precision: int,
-               wkey: int, act: int = 0, slope: float = 0.0, out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
-    """gx [N, Cin, H, W] of the conv x -> y described by (alpha * w [Cout,Cin,kh,kw], stride, padding), given gy.
-    `bias` ([Cin]) is added to gx: the bias of a transposed convolution whose forward pass this is.
-    out_dtype as for conv_fprop."""
-    _check_cuda(gy, w, bias)
+def _dgrad_launch(gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, out_dtype, alpha, mask=None, mask_slope=0.0):
+    _check_cuda(gy, w, bias, mask)
     N, Cout, Ho, Wo = gy.shape
     Cout_w, Cin, kh, kw = w.shape
     if Cout_w != Cout:
@@ -508,17 +509,51 @@ def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, st
         raise RuntimeError(f"ganconv: input size ({H}x{W}) is inconsistent with the gradient's ({Ho}x{Wo})")
     gy = _nhwc(gy)
     want = _out_dtype(gy, out_dtype)
-    narrow = _small_output_in_f32(N * Cin * H * W, want, act)
+    narrow = mask is None and _small_output_in_f32(N * Cin * H * W, want, act)
     gx = torch.empty((N, Cin, H, W), dtype=torch.float32 if narrow else want, device=gy.device, memory_format=torch.channels_last)
     if _dma_ok(gy, Cout, Cin, precision):
         gy = _to_bf16(gy)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gx), precision, _dtype_code(gy))
     wp = _packed(d, w, _lib.GC_PASS_DGRAD, wkey, alpha)
-    ep, keep = _epilogue(bias, act, slope, gx if (act != 0 and gx.dtype == torch.float32) else None)
+    if mask is not None:
+        if mask.shape != gx.shape:
+            raise RuntimeError(f"ganconv: the activated tensor {tuple(mask.shape)} does not have the gradient's shape {tuple(gx.shape)}")
+        mask = _nhwc(mask)
+        if mask.dtype != gx.dtype:
+            mask = mask.to(gx.dtype)
+        ep, keep = Epilogue(), (mask,)
+        ep.act, ep.slope, ep.grad_mask = _lib.GC_ACT_NONE, mask_slope, mask.data_ptr()
+        if bias is not None:
+            raise RuntimeError("ganconv: a masked data gradient takes no bias")
+    else:
+        ep, keep = _epilogue(bias, act, slope, gx if (act != 0 and gx.dtype == torch.float32) else None)
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(gx.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_dgrad")
     return gx.to(want) if narrow else gx
+
+
+@torch.library.custom_op("ganconv::conv_dgrad", mutates_args=())
+def conv_dgrad(gy: Tensor, w: Tensor, bias: Optional[Tensor], H: int, W: int, stride: int, padding: int, precision: int,
+               wkey: int, act: int = 0, slope: float = 0.0, out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
+    """gx [N, Cin, H, W] of the conv x -> y described by (alpha * w [Cout,Cin,kh,kw], stride, padding), given gy.
+    `bias` ([Cin]) is added to gx: the bias of a transposed convolution whose forward pass this is.
+    out_dtype as for conv_fprop."""
+    return _dgrad_launch(gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, out_dtype, alpha)
+
+
+@torch.library.custom_op("ganconv::conv_dgrad_masked", mutates_args=())
+def conv_dgrad_masked(gy: Tensor, w: Tensor, x: Tensor, x_act_slope: float, stride: int, padding: int, precision: int, wkey: int,
+                      out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
+    """conv_dgrad(gy, w) * (x > 0 ? 1 : x_act_slope): the gradient of the conv x -> y with respect to the value in front
+    of the ReLU / LeakyReLU epilogue that produced x, the activation's derivative applied in the data-gradient kernel's
+    epilogue (the kernel reads x at the position it stores)."""
+    return _dgrad_launch(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, out_dtype, alpha, x, x_act_slope)
+
+
+@conv_dgrad_masked.register_fake
+def _(gy, w, x, x_act_slope, stride, padding, precision, wkey, out_dtype=-1, alpha=1.0):
+    return gy.new_empty(x.shape, dtype=_out_dtype(gy, out_dtype))
 
 
 @conv_dgrad.register_fake
@@ -693,13 +728,18 @@ def _wanted(ctx, i):
 
 
 def _fprop_setup(ctx, inputs, output):
-    x, w, bias, stride, padding, precision, wkey, act, slope, _, alpha = inputs
+    x, w, bias, stride, padding, precision, wkey, act, slope, _, alpha, defer_act_grad, x_act_slope = inputs
     ctx.edges = _edges(x, w, bias)
+    if defer_act_grad:
+        if act not in (_lib.GC_ACT_RELU, _lib.GC_ACT_LRELU):
+            raise RuntimeError("ganconv: defer_act_grad is for ReLU / LeakyReLU epilogues")
+        act = 0                      # the consumer's data-gradient kernel applies the derivative
     if act != 0:
         ctx.save_for_backward(x, w, output)
     else:
         ctx.save_for_backward(x, w)
     ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope, alpha)
+    ctx.x_act_slope = x_act_slope
 
 
 def _fprop_backward(ctx, gy):
@@ -715,22 +755,28 @@ def _fprop_backward(ctx, gy):
     else:
         x, w = ctx.saved_tensors
     gx = gw = None
+
+    def dgrad():
+        if ctx.x_act_slope >= 0.0:
+            return conv_dgrad_masked(gy, w, x, ctx.x_act_slope, stride, padding, precision, wkey, _code_of(x.dtype), alpha)
+        return conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
+
     if need_w and _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
         need_w = False
     if _overlap and need_x and need_w and gy.is_cuda:
         with _SideLaunch(gy.device) as side:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
-        gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
+        gx = dgrad()
         side.join()
         gw = gw.to(w.dtype)
     else:
         if need_x:
-            gx = conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
+            gx = dgrad()
         if need_w:
             gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
     if need_b and gb is None:
         gb = channel_sum(gy)
-    return gx, gw, gb, None, None, None, None, None, None, None, None
+    return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_fprop", _fprop_backward, setup_context=_fprop_setup)
@@ -778,6 +824,33 @@ def _dgrad_backward(ctx, u):
 
 
 torch.library.register_autograd("ganconv::conv_dgrad", _dgrad_backward, setup_context=_dgrad_setup)
+
+
+def _dgrad_masked_setup(ctx, inputs, output):
+    gy, w, x, x_act_slope, stride, padding, precision, wkey, _, alpha = inputs
+    ctx.edges = _edges(gy, w)
+    ctx.save_for_backward(gy, w, x)
+    ctx.cfg = (x_act_slope, stride, padding, precision, wkey, alpha)
+
+
+def _dgrad_masked_backward(ctx, u):
+    """The op is linear in gy and in w for a fixed mask, and the mask's derivative with respect to x is zero almost
+    everywhere: u passes through the same mask, then through the adjoints of the data gradient."""
+    x_act_slope, stride, padding, precision, wkey, alpha = ctx.cfg
+    gy, w, x = ctx.saved_tensors
+    need_gy, need_w = _wanted(ctx, 0), _wanted(ctx, 1)
+    u = _act_backward(u, x, _lib.GC_ACT_LRELU if x_act_slope != 0.0 else _lib.GC_ACT_RELU, x_act_slope)
+    g_gy = g_w = None
+    if need_w and _wgrad_to_sink(w, u, gy, stride, padding, precision, alpha):
+        need_w = False
+    if need_gy:
+        g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
+    if need_w:
+        g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
+    return g_gy, g_w, None, None, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::conv_dgrad_masked", _dgrad_masked_backward, setup_context=_dgrad_masked_setup)
 
 
 def _wgrad_setup(ctx, inputs, output):

@@ -73,7 +73,8 @@ typedef struct gc_conv_desc {
 } gc_conv_desc;
 
 /* Fused output stage of gc_conv2d_fprop / gc_conv2d_dgrad, applied in this order:
- *   v = acc (+ bias[c]) ; v = act(v) ; store ; optional per-channel statistics of the STORED value.
+ *   v = acc (+ bias[c]) ; v = act(v) (or v *= the derivative selected by grad_mask) ; store ; optional per-channel
+ *   statistics of the STORED value.
  * ch_sum / ch_sumsq, when non-NULL, are float[C] accumulators the kernel ADDS into with atomics (the caller
  * zeroes them): sum and sum of squares over N*H*W per output channel -- the batch statistics BatchNorm2d
  * needs right after the conv (BasicGANs/models.py:37,79; Pix2Pix/models.py:86,127). */
@@ -85,7 +86,13 @@ typedef struct gc_epilogue {
   float* ch_sumsq;        /* float[C] or NULL */
   void* out_bf16;         /* NULL, or where to write a bf16 copy of an fp32 output (same layout and channel slice):
                              the operand image of the convolution that reads this output next in GC_PREC_BF16 mode */
-  int32_t reserved[2];    /* must be zero */
+  const void* grad_mask;  /* NULL, or a tensor of the output's dtype, layout and channel slice, 16-byte aligned: the stored
+                             value is multiplied by 1 where grad_mask > 0 and by `slope` elsewhere.  For a data gradient
+                             that flows on through the ReLU (slope 0) / LeakyReLU whose OUTPUT is grad_mask, i.e. the
+                             activation in front of the convolution being differentiated: its derivative is applied in the
+                             kernel that computes the gradient instead of by aten::leaky_relu_backward /
+                             threshold_backward behind it (BasicGANs/models.py:78, the critic's first LeakyReLU).  Needs
+                             act == GC_ACT_NONE, no statistics and no out_bf16. */
 } gc_epilogue;
 
 int gc_version(void);

@@ -622,6 +622,44 @@ def test_unwanted_weight_gradients_are_skipped_not_changed(gan):
         assert torch.equal(a, p_.grad)
 
 
+@pytest.mark.parametrize("slope", [0.2, 0.0], ids=["leaky_relu", "relu"])
+@pytest.mark.parametrize("dt,shape", [(torch.float32, (3, 8, 12, 12)), (torch.bfloat16, (256, 64, 32, 32)), (torch.bfloat16, (2, 24, 10, 6))],
+                         ids=["fp32_small", "bf16_benchmark_layer", "bf16_ragged"])
+def test_deferred_activation_gradient_matches_plain_pair(gan, slope, dt, shape):
+    """conv + (Leaky)ReLU epilogue + conv with the activation's derivative applied by the second convolution's
+    data-gradient kernel (wave-specialised kernel on the benchmark layer, the sweep behind the other kernels elsewhere)
+    against the plain pair: first-order gradients, and the double backward of a gradient penalty."""
+    torch.manual_seed(6)
+    N, C, H, W = shape
+    act = "leaky_relu" if slope else "relu"
+    prec = "fp32x3" if dt == torch.float32 else "bf16"
+    gan.set_precision(prec)
+    try:
+        def build(fused):
+            torch.manual_seed(7)
+            a = gan.nn.Conv2d(3, C, 4, 2, 1, bias=False, activation=act, negative_slope=slope, out_dtype=dt, defer_activation_grad=fused).cuda()
+            b = gan.nn.Conv2d(C, 2 * C, 4, 2, 1, bias=False, out_dtype=torch.float32, input_activation_slope=slope if fused else None).cuda()
+            return a, b
+
+        x = torch.randn(N, 3, 2 * H, 2 * W, device="cuda").contiguous(memory_format=torch.channels_last)
+        probe = torch.randn(N, 2 * C, H // 2, W // 2, device="cuda")
+        res = []
+        for fused in (False, True):
+            a, b = build(fused)
+            xi = x.clone().requires_grad_(True)
+            y = b(a(xi))
+            first = torch.autograd.grad((y * probe).sum(), [xi, a.weight, b.weight], retain_graph=True)
+            with gan.ops.input_gradients_only():
+                g = torch.autograd.grad(y.sum(), xi, create_graph=True)[0]
+            second = torch.autograd.grad(gan.ops.gradient_penalty(g, 10.0)[0], [a.weight, b.weight])
+            res.append(list(first) + list(second))
+        tol = 1e-6 if dt == torch.float32 else 6e-3       # bf16 storage: one rounding (fused) against two
+        for plain, fused in zip(*res):
+            assert rel(fused.float(), plain.float()) <= tol, (rel(fused.float(), plain.float()), tuple(plain.shape))
+    finally:
+        gan.set_precision("bf16")
+
+
 def test_full_size_properties(gan):
     """Benchmark-size layers (WGAN-GP-64 at batch 256), checked through properties that need no oracle run:
     adjointness <conv(x), gy> = <x, dgrad(gy)> = <w, wgrad(x, gy)> and linearity in x."""
