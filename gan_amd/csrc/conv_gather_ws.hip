@@ -115,7 +115,9 @@ __device__ __forceinline__ bool tile_of(const WsParams& p, int k, TileId& id) {
   return true;
 }
 
-template <typename TOut, int TO, int STAGES>
+// MASK: the epilogue scales the stored value by the derivative selected by p.mask (a variant of its own: the extra loads
+// cost the 128-channel tile the register budget of its second workgroup per CU)
+template <typename TOut, int TO, int STAGES, bool MASK = false>
 __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsParams p) {
   constexpr int WO = TO >= 128 ? 2 : 1, WP = kNW / WO;
   constexpr int FO = TO / WO / 16, FP = kTP / WP / 16;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
           va[r] = va[r] > 0.f ? va[r] : va[r] * sl;
           vb[r] = vb[r] > 0.f ? vb[r] : vb[r] * sl;
         }
-        if (mask != nullptr) {          // (uniform branch) derivative of the activation whose output is `mask`
+        if (MASK) {                     // derivative of the activation whose output is `mask`
           f32x4 ma, mb;
           const size_t moff = mok ? eoff + (i >> 1) * 32 : 0;
           if (sizeof(TOut) == 2) {
@@ -428,10 +430,10 @@ void ws_div(uint32_t d, uint32_t* mul, uint32_t* shift) {
   *shift = f.shift;
 }
 
-template <typename TOut, int TO, int STAGES>
+template <typename TOut, int TO, int STAGES, bool MASK = false>
 int launch_one(const WsParams& p, int grid, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * (TO + kTP) * 128 + kMaxTaps * 4;
-  auto kern = conv_gather_ws_kernel<TOut, TO, STAGES>;
+  auto kern = conv_gather_ws_kernel<TOut, TO, STAGES, MASK>;
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [&]() {
@@ -514,7 +516,7 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
   // trimmed so that every workgroup gets the same number of tiles where that is possible.
   static const int force_stages = getenv("GC_WS_STAGES") ? atoi(getenv("GC_WS_STAGES")) : 0;
   static const int force_slots = getenv("GC_WS_SLOTS") ? atoi(getenv("GC_WS_SLOTS")) : 0;
-  const int stages = force_stages ? force_stages : (l.to == 128 ? 2 : 3);
+  const int stages = (force_stages && p.mask == nullptr) ? force_stages : (l.to == 128 ? 2 : 3);
   const int lds = stages * (l.to + kTP) * 128 + kMaxTaps * 4;
   int per_cu = (160 * 1024) / lds;
   if (per_cu > 2) per_cu = 2;
@@ -522,6 +524,10 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
   const int slots = force_slots ? force_slots : 256 * per_cu;
   const int rounds = (p.n_tiles + slots - 1) / slots;
   const int grid = (p.n_tiles + rounds - 1) / rounds;
+  if (p.mask != nullptr) {       // masked variants exist for the default ring depths only
+    if (l.to == 64) return out_f32 ? launch_one<float, 64, 3, true>(p, grid, l.flops, stream) : launch_one<uint16_t, 64, 3, true>(p, grid, l.flops, stream);
+    return out_f32 ? launch_one<float, 128, 2, true>(p, grid, l.flops, stream) : launch_one<uint16_t, 128, 2, true>(p, grid, l.flops, stream);
+  }
 #define WS_CASE(TO_, ST_)                                                                                       \
   if (l.to == TO_ && stages == ST_)                                                                             \
     return out_f32 ? launch_one<float, TO_, ST_>(p, grid, l.flops, stream) : launch_one<uint16_t, TO_, ST_>(p, grid, l.flops, stream);
