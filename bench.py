@@ -13,6 +13,8 @@ pass, fake pass, gradient-penalty double backward, Adam step) + 1 generator iter
                traffic = HBM bytes per launch of that kernel recorded by separate rocprofv3 counter passes
   cpu_baseline the same cycle on the host CPU through the oracle's restatement of the reference (stock torch
                CPU ops), rank 0 and N=1 only
+  families     (N=1) images/s of one training step of the other model families at the reference's per-GPU sizes, each
+               replayed as one HIP graph: DCGAN-64 batch 128, Pix2Pix-256 batch 8, StyleGAN-256 batch 32; not part of `value`
 """
 import argparse
 import json
@@ -53,6 +55,32 @@ def cpu_baseline(threads):
             "seconds": dt}
 
 
+def families(device, steps=8):
+    """{name: {"img_per_s", "ms_per_step", "batch", "what"}} for the steps of gan_amd.harness.steps, each one HIP graph."""
+    import gan_amd
+    from gan_amd.harness import steps as S
+    out = {}
+    for name, make in S.FAMILIES.items():
+        try:
+            step, batch, what = make(device)
+            g = gan_amd.GraphedStep(step)
+            for _ in range(2):
+                g()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[name] = {"img_per_s": batch / dt, "ms_per_step": 1e3 * dt, "batch": batch, "what": what, "hip_graph": True}
+            del g, step
+        except Exception as e:      # a family that fails does not take the headline line with it
+            out[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    S.reset_options()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="run the cycle eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-families", action="store_true", help="skip the per-family figures (DCGAN, Pix2Pix, StyleGAN steps)")
     ap.add_argument("--overlap", action="store_true",
                     help="launch weight-gradient kernels on a second stream beside the data gradient (measured: about 1 %% faster)")
     ap.add_argument("--force-reducer", action="store_true", help="use the data-parallel gradient reducer even with one rank (test aid)")
@@ -180,6 +209,10 @@ def main():
                        "losses_finite": finite},
             "roofline": roofline,
         }
+        if world == 1 and not a.no_families:
+            del tr
+            torch.cuda.empty_cache()
+            out["families"] = families(f"cuda:{local_rank}")
         if world == 1 and not a.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
             try:

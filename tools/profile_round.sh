@@ -12,10 +12,10 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 400 python3 bench.py > $out/bench_line.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --one-stream > $out/bench_line_under_rocprof.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace2 -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_line_under_rocprof_concurrent.json
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --one-stream > /dev/null
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --one-stream > /dev/null
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-families --one-stream > $out/bench_line_under_rocprof.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace2 -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-families > $out/bench_line_under_rocprof_concurrent.json
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-families --one-stream > /dev/null
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-families --one-stream > /dev/null
 python3 tools/pmc_traffic.py $(find $out/fetch -name '*counter_collection.csv') $(find $out/write -name '*counter_collection.csv') $out/traffic.json > $out/traffic.txt
 cp $(find $out/trace -name '*kernel_stats.csv') $out/bench_kernel_stats.csv
 cp $(find $out/trace2 -name '*kernel_stats.csv') $out/bench_kernel_stats_concurrent.csv
