@@ -128,6 +128,7 @@ class InstanceNormAct2d(torch.nn.Module):
     def __init__(self, num_features, eps=1e-5, negative_slope=0.2):
         super().__init__()
         self.num_features, self.eps, self.negative_slope = num_features, eps, negative_slope
+        self.activation = None if negative_slope is None else "leaky_relu"
 
     def forward(self, input):
         if input.shape[1] != self.num_features:

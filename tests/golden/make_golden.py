@@ -118,6 +118,63 @@ def make_ops(out):
     print("ops.npz:", len(OP_CASES), "cases")
 
 
+# ------------------------------------------------------------------------------------- full-width layers
+# Single layers at the reference's full channel widths (the reduced traces above run at ch 8): inputs are regenerated from
+# a torch CPU generator seed by the test, the file holds the results of the reference's call forms.  Large results are
+# stored as a strided sample plus eight random +-1 projections of the whole tensor.
+WIDE_CASES = [
+    # name, kind, N, Cin, H, W, Cout, k, stride, pad
+    ("p2p_enc_512_4to2", "conv", 4, 512, 4, 4, 512, 4, 2, 1),       # Pix2Pix/models.py:225-232 (U-Net bottom, ch 64)
+    ("p2p_enc_512_2to1", "conv", 4, 512, 2, 2, 512, 4, 2, 1),
+    ("p2p_dec_512_1to2", "convt", 4, 512, 1, 1, 512, 4, 2, 1),
+    ("p2p_dec_1024_2to4", "convt", 4, 1024, 2, 2, 512, 4, 2, 1),    # (skip connection doubles the input channels)
+    ("patchgan_256_512_s1", "conv", 2, 256, 31, 31, 512, 4, 1, 1),  # Pix2Pix/models.py:123-124 (PatchGAN conv_4 at 256x256 input)
+    ("stylegan_pg6_3x3", "conv", 1, 64, 256, 256, 32, 3, 1, 1),     # StyleGAN/model.py:72 (synthesis block 6, 256x256)
+    ("biggan_1024_8x8", "conv", 2, 1024, 8, 8, 1024, 3, 1, 1),      # BigGAN/model.py:121-124 (generator block 1 at ch 64)
+]
+WIDE_SAMPLE = 32768
+
+
+def wide_inputs(case, seed=SEED):
+    """(x, w, gy) of a WIDE_CASES entry, from a CPU generator (the same numbers wherever this torch version runs)."""
+    name, kind, N, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(seed + sum(name.encode()))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn((Cout, Cin, k, k) if kind == "conv" else (Cin, Cout, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    Ho = (H + 2 * p - k) // s + 1 if kind == "conv" else (H - 1) * s - 2 * p + k
+    Wo = (W + 2 * p - k) // s + 1 if kind == "conv" else (W - 1) * s - 2 * p + k
+    gy = torch.randn(N, Cout, Ho, Wo, generator=g)
+    return x, w, gy
+
+
+def wide_digest(t, seed):
+    """(strided sample of at most WIDE_SAMPLE elements, eight +-1 projections) of a tensor, in float64 accumulation."""
+    flat = t.detach().reshape(-1)
+    step = max(1, flat.numel() // WIDE_SAMPLE) | 1        # odd: walks through every tap and channel residue
+    g = torch.Generator().manual_seed(seed)
+    proj = []
+    for _ in range(8):
+        signs = torch.randint(0, 2, (flat.numel(),), generator=g, dtype=torch.int8).double() * 2 - 1
+        proj.append(float((flat.double() * signs).sum()))
+    return flat[::step].clone().numpy(), np.array(proj), float(flat.double().norm())
+
+
+def make_wide_ops(out):
+    blob = {}
+    for case in WIDE_CASES:
+        name, kind, N, Cin, H, W, Cout, k, s, p = case
+        x, w, gy = wide_inputs(case)
+        x.requires_grad_(True); w.requires_grad_(True)
+        y = F.conv2d(x, w, None, s, p) if kind == "conv" else F.conv_transpose2d(x, w, None, s, p)
+        gx, gw = torch.autograd.grad(y, [x, w], gy)
+        for tag, t in (("y", y), ("gx", gx), ("gw", gw)):
+            sample, proj, norm = wide_digest(t, 17)
+            blob[f"{name}.{tag}.sample"], blob[f"{name}.{tag}.proj"], blob[f"{name}.{tag}.norm"] = sample, proj, np.array(norm)
+        blob[name + ".meta"] = np.array([N, Cin, H, W, Cout, k, s, p, int(kind == "convt")], np.int64)
+    np.savez_compressed(os.path.join(out, "wide_ops.npz"), **blob)
+    print("wide_ops.npz:", len(WIDE_CASES), "cases")
+
+
 # --------------------------------------------------------------------------------------------- traces
 class ConvTap:
     """Records (x, y, gy, gx) of every Conv2d / ConvTranspose2d call, in call order."""
@@ -589,8 +646,9 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "pix2pixhd_trace", "stylegan_trace", "biggan_trace"]
+    todo = a.only.split(",") if a.only else ["ops", "wide_ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "pix2pixhd_trace", "stylegan_trace", "biggan_trace"]
     if "ops" in todo: make_ops(a.out)
+    if "wide_ops" in todo: make_wide_ops(a.out)
     if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
     if "wgangp_trace" in todo: make_wgangp_trace(a.ref, a.out)
     if "dcgan_losses" in todo: make_dcgan_losses(a.ref, a.out)

@@ -329,3 +329,31 @@ def test_full_size_biggan_parameter_counts():
     from oracle import ref_biggan as Bg
     assert sum(p.numel() for p in Bg.Generator(n_classes=4, ch=64).parameters()) == 31859620
     assert sum(p.numel() for p in Bg.Discriminator(n_classes=4, ch=64).parameters()) == 39478034
+
+
+def test_c_oracle_on_full_width_layer_digests(golden_dir):
+    """The C restatement of the three passes on layers at the reference's full channel widths (the Pix2Pix U-Net bottom
+    and a BigGAN 1024 -> 1024 block; the larger spatial cases are left to the GPU test, the scalar C loops would take
+    minutes), against the digests of the reference's torch calls in wide_ops.npz."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    z = np.load(os.path.join(golden_dir, "wide_ops.npz"))
+    for case in mk.WIDE_CASES:
+        name, kind, N, Cin, H, W, Cout, k, s, p = case
+        if not (name.startswith("p2p_") or name == "biggan_1024_8x8"):
+            continue
+        x, w, gy = (t.numpy() for t in mk.wide_inputs(case))
+        if kind == "conv":
+            got = {"y": oracle.conv2d_fprop(x, w, None, s, p), "gx": oracle.conv2d_dgrad(gy, w, x.shape, s, p),
+                   "gw": oracle.conv2d_wgrad(x, gy, w.shape, s, p)}
+        else:
+            got = {"y": oracle.conv2d_dgrad(x, w, gy.shape, s, p), "gx": oracle.conv2d_fprop(gy, w, None, s, p),
+                   "gw": oracle.conv2d_wgrad(gy, x, w.shape, s, p)}
+        for tag, t in got.items():
+            sample, proj, norm = mk.wide_digest(torch.from_numpy(np.ascontiguousarray(t)), 17)
+            want_n = float(z[f"{name}.{tag}.norm"])
+            err = np.linalg.norm(sample - z[f"{name}.{tag}.sample"]) / np.linalg.norm(z[f"{name}.{tag}.sample"])
+            assert err < 2e-5, (name, tag, err)
+            assert np.all(np.abs(proj - z[f"{name}.{tag}.proj"]) < 1e-4 * want_n), (name, tag)
