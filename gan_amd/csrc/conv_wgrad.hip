@@ -8,6 +8,7 @@
 // the splits in a fixed order, scales, and scatters into the caller's [Cout][Cin][kh][kw] layout -- bitwise
 // reproducible, no float atomics.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "conv_wgrad.h"
 
@@ -227,11 +228,14 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
 }
 
 // Sums the split-K partials in a fixed order, scales and scatters into the caller's weight-gradient layout.
-// Workgroup = 64 runs of V consecutive partial elements x 4 split lanes; each lane keeps four loads in flight.
+// Workgroup = 64 runs of V consecutive partial elements x SL split lanes (SL = waves of the launch: 4, or 16 for the
+// many short slabs of a thin layer, whose few output elements would otherwise each wait for a long serial sum); each lane
+// keeps four loads in flight.
 template <int V>
-__global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const WgradReduceParams p) {
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReduceParams p) {
   typedef float vec_t __attribute__((ext_vector_type(V)));
-  __shared__ vec_t red[kThreads];
+  __shared__ vec_t red[1024];
+  const int SL = blockDim.x >> 6;
   const int T = p.kh * p.kw;
   const int inner = p.thin ? p.ICp : p.Cin;
   const size_t total = (size_t)T * p.Cout * inner;      // elements of one partial slab
@@ -241,19 +245,20 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const WgradReduc
   if (e0 < total) {
     const float* src = p.part + e0;
     int sp = sl;
-    for (; sp + 12 < p.splits; sp += 16) {
+    for (; sp + 3 * SL < p.splits; sp += 4 * SL) {
       const vec_t v0 = *reinterpret_cast<const vec_t*>(src + (size_t)sp * total);
-      const vec_t v1 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 4) * total);
-      const vec_t v2 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 8) * total);
-      const vec_t v3 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 12) * total);
+      const vec_t v1 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + SL) * total);
+      const vec_t v2 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 2 * SL) * total);
+      const vec_t v3 = *reinterpret_cast<const vec_t*>(src + (size_t)(sp + 3 * SL) * total);
       sum += (v0 + v1) + (v2 + v3);
     }
-    for (; sp < p.splits; sp += 4) sum += *reinterpret_cast<const vec_t*>(src + (size_t)sp * total);
+    for (; sp < p.splits; sp += SL) sum += *reinterpret_cast<const vec_t*>(src + (size_t)sp * total);
   }
   red[threadIdx.x] = sum;
   __syncthreads();
   if (sl != 0 || e0 >= total) return;
-  sum = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192];
+  sum = red[threadIdx.x];
+  for (int w = 1; w < SL; w++) sum += red[threadIdx.x + 64 * w];      // fixed order
 #pragma unroll
   for (int q = 0; q < V; q++) {
     const size_t e = e0 + q;
@@ -374,7 +379,8 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
     }
     // 256 output channels per tile (fewer bytes into LDS per FLOP) where that does not multiply the partial sums:
     // long reductions, or weights with enough tiles to fill the chip anyway
-    if (p.Cout % 256 == 0 && (p.K >= 65536 || (long)(p.Cout / 256) * p.n_ci_tiles * p.n_tap_groups >= 256)) l.to = 256;
+    static const int force256 = getenv("GC_WGRAD_TO256") ? atoi(getenv("GC_WGRAD_TO256")) : 0;
+    if (p.Cout % 256 == 0 && (force256 || p.K >= 65536 || (long)(p.Cout / 256) * p.n_ci_tiles * p.n_tap_groups >= 256)) l.to = 256;
   } else if (p.thin) {
     p.ICp = 4;
     while (p.ICp < p.Cin) p.ICp *= 2;
@@ -390,7 +396,8 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
   const long tiles = (long)p.n_co_tiles * p.n_ci_tiles * (p.thin ? 1 : p.n_tap_groups);
   if (p.K <= 0) { p.k_per_split = kWBK; p.splits = 1; return; }
   // enough splits for about two workgroups per CU, each split at least 8 reduction steps long
-  long want = (2 * 256 + tiles - 1) / tiles;
+  static const int wg_target = getenv("GC_WGRAD_WGS") ? atoi(getenv("GC_WGRAD_WGS")) : 512;
+  long want = (wg_target + tiles - 1) / tiles;
   const long max_splits = (p.K + 8 * kWBK - 1) / (8 * kWBK);
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
@@ -449,10 +456,12 @@ int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
   }
   if (total % 4 == 0) {   // slabs stay 16-byte aligned: 4 elements per lane
     const size_t blocks = (total / 4 + 63) / 64;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+    const unsigned threads = (p.splits >= 64 && blocks * 16 <= 4096) ? 1024u : (unsigned)kThreads;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, stream, p);
   } else {
     const size_t blocks = (total + 63) / 64;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+    const unsigned threads = (p.splits >= 64 && blocks * 16 <= 4096) ? 1024u : (unsigned)kThreads;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(threads), 0, stream, p);
   }
   return check_hip(hipGetLastError(), "wgrad_reduce launch");
 }

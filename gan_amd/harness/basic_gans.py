@@ -166,7 +166,7 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
         if not weight_gradient_sink:
             return torch.autograd.grad(out, params, grad_outputs=seed)
         bufs = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params]
-        with gops.weight_gradient_sink(params, bufs, fork=fork) as sink:
+        with gops.weight_gradient_sink(params, bufs, fork=fork) as sink, gops.parameter_gradients_only():
             rest = torch.autograd.grad(out, params, grad_outputs=seed, allow_unused=True)
         grads = []
         for p, b, r in zip(params, bufs, rest):
@@ -272,7 +272,8 @@ def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_bac
     penalty = _penalty(net_D, real, fake, epsilon, c_lambda)
     if on_last_backward is not None:
         on_last_backward()
-    penalty.backward()
+    with gops.parameter_gradients_only():      # (the mixed images are leaves that require grad; nobody reads their .grad)
+        penalty.backward()
     return d_real.detach(), d_fake.detach(), penalty.detach()
 
 

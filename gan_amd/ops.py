@@ -690,6 +690,25 @@ def _edges(*ts):
 
 
 _inputs_only = False
+_skip_leaf_inputs = False
+
+
+class parameter_gradients_only:
+    """While active, the convolution backward formulas compute no gradient with respect to an activation operand that
+    is a leaf of the autograd graph (an input image marked requires_grad).  For torch.autograd.grad(loss, parameters)
+    behind a gradient penalty: the mixed images were differentiated by in the first pass and are leaves that require
+    grad, so the second pass would run the first layer's data-gradient kernel for a gradient nobody asked for (the engine
+    cannot be asked about leaves).  Process-wide like input_gradients_only."""
+
+    def __enter__(self):
+        global _skip_leaf_inputs
+        self.prev, _skip_leaf_inputs = _skip_leaf_inputs, True
+        return self
+
+    def __exit__(self, *exc):
+        global _skip_leaf_inputs
+        _skip_leaf_inputs = self.prev
+        return False
 
 
 class input_gradients_only:
@@ -720,7 +739,7 @@ def _wanted(ctx, i):
         return False
     node = ctx.edges[i]
     if node is None:
-        return True
+        return not (_skip_leaf_inputs and i == 0)
     try:
         return torch._C._will_engine_execute_node(node)
     except RuntimeError:          # no information
