@@ -92,11 +92,9 @@ class Linear(torch.nn.Linear):
 def _batchnorm_relu(bn, x, gain, shift):
     """relu(gain * BatchNorm(x) + shift); gain / shift: [C] parameters or per-sample [N, C] tensors."""
     if _opt["fused_norm"] and bn.training and x.shape[1] % 4 == 0:
-        y, mean, _, var = ops.batchnorm_act(x, gain, shift, bn.running_mean, bn.running_var, True, float(bn.eps), 1, 0.0)
-        if bn.track_running_stats:
-            with torch.no_grad():
-                ops.batchnorm_update_running_(bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, var, float(bn.momentum))
-        return y
+        track = bn.track_running_stats
+        return ops.batchnorm_act_train(x, gain, shift, bn.running_mean if track else None, bn.running_var if track else None,
+                                       bn.num_batches_tracked if track else None, bn.momentum, bn.eps, 1, 0.0)
     if gain.dim() == 2:
         gain, shift = gain[:, :, None, None], shift[:, :, None, None]
         return torch.relu(gain.to(x.dtype) * bn(x) + shift.to(x.dtype))

@@ -196,13 +196,15 @@ class BatchNormAct2d(torch.nn.Module):
             return torch.nn.functional.leaky_relu(y, self.negative_slope) if act == 2 else y
         if training and self.sync_stats:
             y, mean, var = ops.sync_batchnorm_act(input, self.weight, self.bias, self.eps, act, self.negative_slope, self.process_group)
-        else:
-            y, mean, _, var = ops.batchnorm_act(input, self.weight, self.bias, self.running_mean, self.running_var, training,
-                                                float(self.eps), act, float(self.negative_slope))
-        if training and self.track_running_stats:
-            with torch.no_grad():
-                ops.batchnorm_update_running_(self.running_mean, self.running_var, self.num_batches_tracked, mean, var, float(self.momentum))
-        return y
+            if self.track_running_stats:
+                with torch.no_grad():
+                    ops.batchnorm_update_running_(self.running_mean, self.running_var, self.num_batches_tracked, mean, var, float(self.momentum))
+            return y
+        if training:      # (the running statistics are updated by the forward pass's own launches)
+            return ops.batchnorm_act_train(input, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
+                                           self.momentum, self.eps, act, self.negative_slope)
+        return ops.batchnorm_act(input, self.weight, self.bias, self.running_mean, self.running_var, False, float(self.eps), act,
+                                 float(self.negative_slope))[0]
 
     def extra_repr(self):
         return (f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine={self.affine}, "

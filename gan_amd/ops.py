@@ -1015,12 +1015,9 @@ def _cond_affine(weight, bias, N, C):
     return weight.float().contiguous(), bias.float().contiguous()
 
 
-@torch.library.custom_op("ganconv::batchnorm_act", mutates_args=())
-def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
-                  running_var: Optional[Tensor], training: bool, eps: float, act: int, slope: float) -> tuple[Tensor, Tensor, Tensor, Tensor]:
-    """act(batch_norm(x)) with torch.nn.BatchNorm2d semantics.  training: batch statistics; otherwise the running
-    ones (read only).  Returns (y, mean, rstd, unbiased variance); the caller folds the last two into its running
-    statistics with batchnorm_update_running_."""
+def _bn_forward_launch(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, training, eps, act, slope):
+    """One fused forward: (y, mean, rstd, unbiased variance).  Training mode with running buffers given: the finalize
+    kernel also folds the batch statistics into them (momentum) and counts the batch."""
     _check_cuda(x, weight, bias, running_mean, running_var)
     x = _nhwc(x)
     N, C, H, W = x.shape
@@ -1029,19 +1026,31 @@ def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], r
     y = torch.empty_like(x, memory_format=torch.channels_last)
     mean, rstd, var = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(3))
     L = _lib.lib()
-    rm, rv = (None, None) if training else (running_mean, running_var)
     if weight is not None and weight.dim() == 2:     # conditional: gain and bias per sample and channel
         weight, bias = _cond_affine(weight, bias, N, C)
         ws = torch.empty(max(L.gc_cond_batchnorm_workspace_bytes(N, H * W, C), 16), dtype=torch.uint8, device=x.device)
-        _lib.check(L.gc_cond_batchnorm_act_fwd(_ptr(x), _ptr(y), _ptr(weight), _ptr(bias), _optr(rm), _optr(rv), None, _ptr(mean),
-                                               _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), N, H * W, C, dt, eps, 0.0, act, slope,
-                                               1 if training else 0, _stream()), "gc_cond_batchnorm_act_fwd")
+        _lib.check(L.gc_cond_batchnorm_act_fwd(_ptr(x), _ptr(y), _ptr(weight), _ptr(bias), _optr(running_mean), _optr(running_var),
+                                               _optr(num_batches_tracked), _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), N,
+                                               H * W, C, dt, eps, momentum, act, slope, 1 if training else 0, _stream()),
+                   "gc_cond_batchnorm_act_fwd")
         return y, mean, rstd, var
     ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
-    _lib.check(L.gc_batchnorm_act_fwd(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _optr(rm), _optr(rv), None,
-                                      _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws), ws.numel(), P, C, dt, eps, 0.0, act, slope,
-                                      1 if training else 0, _stream()), "gc_batchnorm_act_fwd")
+    _lib.check(L.gc_batchnorm_act_fwd(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _optr(running_mean),
+                                      _optr(running_var), _optr(num_batches_tracked), _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws),
+                                      ws.numel(), P, C, dt, eps, momentum, act, slope, 1 if training else 0, _stream()),
+               "gc_batchnorm_act_fwd")
     return y, mean, rstd, var
+
+
+@torch.library.custom_op("ganconv::batchnorm_act", mutates_args=())
+def batchnorm_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
+                  running_var: Optional[Tensor], training: bool, eps: float, act: int, slope: float) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """act(batch_norm(x)) with torch.nn.BatchNorm2d semantics.  training: batch statistics; otherwise the running
+    ones (read only).  Returns (y, mean, rstd, unbiased variance); the running statistics are never written here (a
+    caller folds the last two into them with batchnorm_update_running_, or uses batchnorm_act_train, which does it
+    inside the same launches)."""
+    rm, rv = (None, None) if training else (running_mean, running_var)
+    return _bn_forward_launch(x, weight, bias, rm, rv, None, 0.0, training, eps, act, slope)
 
 
 @batchnorm_act.register_fake
@@ -1097,6 +1106,7 @@ def _(x, gy, weight, bias, mean, rstd, act, slope):
 
 
 def _bn_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)      # no zero tensors for the statistics outputs, whose gradients are ignored
     x, weight, bias, _, _, training, _, act, slope = inputs
     if not training:
         raise RuntimeError("ganconv: batchnorm_act is differentiable in training mode only")
@@ -1108,6 +1118,8 @@ def _bn_setup(ctx, inputs, output):
 def _bn_backward(ctx, gy, g_mean, g_rstd, g_var):
     x, weight, bias, mean, rstd = ctx.saved_tensors
     # (mean / rstd are returned for the backward pass only; gradients arriving at them are ignored)
+    if gy is None:
+        return (None,) * 9
     if gy.requires_grad and torch.is_grad_enabled():
         raise RuntimeError("ganconv: batchnorm_act has no second-order backward")
     gx, gw, gb = batchnorm_act_bwd(x, gy, weight, bias, mean, rstd, *ctx.cfg)
@@ -1115,6 +1127,33 @@ def _bn_backward(ctx, gy, g_mean, g_rstd, g_var):
 
 
 torch.library.register_autograd("ganconv::batchnorm_act", _bn_backward, setup_context=_bn_setup)
+
+
+class _BatchNormActTrain(torch.autograd.Function):
+    """Training-mode batchnorm_act that also updates the running statistics in place, in the launches of the forward
+    pass (an operator registered through torch.library may not both mutate an argument and carry an autograd formula)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, act, slope):
+        y, mean, rstd, _ = _bn_forward_launch(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, True, eps, act, slope)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        if gy.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("ganconv: batchnorm_act has no second-order backward")
+        gx, gw, gb = batchnorm_act_bwd(x, gy, weight, bias, mean, rstd, *ctx.cfg)
+        return gx, gw if weight is not None else None, gb if bias is not None else None, None, None, None, None, None, None, None
+
+
+def batchnorm_act_train(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, act, slope):
+    """act(batch_norm(x)) on batch statistics; running_mean / running_var / num_batches_tracked (all or none) are updated
+    as torch.nn.BatchNorm2d updates them.  weight / bias: [C] parameters, per-sample [N, C] gains and shifts, or None."""
+    return _BatchNormActTrain.apply(x, weight, bias, running_mean, running_var, num_batches_tracked, float(momentum), float(eps),
+                                    int(act), float(slope))
 
 
 # ---- BatchNorm with statistics over all ranks of a process group ---------------------------------------------------
@@ -1256,11 +1295,14 @@ def _(k, q, v, out, dout, lse):
 
 
 def _attn_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)      # (no zero tensor for the log-sum-exp output, whose gradient is ignored)
     ctx.save_for_backward(*inputs, *output)
 
 
 def _attn_backward(ctx, g_out, g_lse):
     k, q, v, out, lse = ctx.saved_tensors
+    if g_out is None:
+        return None, None, None
     if g_out.requires_grad and torch.is_grad_enabled():
         raise RuntimeError("ganconv: attention has no second-order backward")
     return attention_bwd(k, q, v, out, g_out, lse)
@@ -1418,6 +1460,7 @@ def _(x, noise, sf, ys, yb, mu, r, gout, slope):
 
 
 def _adain_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)      # (no zero tensors for the statistics outputs, whose gradients are ignored)
     x, noise, sf, ys, yb, _, slope = inputs
     ctx.save_for_backward(x, noise, sf, ys, yb, output[1], output[2])
     ctx.slope = slope
@@ -1425,6 +1468,8 @@ def _adain_setup(ctx, inputs, output):
 
 def _adain_backward(ctx, gout, g_mu, g_r):
     x, noise, sf, ys, yb, mu, r = ctx.saved_tensors
+    if gout is None:
+        return (None,) * 7
     if gout.requires_grad and torch.is_grad_enabled():
         raise RuntimeError("ganconv: noise_lrelu_adain has no second-order backward")
     gx, g_sf, g_ys, g_yb = noise_lrelu_adain_bwd(x, noise, sf, ys, yb, mu, r, gout, ctx.slope)
@@ -1513,11 +1558,14 @@ def _(gradient, coef, g_penalty):
 
 
 def _gp_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(inputs[0], output[2])
 
 
 def _gp_backward(ctx, g_penalty, g_norms, g_coef):
     gradient, coef = ctx.saved_tensors
+    if g_penalty is None:
+        return None, None
     return gradient_penalty_bwd(gradient, coef, g_penalty), None
 
 

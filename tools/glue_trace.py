@@ -12,17 +12,23 @@ import gan_amd  # noqa: E402
 from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs  # noqa: E402
 
 gan_amd.set_precision("bf16")
-tr = WganGpTrainer(256, 64, 100, 64, device="cuda:0", batch_real_fake=True, fused_adam=True, activation_dtype=torch.bfloat16,
-                   two_streams=False)
-tr.reps = int(os.environ.get("REPS", "1"))
-gen = torch.Generator().manual_seed(5001)
-real, zs = synth_inputs(gen, 256, 100, 64, 6)
-tr.set_inputs(real, zs, torch.rand(5, 256, 1, 1, 1, generator=gen))
+family = sys.argv[1] if len(sys.argv) > 1 else "wgan"      # wgan | dcgan64_b128 | pix2pix256_b8 | stylegan256_b32
+if family == "wgan":
+    tr = WganGpTrainer(256, 64, 100, 64, device="cuda:0", batch_real_fake=True, fused_adam=True, activation_dtype=torch.bfloat16,
+                       two_streams=False)
+    tr.reps = int(os.environ.get("REPS", "1"))
+    gen = torch.Generator().manual_seed(5001)
+    real, zs = synth_inputs(gen, 256, 100, 64, 6)
+    tr.set_inputs(real, zs, torch.rand(5, 256, 1, 1, 1, generator=gen))
+    step = tr.cycle_eager
+else:
+    from gan_amd.harness import steps
+    step = steps.FAMILIES[family]("cuda:0")[0]
 for _ in range(2):
-    tr.cycle_eager()
+    step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    tr.cycle_eager()
+    step()
     torch.cuda.synchronize()
 evs = prof.events()
 kernels = [e for e in evs if e.device_type == torch.autograd.DeviceType.CUDA]
