@@ -58,6 +58,7 @@ def cpu_baseline(threads):
 def families(device, steps=8):
     """{name: {"img_per_s", "ms_per_step", "batch", "what"}} for the steps of gan_amd.harness.steps, each one HIP graph."""
     import gan_amd
+    from gan_amd import _lib
     from gan_amd.harness import steps as S
     out = {}
     for name, make in S.FAMILIES.items():
@@ -73,6 +74,21 @@ def families(device, steps=8):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
             out[name] = {"img_per_s": batch / dt, "ms_per_step": 1e3 * dt, "batch": batch, "what": what, "hip_graph": True}
+            # one eager pass with the library's event timer: algorithmic conv FLOPs of a step and the dominant conv kernel
+            _lib.profile_enable(True)
+            step()
+            torch.cuda.synchronize()
+            prof = _lib.profile_collect()
+            _lib.profile_enable(False)
+            conv = {k: v for k, v in prof.items() if v["flops"] > 0}
+            if conv:
+                dom = max(conv, key=lambda k: conv[k]["total_ms"])
+                tf = conv[dom]["flops"] / (conv[dom]["total_ms"] * 1e-3) / 1e12
+                flops = sum(v["flops"] for v in conv.values())
+                out[name].update({"dominant_kernel": dom, "dominant_kernel_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS,
+                                  "conv_gflop_per_step": flops / 1e9, "step_tflops": flops / dt / 1e12,
+                                  "library_kernel_ms_per_step": sum(v["total_ms"] for v in prof.values()),
+                                  "hbm_gb_s": None})      # (no byte counters in this run: rocprofv3 --pmc passes are separate)
             del g, step
         except Exception as e:      # a family that fails does not take the headline line with it
             out[name] = {"error": repr(e)}

@@ -442,7 +442,8 @@ int launch_one(const WsParams& p, int grid, double flops, hipStream_t stream) {
   });
   if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
   char name[96];
-  snprintf(name, sizeof(name), "gc::conv_gather_ws_kernel<%s, %d, %d>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, STAGES);
+  snprintf(name, sizeof(name), "gc::conv_gather_ws_kernel<%s, %d, %d, %s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, STAGES,
+           MASK ? "true" : "false");
   static const bool stamps = getenv("GC_DIAG_STAMPS") != nullptr;
   if (stamps) {   // diagnostic: synchronous launches with cycle stamps per workgroup, summary on stderr
     static unsigned long long* dbuf = nullptr;
