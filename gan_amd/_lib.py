@@ -22,6 +22,7 @@ EXPORTS = (
     "gc_instnorm_act_fwd", "gc_instnorm_act_bwd", "gc_instnorm_act_bwd_bwd",
     "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_channel_sum_workspace_bytes", "gc_channel_sum", "gc_act_backward_channel_sum", "gc_batchnorm_stats", "gc_batchnorm_act_bwd_sums", "gc_batchnorm_act_bwd_apply", "gc_adam_step", "gc_adam_ema_step", "gc_set_split_reduction", "gc_set_patch_kernel", "gc_pack_weights", "gc_attention_fwd", "gc_attention_bwd", "gc_pool2x2", "gc_replicate2x", "gc_reflect_pad", "gc_reflect_pad_adjoint",
     "gc_cond_batchnorm_workspace_bytes", "gc_cond_batchnorm_act_fwd", "gc_cond_batchnorm_act_bwd", "gc_noise_lrelu_adain_workspace_bytes", "gc_noise_lrelu_adain_fwd", "gc_noise_lrelu_adain_bwd",
+    "gc_wgrad_multi_workspace_bytes", "gc_conv2d_wgrad_multi",
     "gc_wgan_mix", "gc_gradient_penalty_workspace_bytes", "gc_gradient_penalty_fwd", "gc_gradient_penalty_bwd", "gc_wgan_critic_loss",
 )
 
@@ -89,6 +90,9 @@ def lib():
     L.gc_cond_batchnorm_act_bwd.argtypes = [vp] * 10 + [sz, i32, i32, i32, i32, i32, f32, vp]
     L.gc_batchnorm_update_running.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp]
     L.gc_batchnorm_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, i32, f32, vp]
+    L.gc_wgrad_multi_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc), i32, vp]
+    L.gc_wgrad_multi_workspace_bytes.restype = sz
+    L.gc_conv2d_wgrad_multi.argtypes = [ctypes.POINTER(ConvDesc), i32, vp, vp, vp, vp, i64p, f32, ctypes.c_int, vp, sz, vp]
     L.gc_wgan_mix.argtypes = [vp, vp, vp, vp, i32, i64, vp]
     L.gc_gradient_penalty_workspace_bytes.argtypes = [i32, i64]
     L.gc_gradient_penalty_workspace_bytes.restype = sz

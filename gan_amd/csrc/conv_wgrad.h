@@ -4,6 +4,8 @@
 
 namespace gc {
 
+constexpr int kMaxWgradSegments = 4;
+
 struct WgradParams {
   const void* x;    // [N, H, W, x_cstride]
   const void* gy;   // [N, Ho, Wo, y_cstride]
@@ -19,7 +21,38 @@ struct WgradParams {
   int32_t n_tap_groups, tpt, cw_log2;   // LDS-DMA kernel: a 128-column tile holds tpt taps of (1 << cw_log2) channels
   FastDiv div_wo, div_ho;
   int64_t x_bytes, y_bytes;   // extents of x and gy (buffer ranges of the LDS-DMA kernel)
+  // Several (x, gy) pairs of one layer reduced into one gradient (the passes of a training phase that all add to the
+  // same weight gradient): n_seg > 1, segment g owns the splits seg_split0[g] .. seg_split0[g + 1] - 1 and K = seg_K[g].
+  int32_t n_seg;
+  int32_t seg_K[kMaxWgradSegments];
+  int32_t seg_split0[kMaxWgradSegments];
+  const void* seg_x[kMaxWgradSegments];
+  const void* seg_gy[kMaxWgradSegments];
+  int64_t seg_x_bytes[kMaxWgradSegments], seg_y_bytes[kMaxWgradSegments];
 };
+
+// The tensors and the pixel range a workgroup of split `split` reduces over.
+struct WgradRange {
+  const void* x;
+  const void* gy;
+  int64_t x_bytes, y_bytes;
+  int kb0, kend;
+};
+__device__ __forceinline__ WgradRange wgrad_range(const WgradParams& p, int split) {
+  WgradRange r{p.x, p.gy, p.x_bytes, p.y_bytes, split * p.k_per_split, 0};
+  int K = p.K;
+  if (p.n_seg > 1) {
+#pragma unroll
+    for (int g = 0; g < kMaxWgradSegments; g++)      // (static indices: the argument block is read at fixed offsets)
+      if (g < p.n_seg && split >= p.seg_split0[g]) {
+        r.x = p.seg_x[g]; r.gy = p.seg_gy[g]; r.x_bytes = p.seg_x_bytes[g]; r.y_bytes = p.seg_y_bytes[g];
+        r.kb0 = (split - p.seg_split0[g]) * p.k_per_split;
+        K = p.seg_K[g];
+      }
+  }
+  r.kend = min(K, r.kb0 + p.k_per_split);
+  return r;
+}
 
 struct WgradLaunch {
   int to, tc;

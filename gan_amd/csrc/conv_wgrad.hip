@@ -50,11 +50,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
   const int tap = (int)(lid % ntaps), r = tap / p.kw, s = tap % p.kw;
   const int split = (int)(lid / ntaps);
   const int co0 = (tile / p.n_ci_tiles) * TO, ci0 = (tile % p.n_ci_tiles) * TC;
-  const int kb0 = split * p.k_per_split;
-  const int kend = min(p.K, kb0 + p.k_per_split);
+  const WgradRange rg = wgrad_range(p, split);
+  const int kb0 = rg.kb0, kend = rg.kend;
 
-  const T* gy = reinterpret_cast<const T*>(p.gy);
-  const T* x = reinterpret_cast<const T*>(p.x);
+  const T* gy = reinterpret_cast<const T*>(rg.gy);
+  const T* x = reinterpret_cast<const T*>(rg.x);
   const int cy = t % CPRY, cx = t % CPRX;
 
   u32x4 yreg[PY], xreg[PX];

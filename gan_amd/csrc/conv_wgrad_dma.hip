@@ -62,14 +62,14 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
   const int split = (int)(lid / ngroups);
   const int co0 = (tile / p.n_ci_tiles) * TO, ci0 = (tile % p.n_ci_tiles) * kTC;
   const int T = p.kh * p.kw;
-  const int kb0 = split * p.k_per_split;
-  const int kend = min(p.K, kb0 + p.k_per_split);
+  const WgradRange rg = wgrad_range(p, split);
+  const int kb0 = rg.kb0, kend = rg.kend;
 
   // Buffer addressing: a lane whose source is padding, past the channel count or past the last pixel uses an
   // offset beyond the buffer's range and receives zeros.  Both tensors are below 2 GiB (checked by the planner).
   constexpr uint32_t kOutOfRange = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gy), 0, (int)p.y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(rg.gy), 0, (int)rg.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(rg.x), 0, (int)rg.x_bytes, 0x00020000);
 
   // ---- per-lane source geometry (fixed over the steps except for the pixel index)
   // gy: wave-instruction j of this wave covers tile rows (wave*YJ + j)*RPIY .. ; lane / CPRY picks the row

@@ -602,23 +602,47 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
   return need;
 }
 
-int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float* gw, const int64_t gw_strides[4], float alpha,
-                    int accumulate, float* gbias, void* workspace, size_t workspace_bytes, void* stream) {
+// Splits per segment for a plan made on the summed reduction length: every segment keeps the plan's k_per_split.
+static void wgrad_split_segments(WgradParams& p, int32_t n_seg, const int32_t* Ns, int pix_per_sample) {
+  p.n_seg = n_seg;
+  int splits = 0;
+  for (int g = 0; g < n_seg; g++) {
+    p.seg_K[g] = Ns[g] * pix_per_sample;
+    p.seg_split0[g] = splits;
+    splits += (p.seg_K[g] + p.k_per_split - 1) / p.k_per_split;
+  }
+  p.splits = splits;
+}
+
+static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs, const void* const* gys, const int32_t* Ns, float* gw,
+                     const int64_t gw_strides[4], float alpha, int accumulate, float* gbias, void* workspace, size_t workspace_bytes,
+                     void* stream, const char* who) {
   int rc = validate(d);
   if (rc != GC_OK) return rc;
-  if (x == nullptr || gy == nullptr || gw == nullptr || gw_strides == nullptr) { set_error("gc_conv2d_wgrad: null pointer"); return GC_BAD_ARGUMENT; }
+  bool al = true;
+  for (int g = 0; g < n_seg; g++) {
+    if (xs[g] == nullptr || gys[g] == nullptr) { set_error("%s: null pointer", who); return GC_BAD_ARGUMENT; }
+    al = al && aligned16(xs[g]) && aligned16(gys[g]);
+  }
+  if (gw == nullptr || gw_strides == nullptr) { set_error("%s: null pointer", who); return GC_BAD_ARGUMENT; }
   WgradParams p; WgradLaunch l;
-  wgrad_setup(d, p, l, aligned16(x) && aligned16(gy));
+  wgrad_setup(d, p, l, al);
+  if (n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
   const size_t need = wgrad_need(d, p);
   if (workspace == nullptr || workspace_bytes < need) {
-    set_error("gc_conv2d_wgrad: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    set_error("%s: workspace of %zu bytes given, %zu needed", who, workspace_bytes, need);
     return GC_WORKSPACE_TOO_SMALL;
   }
-  if (!aligned16(workspace)) { set_error("gc_conv2d_wgrad: workspace must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
-  p.x = x; p.gy = gy; p.part = (float*)workspace;
+  if (!aligned16(workspace)) { set_error("%s: workspace must be 16-byte aligned", who); return GC_BAD_ARGUMENT; }
+  p.x = xs[0]; p.gy = gys[0]; p.part = (float*)workspace;
+  for (int g = 0; g < n_seg && n_seg > 1; g++) {
+    p.seg_x[g] = xs[g]; p.seg_gy[g] = gys[g];
+    p.seg_x_bytes[g] = (int64_t)Ns[g] * d->H * d->W * p.x_cstride * 2;
+    p.seg_y_bytes[g] = (int64_t)p.seg_K[g] * p.y_cstride * 2;
+  }
   const int epc = elems_per_chunk(d->x_dtype);
-  const bool x_vec = aligned16(x) && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0);
-  const bool y_vec = aligned16(gy) && (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
+  const bool x_vec = al && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0);
+  const bool y_vec = al && (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
   // thin input: the template flag is about the gy side (the x side always takes element loads); otherwise it is about the
   // x side, and a gy side with an odd channel count (1- and 3-channel outputs) takes element loads inside that kernel
   l.aligned = p.thin ? y_vec : x_vec;
@@ -636,9 +660,57 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   }
   if (gbias != nullptr) {
     ProfScope ps("gc::colsum_kernel", 0.0, (hipStream_t)stream);
-    if ((rc = launch_colsum(gy, gbias, p.K, d->Cout, p.y_cstride, p.y_coff, l.bf16, (hipStream_t)stream)) != GC_OK) return rc;
+    if ((rc = launch_colsum(gys[0], gbias, p.K, d->Cout, p.y_cstride, p.y_coff, l.bf16, (hipStream_t)stream)) != GC_OK) return rc;
   }
   return GC_OK;
+}
+
+int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float* gw, const int64_t gw_strides[4], float alpha,
+                    int accumulate, float* gbias, void* workspace, size_t workspace_bytes, void* stream) {
+  if (d == nullptr) { set_error("gc_conv2d_wgrad: null descriptor"); return GC_BAD_ARGUMENT; }
+  const int32_t n = d->N;
+  return wgrad_run(d, 1, &x, &gy, &n, gw, gw_strides, alpha, accumulate, gbias, workspace, workspace_bytes, stream, "gc_conv2d_wgrad");
+}
+
+static int multi_desc(const gc_conv_desc* d, int32_t n_seg, const int32_t* Ns, gc_conv_desc* total, const char* who) {
+  if (d == nullptr || Ns == nullptr || n_seg < 1 || n_seg > kMaxWgradSegments) {
+    set_error("%s: 1 to %d segments", who, kMaxWgradSegments);
+    return GC_BAD_ARGUMENT;
+  }
+  *total = *d;
+  long sum = 0;
+  for (int g = 0; g < n_seg; g++) {
+    if (Ns[g] <= 0) { set_error("%s: every segment needs at least one sample", who); return GC_BAD_ARGUMENT; }
+    sum += Ns[g];
+  }
+  if (sum >= (1l << 31)) { set_error("%s: too many samples", who); return GC_UNSUPPORTED_GEOMETRY; }
+  total->N = (int32_t)sum;
+  return GC_OK;
+}
+
+size_t gc_wgrad_multi_workspace_bytes(const gc_conv_desc* d, int32_t n_seg, const int32_t* Ns) {
+  gc_conv_desc t;
+  if (multi_desc(d, n_seg, Ns, &t, "gc_wgrad_multi_workspace_bytes") != GC_OK || validate(&t) != GC_OK) return 0;
+  size_t need = 0;
+  for (int dma = 0; dma < 2; dma++) {      // the call knows the alignment, the query covers both plans
+    WgradParams p; WgradLaunch l;
+    wgrad_setup(&t, p, l, dma != 0);
+    if (n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
+    const size_t b = wgrad_need(&t, p);
+    if (b > need) need = b;
+  }
+  return need;
+}
+
+int gc_conv2d_wgrad_multi(const gc_conv_desc* d, int32_t n_seg, const void* const* xs, const void* const* gys, const int32_t* Ns,
+                          float* gw, const int64_t gw_strides[4], float alpha, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  gc_conv_desc t;
+  int rc = multi_desc(d, n_seg, Ns, &t, "gc_conv2d_wgrad_multi");
+  if (rc != GC_OK) return rc;
+  if (xs == nullptr || gys == nullptr) { set_error("gc_conv2d_wgrad_multi: null pointer"); return GC_BAD_ARGUMENT; }
+  return wgrad_run(&t, n_seg, xs, gys, Ns, gw, gw_strides, alpha, accumulate, nullptr, workspace, workspace_bytes, stream,
+                   "gc_conv2d_wgrad_multi");
 }
 
 // ---- the entry point that allocates nothing -----------------------------------------------------------------------

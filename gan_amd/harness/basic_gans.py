@@ -96,15 +96,15 @@ def _side_stream(device, i):
 # Which scalar parts of a critic iteration run as single launches of the library on a GPU (the others, and everything
 # on the CPU, as the reference's tensor expressions; narrowing the set is an A/B aid).
 fused_scalars = {"mix", "ones", "penalty", "loss"}
-# The streamed critic iteration collects weight gradients through gan_amd.ops.weight_gradient_sink (those of the penalty
-# chain on a stream of their own); False: autograd returns and accumulates them (A/B aid).
+# The streamed critic iteration collects its weight gradients through gan_amd.ops.weight_gradient_sink and reduces them
+# with one launch per layer after the chains have joined; False: autograd returns and accumulates them (A/B aid).
 weight_gradient_sink = True
-# Measured on the recorded benchmark cycle (tools/ab_bench.py --what flag): the sink itself is neutral (10.36 against
-# 10.44 ms); the penalty chain's weight-gradient kernels on a stream of their own cost 0.4 ms (a fork and an event wait
-# per launch inside the graph outweigh the overlap), so both switches below are off.
+# Measured on the recorded benchmark cycle (tools/ab_bench.py --what flag): which chain stays on the calling stream is
+# neutral; recording the forked chains after the calling stream's chain costs 0.3 ms (the graph runtime's
+# branch-to-queue assignment follows recording order); the penalty chain's weight-gradient kernels on a stream of
+# their own (ops.weight_gradient_sink(fork=True)) cost 0.4 ms, a fork and an event wait per launch outweigh the overlap.
 side_chains_first = True            # launch (and record) the forked chains before the calling stream's own chain
-sink_fork = False                   # the penalty chain's weight-gradient kernels on a stream of their own
-penalty_on_calling_stream = False   # True: the penalty chain on the calling stream (needed for sink_fork), the others fork
+penalty_on_calling_stream = False   # True: the penalty chain on the calling stream, the real / fake chains fork
 _ones = {}
 
 
@@ -160,43 +160,29 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
     main = torch.cuda.current_stream(real.device)
     B = real.shape[0]
 
-    def grads_of(out, seed, fork):
-        """d out / d params with the weight-gradient kernels writing into fresh buffers through a sink (`fork`: on a stream
-        of their own beside the calling one), or through autograd's own accumulation when the sink is switched off."""
-        if not weight_gradient_sink:
-            return torch.autograd.grad(out, params, grad_outputs=seed)
-        bufs = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params]
-        with gops.weight_gradient_sink(params, bufs, fork=fork) as sink, gops.parameter_gradients_only():
-            rest = torch.autograd.grad(out, params, grad_outputs=seed, allow_unused=True)
-        grads = []
-        for p, b, r in zip(params, bufs, rest):
-            if p.data_ptr() in sink.touched:
-                grads.append(b if r is None else b.add_(r))
-            elif r is None:
-                raise RuntimeError("a critic parameter received no gradient")
-            else:
-                grads.append(r)
-        return grads
+    def grads_of(out, seed):
+        """d out / d params as autograd returns them; inside the sink the convolution weights come back as None (their
+        gradients are collected by the sink)."""
+        with gops.parameter_gradients_only():      # (no data gradient for the mixed images, a leaf that requires grad)
+            return torch.autograd.grad(out, params, grad_outputs=seed, allow_unused=weight_gradient_sink)
 
     def penalty_chain():
         penalty = _penalty(net_D, real, fake, epsilon, c_lambda)
-        return grads_of(penalty, None, sink_fork and penalty_on_calling_stream), penalty.detach()
+        return grads_of(penalty, None), penalty.detach()
 
     def real_chain():
         d_real = net_D(real).view(-1)
         d_real = d_real.mean() - 0.001 * (d_real ** 2).mean()
-        return torch.autograd.grad(-d_real, params), d_real.detach()
+        return grads_of(-d_real, None), d_real.detach()
 
     def fake_chain():
         d_fake = net_D(fake).view(-1).mean()
-        return torch.autograd.grad(d_fake, params), d_fake.detach()
+        return grads_of(d_fake, None), d_fake.detach()
 
     def both_chain():
         d_real, d_fake, out, seed = _real_fake_loss(net_D(torch.cat([real, fake])), B)
-        return grads_of(out, seed, False), (d_real, d_fake)
+        return grads_of(out, seed), (d_real, d_fake)
 
-    # Only a chain on the calling stream can fork its weight-gradient kernels to a stream of their own: a chain that is
-    # itself on a forked stream cannot fork again inside a graph capture.
     rf_chains = [real_chain, fake_chain] if split_real_fake else [both_chain]
     side_chains = rf_chains if penalty_on_calling_stream else [penalty_chain] + rf_chains[1:]
     results = []
@@ -211,27 +197,50 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
                 with torch.cuda.stream(st):
                     results.append(chain())
 
-    if side_chains_first:
-        run_side_chains()
-    if penalty_on_calling_stream:
-        head = penalty_chain()
-    else:
-        with gops.suspended_backward_overlap():
-            head = rf_chains[0]()
-    if not side_chains_first:
-        run_side_chains()
-    results.insert(0 if penalty_on_calling_stream else 1, head)
+    def run_chains():
+        if side_chains_first:
+            run_side_chains()
+        if penalty_on_calling_stream:
+            head = penalty_chain()
+        else:
+            with gops.suspended_backward_overlap():
+                head = rf_chains[0]()
+        if not side_chains_first:
+            run_side_chains()
+        results.insert(0 if penalty_on_calling_stream else 1, head)
+        for i in range(len(side_chains)):      # (each fork waits for the main stream again, so a side stream does not
+            main.wait_stream(_side_stream(real.device, i))     # reuse its blocks before the additions below have run)
+
     # results: penalty chain, then the real (+ fake) chain, then the fake chain if it is separate
-    g_main, penalty = results.pop(0)
-    if split_real_fake:
-        d_real, d_fake = results[0][1], results[1][1]
+    if weight_gradient_sink:
+        # Every weight-gradient contribution of the iteration (per layer: the real + fake pass and the two of the
+        # penalty's double backward) is collected and, after the chains have joined, reduced by ONE launch per layer
+        # over the pixels of all of them: a third of the weight-gradient launches and split reductions, no additions.
+        bufs = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params]
+        with gops.weight_gradient_sink(params, bufs, defer=True) as sink:
+            run_chains()
+        g_main = []
+        for i, (p, b) in enumerate(zip(params, bufs)):
+            rest = [r[0][i] for r in results if r[0][i] is not None]
+            if p.data_ptr() in sink.touched:
+                g = b
+            elif rest:
+                g = rest.pop(0).clone()
+            else:
+                raise RuntimeError("a critic parameter received no gradient")
+            for r in rest:
+                g.add_(r)
+            g_main.append(g)
     else:
-        d_real, d_fake = results[0][1]
-    for i in range(len(side_chains)):      # (each fork waits for the main stream again, so a side stream does not reuse
-        main.wait_stream(_side_stream(real.device, i))          # its blocks before the additions below have run)
-    g_main = list(g_main)
-    for r in results:
-        torch._foreach_add_(g_main, list(r[0]))
+        run_chains()
+        g_main = list(results[0][0])
+        for r in results[1:]:
+            torch._foreach_add_(g_main, list(r[0]))
+    penalty = results[0][1]
+    if split_real_fake:
+        d_real, d_fake = results[1][1], results[2][1]
+    else:
+        d_real, d_fake = results[1][1]
     if all(p.grad is None for p in params):
         for p, g in zip(params, g_main):
             p.grad = g

@@ -186,10 +186,12 @@ class weight_gradient_sink:
     those take the ordinary path.  Process-wide like the other switches: one sink at a time."""
     active = None
 
-    def __init__(self, params, buffers, fork=False):
+    def __init__(self, params, buffers, fork=False, defer=False):
         self.buffers = {p.data_ptr(): (p, b) for p, b in zip(params, buffers)}
         self.touched = set()
         self.fork = fork
+        self.defer = defer       # collect the contributions and launch them at flush(): one reduction per weight
+        self.pending = {}        # id of the parameter's storage -> [(x, gy, geometry)]
         self.keep = []
         self.forked = False
 
@@ -211,10 +213,32 @@ class weight_gradient_sink:
 
     def __exit__(self, *exc):
         weight_gradient_sink.active = None
+        if exc[0] is None:
+            self.flush()
         if self.forked:
             self.main.wait_stream(self.side)
         self.keep.clear()
+        self.pending.clear()
         return False
+
+    def flush(self):
+        """Deferred mode: launches what was collected, on the current stream -- per weight one kernel that reduces over
+        the pixels of all its (x, gy) pairs (up to four per launch) and one split reduction.  The caller makes the
+        current stream wait for every stream a contribution was produced on before calling this."""
+        for key, items in self.pending.items():
+            w, buf = self.buffers[key]
+            while items:
+                group, items = items[:4], items[4:]
+                geo = group[0][2]
+                if len(group) > 1 and all(it[2] == geo for it in group):
+                    _wgrad_launch_multi([(it[0], it[1]) for it in group], buf, *geo, accumulate=key in self.touched)
+                    self.touched.add(key)
+                else:
+                    for x, gy, g in group:
+                        kh, kw, stride, padding, precision, alpha = g
+                        _wgrad_launch(x, gy, buf, kh, kw, stride, padding, precision, alpha, key in self.touched, lambda *keep: _stream())
+                        self.touched.add(key)
+        self.pending.clear()
 
     def buffer_for(self, w):
         """(buffer, accumulate flag) when w is one of the sink's parameters and nothing differentiates this pass."""
@@ -603,6 +627,27 @@ def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: in
     return gw
 
 
+def _wgrad_launch_multi(pairs, gw, kh, kw, stride, padding, precision, alpha, accumulate):
+    """gw (+)= alpha * the weight gradient summed over several (x, gy) pairs of one layer, one launch + one reduction."""
+    x0, gy0 = pairs[0]
+    _, Cin, H, W = x0.shape
+    _, Cout, Ho, Wo = gy0.shape
+    for x, gy in pairs:
+        if x.shape[1:] != x0.shape[1:] or gy.shape[1:] != gy0.shape[1:] or x.shape[0] != gy.shape[0] or x.dtype != x0.dtype or gy.dtype != x0.dtype:
+            raise RuntimeError("ganconv: the pairs of a multi-segment weight gradient must share geometry and storage type")
+    d = _desc(x0.shape[0], H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x0), precision)
+    L = _lib.lib()
+    n = len(pairs)
+    Ns = (ctypes.c_int32 * n)(*[p[0].shape[0] for p in pairs])
+    xs = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in pairs])
+    gys = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in pairs])
+    ws_bytes = L.gc_wgrad_multi_workspace_bytes(ctypes.byref(d), n, Ns)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x0.device)
+    _lib.check(L.gc_conv2d_wgrad_multi(ctypes.byref(d), n, xs, gys, Ns, ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), float(alpha),
+                                       1 if accumulate else 0, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+               "gc_conv2d_wgrad_multi")
+
+
 def _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
     """Hands the weight gradient of w to the active sink; False when there is none for it (the caller computes it)."""
     sink = weight_gradient_sink.active
@@ -614,6 +659,10 @@ def _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
     buf, accumulate = ent
     if buf.dtype != torch.float32 or not buf.is_contiguous():
         raise RuntimeError("ganconv: weight_gradient_sink buffers must be contiguous float32 tensors")
+    if sink.defer:      # operands in their kernel form now (on the stream that produced them), the launch at flush()
+        xo, gyo = _wgrad_operands(x, gy, precision)
+        sink.pending.setdefault(w.data_ptr(), []).append((xo, gyo, (w.shape[2], w.shape[3], stride, padding, precision, alpha)))
+        return True
     _wgrad_launch(x, gy, buf, w.shape[2], w.shape[3], stride, padding, precision, alpha, accumulate, lambda *keep: sink.stream_for(w, *keep))
     return True
 

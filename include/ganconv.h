@@ -300,6 +300,17 @@ int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32_t H, int32
 int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream);
 int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream);
 
+/* The weight gradient of ONE layer summed over several (x, gy) pairs in one launch: gw (+)= alpha * sum over segments g of
+ * wgrad(xs[g], gys[g]), segment g holding Ns[g] samples (1 to 4 segments; desc->N is ignored, everything else in the
+ * descriptor is shared).  For the passes of a training phase that all add to the same weight gradient -- in a WGAN-GP
+ * critic iteration (BasicGANs/loss_functions.py:7-28) the real + generated pass and the two contributions of the
+ * penalty's double backward: one reduction over all their pixels instead of three launches, three split reductions
+ * and two additions.  Results equal the sum of the separate calls up to the order of the fp32 partial sums. */
+size_t gc_wgrad_multi_workspace_bytes(const gc_conv_desc* desc, int32_t n_seg, const int32_t* Ns);
+int gc_conv2d_wgrad_multi(const gc_conv_desc* desc, int32_t n_seg, const void* const* xs, const void* const* gys, const int32_t* Ns,
+                          float* gw, const int64_t gw_strides[4], float alpha, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* The scalar parts of a WGAN-GP critic iteration, each one or two launches; they replace the chains of elementwise and
  * reduction tensor operations behind BasicGANs/loss_functions.py:7-27.  fp32 unless `dtype` says otherwise; tensors of
  * N samples with `per_sample` (a multiple of 4) contiguous-or-NHWC elements each, 16-byte aligned, any element order

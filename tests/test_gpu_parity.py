@@ -1035,7 +1035,10 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     # Adam's normalised steps amplify last-bit differences to a per cent of the losses within a cycle.
     gan.set_split_reduction(False)
     try:
-        a, b = make(), make(two_streams)       # (the eager twin always runs the plain one-stream iteration)
+        # the eager twin runs the same form of the iteration: the streamed form reduces each layer's weight gradient over all
+        # passes in one launch, i.e. sums in another order than the plain form, and Adam amplifies last-bit differences
+        # (the two forms are compared with each other, at the tolerance that allows, by the golden-loss test)
+        a, b = make(two_streams), make(two_streams)
         ref = [a.cycle_eager().cpu() for _ in range(2 + 3)]
         gan.set_backward_overlap(overlap)     # the recorded (and its warm-up) cycles fork the weight gradients to a side stream
         b.capture(warmup=2)
@@ -1502,3 +1505,27 @@ def test_wgangp_bf16_activation_storage_against_reference_trace(gan, golden_dir,
                 assert_grad_close(gr, z["critic.gradD." + k], tol, coarse, k)
     finally:
         gan.set_precision("bf16")
+
+
+@pytest.mark.parametrize("case", [(64, 32, 128, 4, 2, 1, (5, 3, 2)), (3, 16, 64, 4, 2, 1, (4, 2)), (128, 8, 1, 4, 1, 0, (3, 3, 1, 2)),
+                                  (24, 9, 40, 3, 1, 1, (2, 1))], ids=["lds_dma", "thin_input", "one_output_channel", "unaligned_channels"])
+def test_multi_segment_weight_gradient_equals_sum_of_calls(gan, case):
+    """gc_conv2d_wgrad_multi (one launch and one split reduction over several (x, gy) pairs of a layer) against the sum of
+    separate gc_conv2d_wgrad calls, on small-integer operands (every partial sum exact in fp32: bit-wise equality), with
+    and without accumulation into an existing gradient."""
+    from gan_amd import ops
+    Cin, H, Cout, k, s, p, Ns = case
+    prec = gan._lib.GC_PREC_BF16
+    torch.manual_seed(9)
+    Ho = (H + 2 * p - k) // s + 1
+    pairs = []
+    for n in Ns:
+        x = torch.randint(-3, 4, (n, Cin, H, H), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gy = torch.randint(-3, 4, (n, Cout, Ho, Ho), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        pairs.append((x, gy))
+    want = sum(ops.conv_wgrad(x, gy, k, k, s, p, prec) for x, gy in pairs)
+    got = torch.full_like(want, float("nan"))
+    ops._wgrad_launch_multi(pairs, got, k, k, s, p, prec, 1.0, accumulate=False)
+    assert torch.equal(got, want)
+    ops._wgrad_launch_multi(pairs, got, k, k, s, p, prec, 0.5, accumulate=True)
+    assert torch.equal(got, 1.5 * want)
