@@ -13,6 +13,8 @@
 // coalesced along the NHWC channel axis) x 16 lanes across pixels.  Statistics are recomputed from x in every
 // kernel (mean first, then centred sums: no E[x^2]-E[x]^2 cancellation); the per-workgroup slab (H*W x 64
 // channels) is re-read from L2.
+#include <type_traits>
+
 #include "common.h"
 
 namespace gc {
@@ -45,9 +47,30 @@ __device__ __forceinline__ f32x4 block_sum(f32x4 v, f32x4* red, int tq, int tl, 
   return r;
 }
 
-template <int MODE, typename T>
+// CACHED: a thread's share of the slab (at most kCachePix pixels x 4 channels per tensor) stays in registers, in storage
+// form, from the first sweep on: every tensor is read once instead of two or three times.  Same arithmetic in the same
+// order as the re-reading form (bit-identical results).
+constexpr int kCachePix = 16;
+
+template <typename T>
+struct RawQuad {          // 4 channels in storage form
+  typedef typename std::conditional<sizeof(T) == 2, u32x2, f32x4>::type type;
+  __device__ __forceinline__ static type load(const void* base, size_t idx) {
+    if constexpr (sizeof(T) == 2) return *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    else return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+  }
+  __device__ __forceinline__ static f32x4 widen(type v) {
+    if constexpr (sizeof(T) == 2) return widen_bf16x4(v);
+    else return v;
+  }
+};
+
+template <int MODE, typename T, bool CACHED>
 __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams p) {
   __shared__ f32x4 red[kThreads];
+  typedef RawQuad<T> RQ;
+  constexpr int KC = CACHED ? kCachePix : 1;
+  typename RQ::type xr[KC], gr[MODE >= 1 ? KC : 1], ur[MODE == 2 ? KC : 1];
   const int QB = 1 << p.qb_log2, PL = kThreads >> p.qb_log2;
   const int t = threadIdx.x, tq = t & (QB - 1), tl = t >> p.qb_log2;
   const int chunks = (p.C / 4 + QB - 1) / QB;
@@ -58,6 +81,31 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
   const float inv_n = 1.f / (float)p.HW;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   auto ld = [&](const void* ptr, int pix) -> f32x4 { return load4<T>(ptr, base + (size_t)pix * p.C); };
+  if (CACHED && cok) {      // all loads of the workgroup's slab are issued here, before the first reduction
+#pragma unroll
+    for (int i = 0; i < KC; i++) {
+      const int pix = tl + i * PL;
+      if (pix < p.HW) {
+        xr[i] = RQ::load(p.x, base + (size_t)pix * p.C);
+        if (MODE >= 1) gr[i] = RQ::load(p.gz, base + (size_t)pix * p.C);
+        if (MODE == 2) ur[i] = RQ::load(p.u, base + (size_t)pix * p.C);
+      }
+    }
+  }
+  // for_pixels(f): f(pix, x, gz, u) over this thread's pixels in ascending order, from the cache or from memory
+  auto for_pixels = [&](auto&& f) {
+    if (CACHED) {
+#pragma unroll
+      for (int i = 0; i < KC; i++) {
+        const int pix = tl + i * PL;
+        if (pix < p.HW) f(pix, RQ::widen(xr[i]), MODE >= 1 ? RQ::widen(gr[MODE >= 1 ? i : 0]) : f32x4{0.f, 0.f, 0.f, 0.f},
+                          MODE == 2 ? RQ::widen(ur[MODE == 2 ? i : 0]) : f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+    } else {
+      for (int pix = tl; pix < p.HW; pix += PL)
+        f(pix, ld(p.x, pix), MODE >= 1 ? ld(p.gz, pix) : f32x4{0.f, 0.f, 0.f, 0.f}, MODE == 2 ? ld(p.u, pix) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  };
   auto mask = [&](f32x4 d) -> f32x4 {
     f32x4 m;
 #pragma unroll
@@ -66,27 +114,25 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
   };
 
   f32x4 s = zero;
-  if (cok)
-    for (int pix = tl; pix < p.HW; pix += PL) s += ld(p.x, pix);
+  if (cok) for_pixels([&](int, f32x4 xv, f32x4, f32x4) { s += xv; });
   const f32x4 mu = block_sum(s, red, tq, tl, QB, PL) * inv_n;
 
   f32x4 s2 = zero, sg = zero, sgd = zero, su = zero, sud = zero, sug = zero;
   if (cok)
-    for (int pix = tl; pix < p.HW; pix += PL) {
-      const f32x4 d = ld(p.x, pix) - mu;
+    for_pixels([&](int, f32x4 xv, f32x4 gv, f32x4 uu) {
+      const f32x4 d = xv - mu;
       s2 += d * d;
       if (MODE >= 1) {
-        const f32x4 gy = ld(p.gz, pix) * mask(d);
+        const f32x4 gy = gv * mask(d);
         sg += gy;
         sgd += gy * d;
         if (MODE == 2) {
-          const f32x4 uu = ld(p.u, pix);
           su += uu;
           sud += uu * d;
           sug += uu * gy;
         }
       }
-    }
+    });
   s2 = block_sum(s2, red, tq, tl, QB, PL);
   f32x4 r;
 #pragma unroll
@@ -103,21 +149,21 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
   if (!cok) return;
 
   if (MODE == 0) {
-    for (int pix = tl; pix < p.HW; pix += PL) {
-      const f32x4 d = ld(p.x, pix) - mu;
+    for_pixels([&](int pix, f32x4 xv, f32x4, f32x4) {
+      const f32x4 d = xv - mu;
       const f32x4 z = d * r * mask(d);
       store4<T>(p.out0, base + (size_t)pix * p.C, z);
       if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(z);
-    }
+    });
   } else if (MODE == 1) {
     const f32x4 gbar = sg * inv_n, cbar = sgd * r * inv_n;   // mean(gy), mean(gy * xh)
-    for (int pix = tl; pix < p.HW; pix += PL) {
-      const f32x4 d = ld(p.x, pix) - mu;
-      const f32x4 gy = ld(p.gz, pix) * mask(d);
+    for_pixels([&](int pix, f32x4 xv, f32x4 gv, f32x4) {
+      const f32x4 d = xv - mu;
+      const f32x4 gy = gv * mask(d);
       const f32x4 gx = r * (gy - gbar - d * r * cbar);
       store4<T>(p.out0, base + (size_t)pix * p.C, gx);
       if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(gx);
-    }
+    });
   } else {
     const float nn = (float)p.HW;
     const f32x4 gbar = sg * inv_n, ubar = su * inv_n;
@@ -125,12 +171,11 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
     const f32x4 a_ = sug - nn * ubar * gbar;
     const f32x4 k0 = a_ - b_ * c_ * inv_n;
     const f32x4 scale = -(r * r) * inv_n;
-    for (int pix = tl; pix < p.HW; pix += PL) {
-      const f32x4 d = ld(p.x, pix) - mu;
+    for_pixels([&](int pix, f32x4 xv, f32x4 gv, f32x4 uu) {
+      const f32x4 d = xv - mu;
       const f32x4 m = mask(d);
       const f32x4 xh = d * r;
-      const f32x4 gy = ld(p.gz, pix) * m;
-      const f32x4 uu = ld(p.u, pix);
+      const f32x4 gy = gv * m;
       const f32x4 pu = uu - ubar - xh * (b_ * inv_n);
       const f32x4 pg = gy - gbar - xh * (c_ * inv_n);
       const f32x4 o0 = scale * (k0 * xh + c_ * pu + b_ * pg), o1 = m * r * pu;
@@ -138,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
       store4<T>(p.out1, base + (size_t)pix * p.C, o1);
       if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o0);
       if (p.out1_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out1_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o1);
-    }
+    });
   }
 }
 
@@ -166,14 +211,22 @@ static int launch_instnorm(int mode, int dtype, const void* x, const void* gz, c
   const dim3 grid((unsigned)N * chunks), block(kThreads);
   static const char* names[3] = {"gc::instnorm_kernel<0>", "gc::instnorm_kernel<1>", "gc::instnorm_kernel<2>"};
   ProfScope ps(names[mode], 0.0, stream);
+  // register-resident slabs: at most kCachePix pixels per thread; fp32 tensors only in the forward pass (three fp32
+  // tensors of 16 quads would need 192 registers)
+  const bool cached = (long)HW * QB <= (long)kCachePix * kThreads && (dtype == GC_BF16 || mode == 0);
   if (dtype == GC_F32) {
-    if (mode == 0) hipLaunchKernelGGL((instnorm_kernel<0, float>), grid, block, 0, stream, p);
-    else if (mode == 1) hipLaunchKernelGGL((instnorm_kernel<1, float>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((instnorm_kernel<2, float>), grid, block, 0, stream, p);
+    if (mode == 0 && cached) hipLaunchKernelGGL((instnorm_kernel<0, float, true>), grid, block, 0, stream, p);
+    else if (mode == 0) hipLaunchKernelGGL((instnorm_kernel<0, float, false>), grid, block, 0, stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((instnorm_kernel<1, float, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((instnorm_kernel<2, float, false>), grid, block, 0, stream, p);
+  } else if (cached) {
+    if (mode == 0) hipLaunchKernelGGL((instnorm_kernel<0, uint16_t, true>), grid, block, 0, stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((instnorm_kernel<1, uint16_t, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((instnorm_kernel<2, uint16_t, true>), grid, block, 0, stream, p);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((instnorm_kernel<0, uint16_t>), grid, block, 0, stream, p);
-    else if (mode == 1) hipLaunchKernelGGL((instnorm_kernel<1, uint16_t>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((instnorm_kernel<2, uint16_t>), grid, block, 0, stream, p);
+    if (mode == 0) hipLaunchKernelGGL((instnorm_kernel<0, uint16_t, false>), grid, block, 0, stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((instnorm_kernel<1, uint16_t, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((instnorm_kernel<2, uint16_t, false>), grid, block, 0, stream, p);
   }
   return check_hip(hipGetLastError(), "instnorm launch");
 }
