@@ -1529,3 +1529,27 @@ def test_multi_segment_weight_gradient_equals_sum_of_calls(gan, case):
     assert torch.equal(got, want)
     ops._wgrad_launch_multi(pairs, got, k, k, s, p, prec, 0.5, accumulate=True)
     assert torch.equal(got, 1.5 * want)
+
+
+def test_one_module_at_two_input_sizes_keeps_one_image_per_layout(gan):
+    """The packed data-gradient image of a layer whose window covers its whole input (4x4 input, k4 s1 p0: one class per
+    input pixel) differs in layout and size from the image the same weights need at a larger input.  One module run at
+    both sizes, alternating, with backward, against torch: a cache that handed out the other layout's image would read
+    the wrong rows (and past the end of the smaller buffer)."""
+    torch.manual_seed(12)
+    gan.set_precision("fp32x3")
+    try:
+        conv = gan.nn.Conv2d(8, 1, 4, 1, 0, bias=False).cuda()
+        ref = torch.nn.Conv2d(8, 1, 4, 1, 0, bias=False)
+        ref.load_state_dict(conv.state_dict())
+        for size in (4, 8, 4, 8, 5):
+            x = torch.randn(3, 8, size, size)
+            xg = x.cuda().requires_grad_(True)
+            xr = x.clone().requires_grad_(True)
+            yg, yr = conv(xg), ref(xr)
+            probe = torch.randn_like(yr)
+            gx, gw = torch.autograd.grad(yg, [xg, conv.weight], probe.cuda())
+            rx, rw = torch.autograd.grad(yr, [xr, ref.weight], probe)
+            assert rel(yg, yr) < TOL_X3 and rel(gx, rx) < TOL_X3 and rel(gw, rw) < TOL_X3, size
+    finally:
+        gan.set_precision("bf16")
