@@ -184,9 +184,14 @@ def main():
     finite = all(x == x and abs(x) != float("inf") for x in losses)
 
     # ---- per-kernel timing of the same cycle (HIP events on the launch stream), eager, outside the timed region
-    # One stream here: a kernel's duration is that of the kernel alone on the GPU, not of a kernel sharing it with another chain.
+    # One stream here: a kernel's duration is that of the kernel alone on the GPU, not of a kernel sharing it with another
+    # chain.  The launches are those of the timed region (its chains serialised), e.g. one weight-gradient launch per layer.
     roofline = None
-    tr.two_streams = False
+    if a.one_stream:
+        tr.two_streams = False
+    else:      # the same kernels as in the timed region, the chains one after the other on one stream
+        from gan_amd.harness import basic_gans
+        basic_gans.serialize_chains = True
     if rank == 0:
         _lib.profile_enable(True)
     for _ in range(2):        # every rank runs the cycles: with more than one rank they contain collectives

@@ -86,7 +86,13 @@ def weights_init(m):
 _side_streams = {}
 
 
+flush_lanes = 2              # side streams that share the layers' weight-gradient launches with the calling stream
+serialize_chains = False     # True: the chains run one after the other on the calling stream (same kernels; for per-kernel timing)
+
+
 def _side_stream(device, i):
+    if serialize_chains:
+        return torch.cuda.current_stream(device)
     st = _side_streams.get((device, i))
     if st is None:
         st = _side_streams[(device, i)] = torch.cuda.Stream(device)
@@ -217,7 +223,8 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
         # penalty's double backward) is collected and, after the chains have joined, reduced by ONE launch per layer
         # over the pixels of all of them: a third of the weight-gradient launches and split reductions, no additions.
         bufs = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params]
-        with gops.weight_gradient_sink(params, bufs, defer=True) as sink:
+        lanes = [] if serialize_chains else [_side_stream(real.device, i) for i in range(flush_lanes)]
+        with gops.weight_gradient_sink(params, bufs, defer=True, flush_streams=lanes) as sink:
             run_chains()
         g_main = []
         for i, (p, b) in enumerate(zip(params, bufs)):

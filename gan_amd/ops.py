@@ -186,7 +186,8 @@ class weight_gradient_sink:
     those take the ordinary path.  Process-wide like the other switches: one sink at a time."""
     active = None
 
-    def __init__(self, params, buffers, fork=False, defer=False):
+    def __init__(self, params, buffers, fork=False, defer=False, flush_streams=()):
+        self.flush_streams = list(flush_streams)     # deferred mode: the weights' launches are dealt out over these streams and the calling one
         self.buffers = {p.data_ptr(): (p, b) for p, b in zip(params, buffers)}
         self.touched = set()
         self.fork = fork
@@ -224,21 +225,46 @@ class weight_gradient_sink:
     def flush(self):
         """Deferred mode: launches what was collected, on the current stream -- per weight one kernel that reduces over
         the pixels of all its (x, gy) pairs (up to four per launch) and one split reduction.  The caller makes the
-        current stream wait for every stream a contribution was produced on before calling this."""
-        for key, items in self.pending.items():
-            w, buf = self.buffers[key]
-            while items:
-                group, items = items[:4], items[4:]
-                geo = group[0][2]
-                if len(group) > 1 and all(it[2] == geo for it in group):
-                    _wgrad_launch_multi([(it[0], it[1]) for it in group], buf, *geo, accumulate=key in self.touched)
-                    self.touched.add(key)
-                else:
-                    for x, gy, g in group:
-                        kh, kw, stride, padding, precision, alpha = g
-                        _wgrad_launch(x, gy, buf, kh, kw, stride, padding, precision, alpha, key in self.touched, lambda *keep: _stream())
-                        self.touched.add(key)
+        current stream wait for every stream a contribution was produced on before calling this.  With `flush_streams`
+        the weights take turns over those streams and the current one (the layers' reductions are independent: a thin
+        layer's memory-bound kernel then runs beside a wide layer's matrix-bound one); the current stream waits for all
+        of them before this returns."""
+        if not self.pending:
+            return
+        main = torch.cuda.current_stream()
+        lanes = [main] + [s for s in self.flush_streams if s != main]
+        if len(lanes) > 1:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            waiting = set()
+            for i, key in enumerate(self.pending):
+                st = lanes[i % len(lanes)]
+                if st is not main and st not in waiting:
+                    st.wait_event(fork)
+                    waiting.add(st)
+                with torch.cuda.stream(st):
+                    self._flush_weight(key, self.pending[key])
+            for st in lanes[1:]:
+                if st in waiting:
+                    main.wait_stream(st)
+        else:
+            for key, items in self.pending.items():
+                self._flush_weight(key, items)
         self.pending.clear()
+
+    def _flush_weight(self, key, items):
+        w, buf = self.buffers[key]
+        while items:
+            group, items = items[:4], items[4:]
+            geo = group[0][2]
+            if len(group) > 1 and all(it[2] == geo for it in group):
+                _wgrad_launch_multi([(it[0], it[1]) for it in group], buf, *geo, accumulate=key in self.touched)
+                self.touched.add(key)
+            else:
+                for x, gy, g in group:
+                    kh, kw, stride, padding, precision, alpha = g
+                    _wgrad_launch(x, gy, buf, kh, kw, stride, padding, precision, alpha, key in self.touched, lambda *keep: _stream())
+                    self.touched.add(key)
 
     def buffer_for(self, w):
         """(buffer, accumulate flag) when w is one of the sink's parameters and nothing differentiates this pass."""

@@ -11,7 +11,7 @@ from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--what", default="two_streams", choices=["two_streams", "three_chains", "repack", "gen_ahead", "flag"])
-ap.add_argument("--flag", default="weight_gradient_sink", help="with --what flag: the boolean switch of gan_amd.harness.basic_gans under test")
+ap.add_argument("--flag", default="weight_gradient_sink", help="with --what flag: the boolean switch of gan_amd.harness.basic_gans under test, or NAME=A,B for two integer values")
 ap.add_argument("--batch", type=int, default=256)
 args = ap.parse_args()
 
@@ -19,7 +19,11 @@ args = ap.parse_args()
 def make(on):
     if args.what == "flag":
         from gan_amd.harness import basic_gans
-        setattr(basic_gans, args.flag, bool(on))
+        if "=" in args.flag:          # NAME=A,B: the integer value A against B
+            name, vals = args.flag.split("=")
+            setattr(basic_gans, name, int(vals.split(",")[0 if on else 1]))
+        else:
+            setattr(basic_gans, args.flag, bool(on))
     # three_chains: real, fake and penalty passes on three streams against real + fake batched beside the penalty pass
     tr = WganGpTrainer(args.batch, 64, 100, 64, device="cuda:0", capturable=True, batch_real_fake=not (on and args.what == "three_chains"),
                        fused_adam=True, activation_dtype=torch.bfloat16,
