@@ -63,27 +63,6 @@ ProfScope::~ProfScope() {
 // dst[plane][row][pitch] (bf16), a row being [tap][colp] followed by zeros up to `pitch`, from fp32 w[co][ci][r][s]
 // with strides.  transpose == 0: row = co, col = ci (forward image); transpose == 1: row = ci, col = co
 // (data-gradient image).
-__global__ __launch_bounds__(kThreads) void pack_weight_kernel(const float* w, int64_t s_co, int64_t s_ci, int64_t s_r, int64_t s_s,
-                                                                uint16_t* dst, int rows, int cols, int colp, int pitch, int kh, int kw,
-                                                                int transpose, int planes, float alpha) {
-  const size_t total = (size_t)rows * pitch;
-  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
-    const int k = (int)(e % pitch);
-    const int row = (int)(e / pitch);
-    const int col = k % colp, tap = k / colp;
-    float v = 0.f;
-    if (col < cols && tap < kh * kw) {
-      const int co = transpose ? col : row, ci = transpose ? row : col;
-      v = alpha * w[co * s_co + ci * s_ci + (tap / kw) * s_r + (tap % kw) * s_s];
-    }
-    const uint16_t hi = float_to_bf16_bits(v);
-    dst[e] = hi;
-    if (planes == 2) dst[total + e] = float_to_bf16_bits(v - bf16_bits_to_float(hi));
-  }
-}
-
-// Several weights in one launch (after an optimizer step): job j owns blocks [block0[j], block0[j + 1]).
-constexpr int kMaxPackJobs = 24;
 struct PackJob {
   const float* w;
   uint16_t* dst;
@@ -91,7 +70,66 @@ struct PackJob {
   int32_t rows, cols, colp, pitch, kh, kw, transpose, planes;
   float alpha;
   uint32_t block0;
+  int32_t taps_contiguous;   // the kh * kw taps of a (co, ci) pair are consecutive floats: 1, or 4 when also 16-byte aligned in fours
 };
+
+// Workgroup `blk` of `nb` working on job q.  With contiguous taps a thread owns one (row, col) pair: it reads the
+// pair's taps as one run of consecutive floats (every fetched byte is used; the element-per-thread form below reads
+// 4 bytes out of every 64-byte run and fetches the tensor sixteen times) and stores one element per tap, neighbouring
+// lanes to neighbouring addresses.
+__device__ __forceinline__ void pack_job(const PackJob& q, uint32_t blk, uint32_t nb) {
+  const size_t total = (size_t)q.rows * q.pitch;
+  const int taps = q.kh * q.kw;
+  auto put = [&](size_t e, float v) {
+    const uint16_t hi = float_to_bf16_bits(v);
+    q.dst[e] = hi;
+    if (q.planes == 2) q.dst[total + e] = float_to_bf16_bits(v - bf16_bits_to_float(hi));
+  };
+  if (q.taps_contiguous) {
+    const size_t units = (size_t)q.rows * q.colp;
+    for (size_t u = (size_t)blk * kThreads + threadIdx.x; u < units; u += (size_t)nb * kThreads) {
+      const int row = (int)(u / q.colp), col = (int)(u - (size_t)row * q.colp);
+      const size_t e0 = (size_t)row * q.pitch + col;
+      if (col >= q.cols) {
+        for (int tap = 0; tap < taps; tap++) put(e0 + (size_t)tap * q.colp, 0.f);
+        continue;
+      }
+      const int co = q.transpose ? col : row, ci = q.transpose ? row : col;
+      const float* src = q.w + co * q.s_co + ci * q.s_ci;
+      if (q.taps_contiguous == 4) {
+        for (int tap = 0; tap < taps; tap += 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + tap);
+#pragma unroll
+          for (int i = 0; i < 4; i++) put(e0 + (size_t)(tap + i) * q.colp, q.alpha * v[i]);
+        }
+      } else {
+        for (int tap = 0; tap < taps; tap++) put(e0 + (size_t)tap * q.colp, q.alpha * src[tap]);
+      }
+    }
+    const int tail0 = taps * q.colp, tail = q.pitch - tail0;       // zeros behind the last tap of every row
+    for (size_t u = (size_t)blk * kThreads + threadIdx.x; u < (size_t)q.rows * tail; u += (size_t)nb * kThreads) {
+      const int row = (int)(u / tail);
+      put((size_t)row * q.pitch + tail0 + (u - (size_t)row * tail), 0.f);
+    }
+    return;
+  }
+  for (size_t e = (size_t)blk * kThreads + threadIdx.x; e < total; e += (size_t)nb * kThreads) {
+    const int k = (int)(e % q.pitch);
+    const int row = (int)(e / q.pitch);
+    const int col = k % q.colp, tap = k / q.colp;
+    float v = 0.f;
+    if (col < q.cols && tap < taps) {
+      const int co = q.transpose ? col : row, ci = q.transpose ? row : col;
+      v = q.alpha * q.w[co * q.s_co + ci * q.s_ci + (tap / q.kw) * q.s_r + (tap % q.kw) * q.s_s];
+    }
+    put(e, v);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void pack_weight_kernel(const PackJob q) { pack_job(q, blockIdx.x, gridDim.x); }
+
+// Several weights in one launch (after an optimizer step): job j owns blocks [block0[j], block0[j + 1]).
+constexpr int kMaxPackJobs = 24;
 struct PackTable {
   int32_t n;
   uint32_t nblocks;
@@ -103,20 +141,7 @@ __global__ __launch_bounds__(kThreads) void pack_weights_kernel(const PackTable 
     if (blockIdx.x >= t.job[i].block0) j = i;
   const PackJob& q = t.job[j];
   const uint32_t nb = (j + 1 < t.n ? t.job[j + 1].block0 : t.nblocks) - q.block0;
-  const size_t total = (size_t)q.rows * q.pitch;
-  for (size_t e = (size_t)(blockIdx.x - q.block0) * kThreads + threadIdx.x; e < total; e += (size_t)nb * kThreads) {
-    const int k = (int)(e % q.pitch);
-    const int row = (int)(e / q.pitch);
-    const int col = k % q.colp, tap = k / q.colp;
-    float v = 0.f;
-    if (col < q.cols && tap < q.kh * q.kw) {
-      const int co = q.transpose ? col : row, ci = q.transpose ? row : col;
-      v = q.alpha * q.w[co * q.s_co + ci * q.s_ci + (tap / q.kw) * q.s_r + (tap % q.kw) * q.s_s];
-    }
-    const uint16_t hi = float_to_bf16_bits(v);
-    q.dst[e] = hi;
-    if (q.planes == 2) q.dst[total + e] = float_to_bf16_bits(v - bf16_bits_to_float(hi));
-  }
+  pack_job(q, blockIdx.x - q.block0, nb);
 }
 
 // ---- depthwise 3x3 binomial blur, NHWC ----------------------------------------------------------------------
@@ -418,6 +443,27 @@ size_t gc_packed_weight_bytes(const gc_conv_desc* d, int pass) {
   return (size_t)planes * (pass == GC_PASS_FPROP ? d->Cout : d->Cin) * g.row_pitch * 2;
 }
 
+// Fills the job of one weight tensor; returns the number of workgroups that cover it once.
+static size_t fill_pack_job(gc::PackJob& q, const gc_conv_desc* d, int pass, const float* w, const int64_t* st, float alpha, void* packed) {
+  const gc::PackGeom g = gc::geom_for(d, pass);
+  q.w = w; q.dst = (uint16_t*)packed;
+  q.s_co = st[0]; q.s_ci = st[1]; q.s_r = st[2]; q.s_s = st[3];
+  q.transpose = pass == GC_PASS_DGRAD;
+  q.rows = q.transpose ? d->Cin : d->Cout; q.cols = q.transpose ? d->Cout : d->Cin;
+  q.colp = g.icp; q.pitch = g.row_pitch; q.kh = d->kh; q.kw = d->kw;
+  q.planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
+  q.alpha = alpha;
+  q.block0 = 0;
+  const int taps = d->kh * d->kw;
+  q.taps_contiguous = 0;
+  if (st[3] == 1 && (d->kh == 1 || st[2] == d->kw) && q.pitch >= taps * q.colp) {
+    q.taps_contiguous = 1;
+    if (taps % 4 == 0 && st[0] % 4 == 0 && st[1] % 4 == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0) q.taps_contiguous = 4;
+  }
+  const size_t work = q.taps_contiguous ? (size_t)q.rows * q.colp : (size_t)q.rows * q.pitch;
+  return (work + gc::kThreads - 1) / gc::kThreads;
+}
+
 int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_t w_strides[4], float alpha, void* packed,
                    void* stream) {
   int rc = validate(d);
@@ -425,17 +471,12 @@ int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_
   if (w == nullptr || packed == nullptr || w_strides == nullptr) { set_error("gc_pack_weight: null pointer"); return GC_BAD_ARGUMENT; }
   if (pass != GC_PASS_FPROP && pass != GC_PASS_DGRAD) { set_error("gc_pack_weight: bad pass"); return GC_BAD_ARGUMENT; }
   if (!aligned16(packed)) { set_error("gc_pack_weight: packed buffer must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
-  const int transpose = pass == GC_PASS_DGRAD;
-  const int rows = transpose ? d->Cin : d->Cout, cols = transpose ? d->Cout : d->Cin;
-  const PackGeom g = geom_for(d, pass);
-  const int colp = g.icp;
-  const int planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
-  const size_t total = (size_t)rows * g.row_pitch;
-  size_t blocks = (total + kThreads - 1) / kThreads;
+  PackJob q;
+  size_t blocks = fill_pack_job(q, d, pass, w, w_strides, alpha, packed);
   if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
   ProfScope ps("gc::pack_weight_kernel", 0.0, (hipStream_t)stream);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, w, w_strides[0], w_strides[1],
-                     w_strides[2], w_strides[3], (uint16_t*)packed, rows, cols, colp, g.row_pitch, d->kh, d->kw, transpose, planes, alpha);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, q);
   return check_hip(hipGetLastError(), "pack_weight launch");
 }
 
@@ -458,18 +499,10 @@ int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes,
       if (ws[base + j] == nullptr || packed[base + j] == nullptr || !aligned16(packed[base + j])) {
         set_error("gc_pack_weights: null weight or null / misaligned packed buffer"); return GC_BAD_ARGUMENT;
       }
-      const PackGeom g = geom_for(d, pass);
       PackJob& q = t.job[j];
-      q.w = ws[base + j]; q.dst = (uint16_t*)packed[base + j];
-      const int64_t* st = w_strides + 4 * (size_t)(base + j);
-      q.s_co = st[0]; q.s_ci = st[1]; q.s_r = st[2]; q.s_s = st[3];
-      q.transpose = pass == GC_PASS_DGRAD;
-      q.rows = q.transpose ? d->Cin : d->Cout; q.cols = q.transpose ? d->Cout : d->Cin;
-      q.colp = g.icp; q.pitch = g.row_pitch; q.kh = d->kh; q.kw = d->kw;
-      q.planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
-      q.alpha = alphas != nullptr ? alphas[base + j] : 1.f;
+      size_t nb = fill_pack_job(q, d, pass, ws[base + j], w_strides + 4 * (size_t)(base + j), alphas != nullptr ? alphas[base + j] : 1.f,
+                                packed[base + j]);
       q.block0 = blocks;
-      size_t nb = ((size_t)q.rows * q.pitch + kThreads - 1) / kThreads;
       if (nb > 512) nb = 512;
       if (nb < 1) nb = 1;
       blocks += (uint32_t)nb;
