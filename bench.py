@@ -154,7 +154,7 @@ def main():
         gan_amd.nn.convert_sync_batchnorm(tr.net_G)
     if distributed:  # replicas start from identical parameters
         for p in list(tr.net_G.parameters()) + list(tr.net_D.parameters()) + list(tr.net_G.buffers()) + list(tr.net_D.buffers()):
-            dist.broadcast(p.data, 0)
+            gan_amd.ddp.broadcast(p.data, 0)
     gen = torch.Generator().manual_seed(5001 + rank)
     real, zs = synth_inputs(gen, BATCH, NZ, RES, REPS + 1)
     eps = torch.rand(REPS, BATCH, 1, 1, 1, generator=gen)

@@ -11,7 +11,7 @@
 namespace gc {
 
 constexpr int kAdamMaxTensors = 48;
-constexpr int kAdamChunk = kThreads * 4 * 4;   // elements per workgroup
+constexpr int kAdamChunk = kThreads * 4 * 4;   // elements per workgroup: four 16-byte accesses per thread and tensor
 
 struct AdamTable {
   float* p[kAdamMaxTensors];
@@ -42,19 +42,49 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(const AdamTable t, float
   const float s = t.step[ti][0];
   const float bc1 = 1.f - powf(b1, s), bc2 = 1.f - powf(b2, s);
   const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+  auto update = [&](float gi, float m0, float v0, float p0, float& mi, float& vi, float& pi) {
+    const float w = 1.f - b1;                                      // lerp_(grad, 1 - beta1), torch's two-sided formula:
+    mi = w < 0.5f ? m0 + w * (gi - m0) : gi - (gi - m0) * (1.f - w);   // exact at both ends (beta1 = 0 gives g)
+    vi = v0 * b2 + (1.f - b2) * gi * gi;                           // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = p0 - step_size * (mi / denom);                            // addcdiv_(exp_avg, denom, value = -step_size)
+  };
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(e)) & 15u) == 0;
+  if (vec && base + kAdamChunk <= n) {       // a full chunk of 16-byte aligned tensors: four elements per access
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = base + ((int64_t)k * kThreads + threadIdx.x) * 4;
+      const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i), m0 = *reinterpret_cast<const f32x4*>(m + i);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(v + i), p0 = *reinterpret_cast<const f32x4*>(p + i);
+      f32x4 mi, vi, pi;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float a, b, c;
+        update(gi[q], m0[q], v0[q], p0[q], a, b, c);
+        mi[q] = a; vi[q] = b; pi[q] = c;
+      }
+      *reinterpret_cast<f32x4*>(m + i) = mi;
+      *reinterpret_cast<f32x4*>(v + i) = vi;
+      *reinterpret_cast<f32x4*>(p + i) = pi;
+      if (e != nullptr) {
+        f32x4 ei = *reinterpret_cast<const f32x4*>(e + i);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ei[q] = ei[q] * ema_w + (1.f - ema_w) * pi[q];     // mul_(weight).add_(1 - weight, p)
+        *reinterpret_cast<f32x4*>(e + i) = ei;
+      }
+    }
+    return;
+  }
   for (int k = 0; k < 16; k++) {
     const int64_t i = base + (int64_t)k * kThreads + threadIdx.x;
     if (i >= n) break;
-    const float gi = g[i];
-    const float w = 1.f - b1, m0 = m[i];                          // lerp_(grad, 1 - beta1), torch's two-sided formula:
-    const float mi = w < 0.5f ? m0 + w * (gi - m0) : gi - (gi - m0) * (1.f - w);   // exact at both ends (beta1 = 0 gives g)
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;           // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    float mi, vi, pi;
+    update(g[i], m[i], v[i], p[i], mi, vi, pi);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    const float pi = p[i] - step_size * (mi / denom);            // addcdiv_(exp_avg, denom, value = -step_size)
     p[i] = pi;
-    if (e != nullptr) e[i] = e[i] * ema_w + (1.f - ema_w) * pi;  // mul_(weight).add_(1 - weight, p)
+    if (e != nullptr) e[i] = e[i] * ema_w + (1.f - ema_w) * pi;
   }
 }
 

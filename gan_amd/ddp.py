@@ -23,13 +23,30 @@ import torch
 import torch.distributed as dist
 
 
-def finish_stream_for_gloo(tensor, group=None):
-    """gloo stages GPU tensors through the host and synchronises a stream of its own that waits for the current one; on
-    ROCm 7.2 that wait was seen not to return (two ranks, right behind a graph replay; now and then behind eager
-    launches) unless the producing work had finished -- so finish it first.  RCCL orders its collectives on the GPU and
-    needs no host wait: nothing happens for it."""
+def all_reduce_sum(tensor, group=None, async_op=False):
+    """Sum of `tensor` over the ranks, in place; returns the work handle of an asynchronous RCCL call, else None.
+
+    RCCL orders its collectives on the GPU.  gloo (the CPU rig of the tests: several ranks on one GPU) is given host
+    tensors only: its own staging of GPU tensors -- a stream of its own that waits for the current one, copies and host
+    waits -- was seen not to return on ROCm 7.2 with two ranks on one GPU.  Both ranks sat inside dist.all_reduce,
+    behind a stream synchronisation that had returned, so the GPU work in front of it was finished and the wait was
+    gloo's own.  Here the copy to the host and back are ordinary torch copies on the current stream."""
     if tensor.is_cuda and dist.get_backend(group) == "gloo":
-        torch.cuda.current_stream(tensor.device).synchronize()
+        host = tensor.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        tensor.copy_(host)
+        return None
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def broadcast(tensor, src=0, group=None):
+    """dist.broadcast with the same host staging for gloo as all_reduce_sum."""
+    if tensor.is_cuda and dist.get_backend(group) == "gloo":
+        host = tensor.cpu()
+        dist.broadcast(host, src, group=group)
+        tensor.copy_(host)
+    else:
+        dist.broadcast(tensor, src, group=group)
 
 
 class GradReducer:
@@ -116,9 +133,8 @@ class GradReducer:
         """Blocking-in-stream-order sum of every bucket over the ranks, without the hook machinery: for callers that
         run forward/backward as a captured HIP graph and reduce between graph replays."""
         if dist.is_available() and dist.is_initialized():
-            finish_stream_for_gloo(self.buckets[0], self.pg)
             for flat in self.buckets:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+                all_reduce_sum(flat, self.pg)
 
     def average_(self):
         if self.average and self.world > 1:
@@ -133,8 +149,7 @@ class GradReducer:
     def _launch(self, bi):
         self._launched[bi] = True
         if self.world > 1:
-            finish_stream_for_gloo(self.buckets[bi], self.pg)
-            self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._works[bi] = all_reduce_sum(self.buckets[bi], self.pg, async_op=True)
 
     def _hook(self, p):
         if not self._armed:

@@ -1255,15 +1255,13 @@ class _SyncBatchNormAct(torch.autograd.Function):
         if world > 1:
             # the shard means go first, so that each rank can centre its squares on the mean of the whole batch before
             # they are added (no cancellation for channels with |mean| >> std)
-            from .ddp import finish_stream_for_gloo
+            from .ddp import all_reduce_sum
             head = torch.cat([m * P, torch.full((1,), float(P), dtype=torch.float32, device=dev)])
-            finish_stream_for_gloo(head, group)
-            dist.all_reduce(head, group=group)
+            all_reduce_sum(head, group)
             count = head[C]
             mean = head[:C] / count
             m2 = v * max(P - 1, 0) + P * (m - mean) ** 2
-            finish_stream_for_gloo(m2, group)
-            dist.all_reduce(m2, group=group)
+            all_reduce_sum(m2, group)
         else:
             count = torch.full((), float(P), dtype=torch.float32, device=dev)
             mean, m2 = m, v * max(P - 1, 0)
@@ -1306,9 +1304,8 @@ class _SyncBatchNormAct(torch.autograd.Function):
                        "gc_batchnorm_act_bwd_sums")
         gb, gw = sums[0].clone(), sums[1].clone()      # parameter gradients stay per rank: the gradient reducer averages them
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            from .ddp import finish_stream_for_gloo
-            finish_stream_for_gloo(sums, group)
-            dist.all_reduce(sums, group=group)
+            from .ddp import all_reduce_sum
+            all_reduce_sum(sums, group)
         means = (sums / count).contiguous()
         gx = torch.empty_like(x, memory_format=torch.channels_last)
         if P > 0:
