@@ -113,7 +113,8 @@ def main():
                          "graphs, the gradient buckets are all-reduced between two replays)")
     ap.add_argument("--one-stream", action="store_true",
                     help="run the independent chains of a critic iteration (real + fake pass, gradient-penalty pass, the generator's "
-                         "forward passes) one after the other instead of on streams of their own (measured: 14 %% slower)")
+                         "forward passes) one after the other on one stream instead of on streams of their own: the same launches, "
+                         "every kernel alone on the GPU (for profiles; measured: about 20 %% slower)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="data parallel: BatchNorm statistics over all ranks (the single-device result on the global batch) "
                          "instead of per rank (what the reference's DataParallel does)")
@@ -140,14 +141,16 @@ def main():
     import gan_amd
     from gan_amd import _lib
     from gan_amd.ddp import GradReducer
+    from gan_amd.harness import basic_gans
     from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
+    basic_gans.serialize_chains = bool(a.one_stream)
     gan_amd.set_precision(a.precision)
     gan_amd.set_backward_overlap(a.overlap)   # weight-gradient kernels on a second stream, beside the data gradient
 
     use_graph = not a.no_graph and not (distributed and a.ddp_eager)
     tr = WganGpTrainer(BATCH, HIDDEN, NZ, RES, device=f"cuda:{local_rank}", reducer_factory=(GradReducer if distributed else None),
                        capturable=use_graph, batch_real_fake=True, fused_adam=True,
-                       activation_dtype=torch.float32 if a.fp32_activations else torch.bfloat16, two_streams=not a.one_stream)
+                       activation_dtype=torch.float32 if a.fp32_activations else torch.bfloat16, two_streams=True)
     if a.sync_bn:
         if use_graph:
             raise SystemExit("--sync-bn exchanges statistics inside the forward pass: run it with --ddp-eager (collectives are never captured)")
@@ -187,11 +190,7 @@ def main():
     # One stream here: a kernel's duration is that of the kernel alone on the GPU, not of a kernel sharing it with another
     # chain.  The launches are those of the timed region (its chains serialised), e.g. one weight-gradient launch per layer.
     roofline = None
-    if a.one_stream:
-        tr.two_streams = False
-    else:      # the same kernels as in the timed region, the chains one after the other on one stream
-        from gan_amd.harness import basic_gans
-        basic_gans.serialize_chains = True
+    basic_gans.serialize_chains = True
     if rank == 0:
         _lib.profile_enable(True)
     for _ in range(2):        # every rank runs the cycles: with more than one rank they contain collectives

@@ -18,6 +18,10 @@ constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 template <typename TOut>
 __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t patch[kPH * kPW * 4];
+  // bf16 output of 64 channels: a wave's row of 32 pixels is transposed here, so that it leaves as whole 128-byte pixels
+  // (1 KB per store instruction, consecutive in memory) instead of 8 bytes per lane
+  constexpr int kRowPitch = 144;                   // bytes per pixel in the staging tile (128 + 16: spreads the banks)
+  __shared__ __attribute__((aligned(16))) char stage[sizeof(TOut) == 2 ? 4 * kTW * kRowPitch : 16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c16 = lane & 15;
   const int tiles_w = p.OW / kTW, tiles_h = p.OH / kTH;
   int bid = blockIdx.x;
@@ -58,6 +62,8 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 
   // wave w: output rows RW * w .. of the rectangle, each in two groups of 16 pixels
   constexpr int RW = kTH / 4;
+  const bool staged = sizeof(TOut) == 2 && p.OC == 64 && p.out_vec8 != 0;
+  char* my_stage = stage + (sizeof(TOut) == 2 ? wave * kTW * kRowPitch : 0);
 #pragma unroll
   for (int grp = 0; grp < 2 * RW; grp++) {
     const int oh_l = RW * wave + (grp >> 1), ow_l = (grp & 1) * 16 + c16;
@@ -83,7 +89,22 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
       for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act, p.slope);
       const size_t o = pix * p.out_cstride + p.out_coff + oc;
       if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+      else if (staged) *reinterpret_cast<u32x2*>(my_stage + ow_l * kRowPitch + oc * 2) = cvt_bf16x4(v);
       else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v);
+    }
+    if (sizeof(TOut) == 2 && staged && (grp & 1)) {       // both halves of the row are in the tile: store it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const size_t row0 = ((size_t)n * p.OH + oh0 + oh_l) * p.OW + ow0;
+#pragma unroll
+      for (int k = 0; k < kTW * 8 / 64; k++) {
+        const int idx = k * 64 + lane, px = idx >> 3, ch = idx & 7;
+        const u32x4 q = *reinterpret_cast<const u32x4*>(my_stage + px * kRowPitch + ch * 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + (row0 + px) * p.out_cstride + p.out_coff + ch * 8) = q;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

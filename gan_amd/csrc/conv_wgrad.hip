@@ -401,7 +401,8 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
   const long max_splits = (p.K + 8 * kWBK - 1) / (8 * kWBK);
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
-  if (want > 512) want = 512;
+  static const int max_want = getenv("GC_WGRAD_MAX_SPLITS") ? atoi(getenv("GC_WGRAD_MAX_SPLITS")) : 512;
+  if (want > max_want) want = max_want;
   long kps = (p.K + want - 1) / want;
   kps = (kps + kWBK - 1) / kWBK * kWBK;
   p.k_per_split = (int)kps;

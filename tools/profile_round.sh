@@ -2,7 +2,8 @@
 # Collects one round's measurement set on the GPU box (run from the repository root through gpurun):
 #   tools/profile_round.sh <tag>        e.g. r1_e
 # Writes gpurun_out/<tag>/: the unprofiled bench line, the rocprofv3 kernel-trace statistics of the same command with
-# --one-stream (each kernel alone on the GPU, the durations the roofline figures are about) and of the default command
+# --one-stream (the same launches with the chains serialised: each kernel alone on the GPU, the durations the roofline
+# figures are about) and of the default command
 # (chains of a critic iteration on concurrent streams: kernels share the GPU and each one takes longer), two counter
 # passes (FETCH_SIZE, WRITE_SIZE; counters never share a run with a trace) over one eager one-stream cycle, and the
 # summary files tools/profile_summary.py derives from them.

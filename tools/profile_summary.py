@@ -24,8 +24,8 @@ print(f"Unprofiled default run (`python bench.py`, `{tag}_bench_line.json`): **{
       f"dominant conv kernel `{r['kernel']}`: {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of the dense bf16 peak, average launch "
       f"{r['avg_launch_us']:.1f} us" + (f", {r['traffic'] / 1e6:.1f} MB HBM traffic per launch" if r.get("traffic") else "") +
       f"; CPU baseline {cb.get('value', float('nan')):.1f} img/s on {cb.get('cores')} cores.\n")
-print(f"Under the profiler with `--one-stream` (every kernel alone on the GPU: the durations below are what the roofline figure is "
-      f"about): {prof['value']:.0f} img/s, {prof['ms_per_step']:.2f} ms per cycle.  {cycles} cycles were traced "
+print(f"Under the profiler with `--one-stream` (the launches of the default command, its chains one after the other on one stream, "
+      f"so every kernel is alone on the GPU: the durations below are what the roofline figure is about): {prof['value']:.0f} img/s, {prof['ms_per_step']:.2f} ms per cycle.  {cycles} cycles were traced "
       f"(the per-cycle columns divide by {cycles}).")
 cpath = os.path.join(d, "bench_line_under_rocprof_concurrent.json")
 if os.path.exists(cpath):
