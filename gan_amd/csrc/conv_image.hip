@@ -15,19 +15,13 @@ namespace {
 constexpr int kTH = 4, kTW = 32;                 // output rectangle of a workgroup (a multiple of 4 rows: one or more per wave)
 constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 
-template <typename TOut>
+// LEAN: the epilogue's activation is none / ReLU / LeakyReLU with a slope in [0, 1], i.e. max(v, s v) with s = 1 / 0 / slope
+template <typename TOut, bool LEAN>
 __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t patch[kPH * kPW * 4];
-  // bf16 output of 64 channels: a wave's row of 32 pixels is transposed here, so that it leaves as whole 128-byte pixels
-  // (1 KB per store instruction, consecutive in memory) instead of 8 bytes per lane
-  constexpr int kRowPitch = 144;                   // bytes per pixel in the staging tile (128 + 16: spreads the banks)
-  __shared__ __attribute__((aligned(16))) char stage[sizeof(TOut) == 2 ? 4 * kTW * kRowPitch : 16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c16 = lane & 15;
-  const int tiles_w = p.OW / kTW, tiles_h = p.OH / kTH;
-  int bid = blockIdx.x;
-  const int tw = bid % tiles_w; bid /= tiles_w;
-  const int th = bid % tiles_h;
-  const int n = bid / tiles_h;
+  const int tiles_w = p.OW / kTW;
+  const int n = blockIdx.y, th = (int)blockIdx.x / tiles_w, tw = (int)blockIdx.x - th * tiles_w;
   const int oh0 = th * kTH, ow0 = tw * kTW;
   const int ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;   // input coordinates of patch element (0, 0)
 
@@ -43,27 +37,36 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
       wa[ob][ks] = __builtin_bit_cast(bf16x8, v);
     }
 
-  // stage the patch: one thread per pixel, channels padded to 4
+  // stage the patch: one thread per pixel, channels padded to 4 (row / column of the walk kept incrementally)
   const float* img = reinterpret_cast<const float*>(p.in) + (size_t)n * p.IH * p.IW * p.IC;
+  int pr = t / kPW, pc = t - pr * kPW;
   for (int e = t; e < kPH * kPW; e += kThreads) {
-    const int pr = e / kPW, pc = e - pr * kPW;
     const int ih = ih0 + pr, iw = iw0 + pc;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
-      const float* src = img + ((size_t)ih * p.IW + iw) * p.IC;
+      const float* src = img + (uint32_t)((ih * p.IW + iw) * p.IC);
       v[0] = src[0];
       if (p.IC > 1) v[1] = src[1];
       if (p.IC > 2) v[2] = src[2];
       if (p.IC > 3) v[3] = src[3];
     }
     *reinterpret_cast<u32x2*>(patch + e * 4) = cvt_bf16x4(v);
+    pr += kThreads / kPW;
+    pc += kThreads % kPW;
+    if (pc >= kPW) { pc -= kPW; pr++; }
   }
   __syncthreads();
 
+  f32x4 bias_v[4];
+#pragma unroll
+  for (int ob = 0; ob < 4; ob++) {
+    bias_v[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && ob * 16 < p.OC) bias_v[ob] = *reinterpret_cast<const f32x4*>(p.bias + ob * 16 + 4 * g);
+  }
+  const float sl = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);
+
   // wave w: output rows RW * w .. of the rectangle, each in two groups of 16 pixels
   constexpr int RW = kTH / 4;
-  const bool staged = sizeof(TOut) == 2 && p.OC == 64 && p.out_vec8 != 0;
-  char* my_stage = stage + (sizeof(TOut) == 2 ? wave * kTW * kRowPitch : 0);
 #pragma unroll
   for (int grp = 0; grp < 2 * RW; grp++) {
     const int oh_l = RW * wave + (grp >> 1), ow_l = (grp & 1) * 16 + c16;
@@ -78,33 +81,22 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
       for (int ob = 0; ob < 4; ob++)
         if (ob * 16 < p.OC) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
     }
-    const size_t pix = ((size_t)n * p.OH + oh0 + oh_l) * p.OW + ow0 + ow_l;
+    const uint32_t pix = (uint32_t)((oh0 + oh_l) * p.OW + ow0 + ow_l);
+    const size_t o0 = ((size_t)n * p.OH * p.OW + pix) * p.out_cstride + p.out_coff + 4 * g;
 #pragma unroll
     for (int ob = 0; ob < 4; ob++) {
-      const int oc = ob * 16 + 4 * g;
-      if (oc >= p.OC) continue;
-      f32x4 v = acc[ob];
-      if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + oc);
+      if (ob * 16 >= p.OC) continue;
+      f32x4 v = acc[ob] + bias_v[ob];
+      if (LEAN) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act, p.slope);
-      const size_t o = pix * p.out_cstride + p.out_coff + oc;
-      if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-      else if (staged) *reinterpret_cast<u32x2*>(my_stage + ow_l * kRowPitch + oc * 2) = cvt_bf16x4(v);
-      else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v);
-    }
-    if (sizeof(TOut) == 2 && staged && (grp & 1)) {       // both halves of the row are in the tile: store it
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const size_t row0 = ((size_t)n * p.OH + oh0 + oh_l) * p.OW + ow0;
+        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], v[e] * sl);
+      } else {
 #pragma unroll
-      for (int k = 0; k < kTW * 8 / 64; k++) {
-        const int idx = k * 64 + lane, px = idx >> 3, ch = idx & 7;
-        const u32x4 q = *reinterpret_cast<const u32x4*>(my_stage + px * kRowPitch + ch * 16);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + (row0 + px) * p.out_cstride + p.out_coff + ch * 8) = q;
+        for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act, p.slope);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      const size_t o = o0 + ob * 16;
+      if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+      else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v);
     }
   }
 }
@@ -121,15 +113,23 @@ bool plan_image(const GatherParams& p, const GatherLaunch& l) {
   if (p.OC % 16 != 0 || p.OC > 64 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
   if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
   if ((reinterpret_cast<uintptr_t>(p.bias) & 15u) != 0) return false;
-  return (long)p.N * (p.OH / kTH) * (p.OW / kTW) < (1l << 31);
+  if ((long)p.IH * p.IW * p.IC >= (1l << 31) || p.N > 65535) return false;      // 32-bit offsets inside a sample; samples on grid.y
+  return (long)(p.OH / kTH) * (p.OW / kTW) < (1l << 31);
 }
 
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
-  const unsigned blocks = (unsigned)((long)p.N * (p.OH / kTH) * (p.OW / kTW));
-  if (blocks == 0) return GC_OK;
+  const unsigned blocks = (unsigned)((p.OH / kTH) * (p.OW / kTW));
+  if (blocks == 0 || p.N == 0) return GC_OK;
   ProfScope ps("gc::conv_image_kernel", l.flops, stream);
-  if (out_f32) hipLaunchKernelGGL(conv_image_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, p);
-  else hipLaunchKernelGGL(conv_image_kernel<uint16_t>, dim3(blocks), dim3(kThreads), 0, stream, p);
+  const bool lean = p.act == GC_ACT_NONE || p.act == GC_ACT_RELU || (p.act == GC_ACT_LRELU && p.slope >= 0.f && p.slope <= 1.f);
+  const dim3 grid(blocks, p.N);
+  if (out_f32) {
+    if (lean) hipLaunchKernelGGL((conv_image_kernel<float, true>), grid, dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL((conv_image_kernel<float, false>), grid, dim3(kThreads), 0, stream, p);
+  } else {
+    if (lean) hipLaunchKernelGGL((conv_image_kernel<uint16_t, true>), grid, dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL((conv_image_kernel<uint16_t, false>), grid, dim3(kThreads), 0, stream, p);
+  }
   return check_hip(hipGetLastError(), "conv_image launch");
 }
 
