@@ -90,6 +90,36 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
                           _out_code(out_dtype), float(weight_scale))
 
 
+def modulated_conv2d(input, weight, style, bias=None, stride=1, padding=0, demodulate=True, eps=1e-8, *, _wkey=0, precision=None,
+                     activation=None, negative_slope=0.2, out_dtype=None, weight_scale=1.0):
+    """EXTENSION -- not part of the reference, whose StyleGAN is version 1 (AdaIN, StyleGAN/model.py:179-261).  StyleGAN2's
+    modulated convolution: per sample n the weight is w'[o, i, k] = style[n, i] * c * weight[o, i, k] (c = weight_scale)
+    and, with `demodulate`, each output channel of w' is normalised to unit L2 norm (plus eps under the root); the result
+    is conv2d(input[n], w'[n]) (+ bias, activation).  Computed without per-sample weights: the style scales the INPUT
+    channels in front of one ordinary convolution (gan_amd kernels), the normalisation factor
+    d[n, o] = rsqrt(sum_i style[n, i]^2 * sum_k (c * weight[o, i, k])^2 + eps) scales the OUTPUT channels behind it.
+    style: [N, Cin].  Differentiable to second order in input, weight and style."""
+    _check_input(input, weight)
+    N, Cin = input.shape[0], input.shape[1]
+    if style.shape != (N, Cin):
+        raise RuntimeError(f"ganconv: style must be [N, Cin] = [{N}, {Cin}], got {tuple(style.shape)}")
+    if Cin % 4 or weight.shape[0] % 4:
+        raise RuntimeError("ganconv: modulated_conv2d needs channel counts that are multiples of 4")
+    style = style.to(torch.float32)
+    y = conv2d(ops.channel_scale(input, style), weight, None, stride, padding, _wkey=_wkey, precision=precision, out_dtype=out_dtype,
+               weight_scale=weight_scale)
+    if demodulate:
+        w2 = (weight.to(torch.float32) * float(weight_scale)).square().sum((2, 3))          # [Cout, Cin]
+        y = ops.channel_scale(y, torch.rsqrt(style.square() @ w2.t() + eps))
+    if bias is not None:
+        y = y + bias.to(y.dtype).view(1, -1, 1, 1)
+    if activation is not None:
+        code = _act_code(activation)
+        y = (torch.relu(y) if code == 1 else torch.nn.functional.leaky_relu(y, negative_slope) if code == 2 else
+             torch.tanh(y) if code == 3 else torch.sigmoid(y))
+    return y
+
+
 def blur3x3(input):
     return ops.blur3x3(input)
 

@@ -84,6 +84,28 @@ class ConvTranspose2d(_FusedActivation, _KeyedWeight, torch.nn.ConvTranspose2d):
                                   out_dtype=self.out_dtype)
 
 
+class ModulatedConv2d(_KeyedWeight, torch.nn.Module):
+    """EXTENSION (StyleGAN2; the reference has no counterpart): convolution whose weight is modulated per sample by a
+    style vector and optionally demodulated, see functional.modulated_conv2d.  `affine` maps the latent [N, style_dim] to
+    the per-input-channel scale (bias initialised to 1, as in StyleGAN2); weight [Cout, Cin, k, k] ~ N(0, 1) with the
+    equalised-learning-rate scalar 1 / sqrt(Cin k^2) folded into the kernel's weight image."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, style_dim, demodulate=True, padding=None, eps=1e-8):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.padding = kernel_size // 2 if padding is None else padding
+        self.demodulate, self.eps = demodulate, eps
+        self.weight = torch.nn.Parameter(torch.randn(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+        self.affine = torch.nn.Linear(style_dim, in_channels)
+        torch.nn.init.ones_(self.affine.bias)
+        self.scale = 1.0 / (in_channels * kernel_size * kernel_size) ** 0.5
+
+    def forward(self, input, latent):
+        return F.modulated_conv2d(input, self.weight, self.affine(latent), self.bias, 1, self.padding, self.demodulate, self.eps,
+                                  _wkey=self._wkey_for(self.weight), weight_scale=self.scale)
+
+
 class BlurLayer(torch.nn.Module):
     """Depthwise 3x3 binomial blur (reference StyleGAN/model.py:140-150)."""
 

@@ -1429,6 +1429,66 @@ torch.library.register_autograd("ganconv::pool2x2", lambda ctx, g: (replicate2x(
 torch.library.register_autograd("ganconv::replicate2x", lambda ctx, g: (pool2x2(g, ctx.scale), None), setup_context=_scale_ctx)
 
 
+# ---- per-sample channel scaling and its adjoint reduction: the halves of a modulated convolution (an extension: the
+# reference's StyleGAN is version 1, StyleGAN/model.py:179-261, and has none) ------------------------------------------
+@torch.library.custom_op("ganconv::channel_scale", mutates_args=())
+def channel_scale(x: Tensor, s: Tensor) -> Tensor:
+    """x[n, c, h, w] * s[n, c]; x fp32 or bf16 with C a multiple of 4, s float [N, C]."""
+    _check_cuda(x, s)
+    N, C, H, W = x.shape
+    if s.shape != (N, C):
+        raise RuntimeError("ganconv: channel_scale expects s of shape [N, C]")
+    x = _nhwc(x)
+    s = s.to(torch.float32).contiguous()
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_channel_scale(_ptr(x), _ptr(s), _ptr(y), N, H * W, C, _dtype_code(x), _stream()), "gc_channel_scale")
+    return y
+
+
+@channel_scale.register_fake
+def _(x, s):
+    return torch.empty_like(x, memory_format=torch.channels_last)
+
+
+@torch.library.custom_op("ganconv::rowdot", mutates_args=())
+def rowdot(a: Tensor, b: Tensor) -> Tensor:
+    """float [N, C]: sum over h, w of a[n, c, h, w] * b[n, c, h, w] (fixed summation order); a and b of one dtype."""
+    _check_cuda(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise RuntimeError("ganconv: rowdot expects two tensors of one shape and dtype")
+    N, C, H, W = a.shape
+    a, b = _nhwc(a), _nhwc(b)
+    out = torch.empty(N, C, dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    ws = torch.empty(max(L.gc_rowdot_workspace_bytes(N, H * W, C), 16), dtype=torch.uint8, device=a.device)
+    _lib.check(L.gc_rowdot(_ptr(a), _ptr(b), _ptr(out), _ptr(ws), ws.numel(), N, H * W, C, _dtype_code(a), _stream()), "gc_rowdot")
+    return out
+
+
+@rowdot.register_fake
+def _(a, b):
+    return a.new_empty(a.shape[0], a.shape[1], dtype=torch.float32)
+
+
+def _channel_scale_backward(ctx, g):
+    x, s = ctx.saved_tensors
+    gx = channel_scale(g, s) if ctx.needs_input_grad[0] else None
+    gs = rowdot(g, x).to(s.dtype) if ctx.needs_input_grad[1] else None
+    return gx, gs
+
+
+def _rowdot_backward(ctx, g):
+    a, b = ctx.saved_tensors
+    return (channel_scale(b, g) if ctx.needs_input_grad[0] else None,
+            channel_scale(a, g) if ctx.needs_input_grad[1] else None)
+
+
+torch.library.register_autograd("ganconv::channel_scale", _channel_scale_backward,
+                                setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1]))
+torch.library.register_autograd("ganconv::rowdot", _rowdot_backward,
+                                setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1]))
+
+
 # ---- reflection padding (Pix2Pix/models.py:162,185,204,210) and its adjoint, each other's gradient ---------------
 def _reflect(fn_name, x, pad, H, W, shape):
     _check_cuda(x)

@@ -300,6 +300,19 @@ int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32_t H, int32
 int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream);
 int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream);
 
+/* EXTENSION (no counterpart in the reference, whose StyleGAN is version 1 with AdaIN: StyleGAN/model.py:179-261): the two
+ * memory-bound halves of a StyleGAN2-style modulated convolution written without per-sample weights,
+ *   y[n, o] = d[n, o] * conv(x[n, i] * s[n, i], w)[o],  d[n, o] = rsqrt(sum_i s[n, i]^2 * sum_k w[o, i, k]^2 + eps),
+ * i.e. gc_channel_scale on the input, gc_conv2d_fprop, gc_channel_scale on the output.  NHWC tensors of one gc_dtype,
+ * C a multiple of 4, s / out float [N, C].
+ *   gc_channel_scale   y[n, p, c] = x[n, p, c] * s[n, c]                        (its gradient by x: the same call on gy)
+ *   gc_rowdot          out[n, c]  = sum over p of a[n, p, c] * b[n, p, c]       (the gradient by s: a = gy, b = x)
+ * gc_rowdot is a fixed-order reduction (no atomics); its workspace holds one partial row per slab of a sample. */
+int gc_channel_scale(const void* x, const float* s, void* y, int32_t N, int32_t HW, int32_t C, int32_t dtype, void* stream);
+size_t gc_rowdot_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int gc_rowdot(const void* a, const void* b, float* out, void* workspace, size_t workspace_bytes, int32_t N, int32_t HW, int32_t C,
+              int32_t dtype, void* stream);
+
 /* The weight gradient of ONE layer summed over several (x, gy) pairs in one launch: gw (+)= alpha * sum over segments g of
  * wgrad(xs[g], gys[g]), segment g holding Ns[g] samples (1 to 4 segments; desc->N is ignored, everything else in the
  * descriptor is shared).  For the passes of a training phase that all add to the same weight gradient -- in a WGAN-GP
