@@ -20,7 +20,7 @@ EXPORTS = (
     "gc_version", "gc_last_error", "gc_packed_weight_bytes", "gc_pack_weight", "gc_conv2d_fprop", "gc_conv2d_dgrad",
     "gc_wgrad_workspace_bytes", "gc_conv2d_wgrad", "gc_conv2d_wgrad_noalloc", "gc_dwblur3x3", "gc_profile_enable", "gc_profile_collect",
     "gc_instnorm_act_fwd", "gc_instnorm_act_bwd", "gc_instnorm_act_bwd_bwd",
-    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_channel_sum_workspace_bytes", "gc_channel_sum", "gc_act_backward_channel_sum", "gc_batchnorm_stats", "gc_batchnorm_act_bwd_sums", "gc_batchnorm_act_bwd_apply", "gc_adam_step", "gc_adam_ema_step", "gc_set_split_reduction", "gc_set_patch_kernel", "gc_pack_weights", "gc_attention_fwd", "gc_attention_bwd", "gc_pool2x2", "gc_replicate2x", "gc_reflect_pad", "gc_reflect_pad_adjoint",
+    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_fwd_rows", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_channel_sum_workspace_bytes", "gc_channel_sum", "gc_act_backward_channel_sum", "gc_batchnorm_stats", "gc_batchnorm_act_bwd_sums", "gc_batchnorm_act_bwd_apply", "gc_adam_step", "gc_adam_ema_step", "gc_set_split_reduction", "gc_set_patch_kernel", "gc_pack_weights", "gc_attention_fwd", "gc_attention_bwd", "gc_pool2x2", "gc_replicate2x", "gc_reflect_pad", "gc_reflect_pad_adjoint",
     "gc_cond_batchnorm_workspace_bytes", "gc_cond_batchnorm_act_fwd", "gc_cond_batchnorm_act_bwd", "gc_noise_lrelu_adain_workspace_bytes", "gc_noise_lrelu_adain_fwd", "gc_noise_lrelu_adain_bwd",
     "gc_wgrad_multi_workspace_bytes", "gc_conv2d_wgrad_multi",
     "gc_channel_scale", "gc_rowdot_workspace_bytes", "gc_rowdot",
@@ -36,7 +36,8 @@ class ConvDesc(ctypes.Structure):
 
 class Epilogue(ctypes.Structure):
     _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("bias", ctypes.c_void_p), ("ch_sum", ctypes.c_void_p),
-                ("ch_sumsq", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("grad_mask", ctypes.c_void_p)]
+                ("ch_sumsq", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("grad_mask", ctypes.c_void_p),
+                ("stat_rows", ctypes.c_void_p), ("stat_rows_capacity", ctypes.c_int32), ("stat_rows_written", ctypes.POINTER(ctypes.c_int32))]
 
 
 _lib = None
@@ -89,6 +90,7 @@ def lib():
     L.gc_batchnorm_workspace_bytes.restype = sz
     L.gc_batchnorm_workspace_bytes.argtypes = [i64, i32]
     L.gc_batchnorm_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, i32, i32, f32, f32, i32, f32, i32, vp]
+    L.gc_batchnorm_act_fwd_rows.argtypes = [vp] * 12 + [i32, vp, sz, i64, i32, i32, f32, f32, i32, f32, vp]
     L.gc_cond_batchnorm_workspace_bytes.restype = sz
     L.gc_cond_batchnorm_workspace_bytes.argtypes = [i32, i32, i32]
     L.gc_cond_batchnorm_act_fwd.argtypes = [vp] * 11 + [sz, i32, i32, i32, i32, f32, f32, i32, f32, i32, vp]

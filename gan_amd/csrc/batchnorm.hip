@@ -155,7 +155,24 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
   const int c = blockIdx.x * kFinCh + tc;
   const bool cok = c < p.C;
   float n = 0.f, a = 0.f, b = 0.f;   // forward: count, mean, M2;  backward: -, sum g, sum g*xh
-  if (MODE == 1 && p.sps > 0) {      // conditional: per-sample sums are outputs, their gain-weighted totals feed gx
+  if (MODE == 2) {                   // (sum, sum of squares) per slice of the rows the convolution in front wrote: plain sums in double
+    __shared__ double sh_s[kThreads], sh_q[kThreads];
+    double ds = 0.0, dq = 0.0;
+    if (cok)
+      for (int s = lane; s < p.slabs; s += kFinLanes) {
+        const double* v = reinterpret_cast<const double*>(p.part) + ((size_t)s * p.C + c) * 2;
+        ds += v[0];
+        dq += v[1];
+      }
+    sh_s[t] = ds; sh_q[t] = dq;
+    __syncthreads();
+    if (lane != 0 || !cok) return;
+    for (int l = 1; l < kFinLanes; l++) { ds += sh_s[l * kFinCh + tc]; dq += sh_q[l * kFinCh + tc]; }
+    const double dmean = ds / (double)p.P;
+    double m2 = dq - ds * dmean;
+    if (m2 < 0.0) m2 = 0.0;
+    a = (float)dmean; b = (float)m2;
+  } else if (MODE == 1 && p.sps > 0) {      // conditional: per-sample sums are outputs, their gain-weighted totals feed gx
     if (cok)
       for (int smp = lane; smp < p.nsamp; smp += kFinLanes) {
         float sg = 0.f, sgx = 0.f;
@@ -186,10 +203,12 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
         b += v.y;
       }
     }
+  if (MODE != 2) {
   sh_a[t] = a; sh_b[t] = b; sh_n[t] = n;
   __syncthreads();
   if (lane != 0 || !cok) return;
-  for (int l = 1; l < kFinLanes; l++) {
+  }
+  for (int l = 1; MODE != 2 && l < kFinLanes; l++) {
     const float va = sh_a[l * kFinCh + tc], vb = sh_b[l * kFinCh + tc], nb = sh_n[l * kFinCh + tc];
     if (MODE == 0) {
       if (nb > 0.f) {
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
       b += vb;
     }
   }
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 2) {
     const float mean = a, var = b / (float)p.P;
     const float r = rsqrtf(var + p.eps);
     p.save_mean[c] = mean;
@@ -226,6 +245,29 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
     p.coef[c] = a / (float)p.P;
     p.coef[p.C + c] = b / (float)p.P;
   }
+}
+
+// Rows of (sum, sum of squares) per channel, written by a convolution's epilogue -> one pair of doubles per slice of rows.
+// grid: (channel chunks of 16, slices); thread (channel, lane) adds the rows lane, lane + 16, ... of its slice, lane 0
+// merges the lanes: a fixed order.
+__global__ __launch_bounds__(kThreads) void bn_rows_partial_kernel(const float* rows, double* out, int n_rows, int rows_per_slice, int C) {
+  __shared__ double sh_s[kThreads], sh_q[kThreads];
+  const int t = threadIdx.x, tc = t & (kFinCh - 1), lane = t / kFinCh;
+  const int c = blockIdx.x * kFinCh + tc;
+  const int r0 = blockIdx.y * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);
+  double ds = 0.0, dq = 0.0;
+  if (c < C)
+    for (int r = r0 + lane; r < r1; r += kFinLanes) {
+      const float2 v = *reinterpret_cast<const float2*>(rows + ((size_t)r * C + c) * 2);
+      ds += (double)v.x;
+      dq += (double)v.y;
+    }
+  sh_s[t] = ds; sh_q[t] = dq;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  for (int l = 1; l < kFinLanes; l++) { ds += sh_s[l * kFinCh + tc]; dq += sh_q[l * kFinCh + tc]; }
+  out[((size_t)blockIdx.y * C + c) * 2] = ds;
+  out[((size_t)blockIdx.y * C + c) * 2 + 1] = dq;
 }
 
 __global__ __launch_bounds__(kThreads) void bn_update_running_kernel(float* rm, float* rv, int64_t* nbt, const float* mean, const float* var,
@@ -555,7 +597,8 @@ size_t gc_cond_batchnorm_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
 static int bn_forward(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
                       void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, float eps, float momentum,
-                      int32_t act, float slope, int32_t training, void* stream, int32_t nsamp) {
+                      int32_t act, float slope, int32_t training, void* stream, int32_t nsamp, const float* stat_rows = nullptr,
+                      int32_t n_rows = 0) {
   if (dtype != GC_F32 && dtype != GC_BF16) { set_error("batchnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
   if (dtype == GC_BF16 && y_bf16 != nullptr) { set_error("batchnorm: bf16 tensors need no bf16 copy"); return GC_BAD_ARGUMENT; }
   if (P < 0 || C <= 0 || P >= (1ll << 31)) { set_error("batchnorm: bad shape"); return GC_BAD_ARGUMENT; }
@@ -586,6 +629,28 @@ static int bn_forward(const void* x, void* y, void* y_bf16, const float* gamma, 
   hipStream_t s = (hipStream_t)stream;
   const int chunks = (C / 4 + kQB - 1) / kQB;
   const dim3 grid((unsigned)(p.slabs * chunks)), block(kThreads);
+  if (stat_rows != nullptr) {          // statistics from the rows the convolution in front wrote: finalize + apply
+    int slices = n_rows / 128;
+    if (slices < 1) slices = 1;
+    if (slices > 64) slices = 64;
+    const int per = (n_rows + slices - 1) / slices;
+    slices = (n_rows + per - 1) / per;
+    if ((size_t)slices * C * 2 * sizeof(double) > (size_t)p.slabs * C * 2 * sizeof(float)) {
+      set_error("batchnorm: workspace too small for %d slices of statistics rows", slices); return GC_WORKSPACE_TOO_SMALL;
+    }
+    BnParams q = p;
+    q.slabs = slices;
+    {
+      ProfScope ps("gc::bn_rows_partial_kernel", 0.0, s);
+      hipLaunchKernelGGL(bn_rows_partial_kernel, dim3((C + kFinCh - 1) / kFinCh, slices), block, 0, s, stat_rows, reinterpret_cast<double*>(p.part),
+                         n_rows, per, C);
+    }
+    { ProfScope ps("gc::bn_finalize_kernel<2>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<2>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, q); }
+    ProfScope ps("gc::bn_apply_kernel<0>", 0.0, s);
+    if (dtype == GC_F32) hipLaunchKernelGGL((bn_apply_kernel<0, float>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((bn_apply_kernel<0, uint16_t>), grid, block, 0, s, p);
+    return check_hip(hipGetLastError(), "batchnorm forward launch");
+  }
   if (training && nsamp == 0 && P <= kSmallPBn) {
     ProfScope ps("gc::bn_small_kernel<0>", 0.0, s);
     const dim3 sgrid((unsigned)((C / 4 + kSmallQB - 1) / kSmallQB));
@@ -618,6 +683,15 @@ int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamm
                          int32_t act, float slope, int32_t training, void* stream) {
   return bn_forward(x, y, y_bf16, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, save_var, workspace,
                     workspace_bytes, P, C, dtype, eps, momentum, act, slope, training, stream, 0);
+}
+
+int gc_batchnorm_act_fwd_rows(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                              const float* stat_rows, int32_t n_rows, void* workspace, size_t workspace_bytes, int64_t P, int32_t C,
+                              int32_t dtype, float eps, float momentum, int32_t act, float slope, void* stream) {
+  if (stat_rows == nullptr || n_rows <= 0 || misaligned(stat_rows, 7)) { set_error("batchnorm: rows of statistics expected"); return GC_BAD_ARGUMENT; }
+  return bn_forward(x, y, y_bf16, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, save_var, workspace,
+                    workspace_bytes, P, C, dtype, eps, momentum, act, slope, 1, stream, 0, stat_rows, n_rows);
 }
 
 int gc_cond_batchnorm_act_fwd(const void* x, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,

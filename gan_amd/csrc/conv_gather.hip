@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
   for (int i = 0; i < C::FO; i++)
 #pragma unroll
     for (int r = 0; r < 4; r++) ssum[i][r] = ssq[i][r] = 0.f;
-  const bool stats = p.ch_sum != nullptr;
+  const bool stats = p.ch_sum != nullptr || p.stat_rows != nullptr;
   const bool of32 = p.out_f32 != 0;
   const int osz = of32 ? 4 : 2;
 #pragma unroll
@@ -356,8 +356,13 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
         }
         const int oc = oc0 + wo * (TO / C::WO) + i * 16 + (lane >> 4) * 4 + r;
         if ((lane & 15) == 0 && oc < p.OC) {
-          atomicAdd(p.ch_sum + oc, s);
-          if (p.ch_sumsq != nullptr) atomicAdd(p.ch_sumsq + oc, q);
+          if (p.stat_rows != nullptr) {      // this wave's pixels of this tile are one row of the partial table
+            const size_t row = (size_t)((p.tt.cls_tile_start[cls] + m0 / TP) * C::WP + wp_);
+            *reinterpret_cast<float2*>(p.stat_rows + (row * (size_t)p.OC + oc) * 2) = float2{s, q};
+          } else {
+            atomicAdd(p.ch_sum + oc, s);
+            if (p.ch_sumsq != nullptr) atomicAdd(p.ch_sumsq + oc, q);
+          }
         }
       }
   }
@@ -423,9 +428,10 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   // Split the reduction when the grid cannot fill the chip and the output can take fp32 adds.
   p.ksplit = 1;
   const long blocks = (long)tiles * p.n_oc_tiles;
-  const bool can_split = split_reduction_allowed() && p.out_f32 != 0 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
+  const bool can_split = split_reduction_allowed() && p.out_f32 != 0 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.stat_rows == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
   // (only for small outputs: the partial tiles are added with per-lane fp32 atomics whose access shape is slow)
-  if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= 65536) {
+  static const long split_max_out = getenv("GC_SPLIT_MAX_OUT") ? atol(getenv("GC_SPLIT_MAX_OUT")) : 65536;
+  if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= split_max_out) {
     long want = (256 + blocks - 1) / blocks;
     if (want > min_steps / 8) want = min_steps / 8;
     if (want > 32) want = 32;
@@ -472,8 +478,14 @@ static int launch_mode(const GatherParams& p, const GatherLaunch& l, hipStream_t
   return launch_tile<TIn, X3, kThinInput>(p, l, s);
 }
 
-int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t s) {
-  if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
+int launch_gather(const GatherParams& p0, const GatherLaunch& l, hipStream_t s) {
+  if (p0.n_pix_tiles == 0 || p0.n_oc_tiles == 0) return GC_OK;
+  GatherParams p = p0;
+  if (p.stat_rows != nullptr) {     // one row per wave's pixel share of a tile; no rows when they do not fit the caller's table
+    const int rows = p.n_pix_tiles * (l.to >= 64 ? 2 : 4);
+    if (p.ksplit == 1 && rows <= p.stat_cap) *p.stat_written = rows;
+    else p.stat_rows = nullptr;
+  }
   if (l.in_bf16) return launch_mode<uint16_t, false>(p, l, s);
   return l.x3 ? launch_mode<float, true>(p, l, s) : launch_mode<float, false>(p, l, s);
 }

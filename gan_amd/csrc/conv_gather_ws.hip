@@ -53,6 +53,7 @@ struct WsParams {
   const float* bias;
   float* ch_sum;
   float* ch_sumsq;
+  float* stat_rows;                 // null, or [pixel tile * WP + wave's pixel part][OC][2]: (sum, sum of squares) of the stored values
   uint16_t* out_bf16;
   const void* mask;                 // null, or indexed like `out`: the stored value is scaled by (mask > 0 ? 1 : mask_slope)
   unsigned long long* diag_buf;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
   const int g = lane >> 4, c16 = lane & 15;
   TOut* out = reinterpret_cast<TOut*>(p.out);
   const TOut* mask = reinterpret_cast<const TOut*>(p.mask);
-  const bool stats = p.ch_sum != nullptr;
+  const bool stats = !MASK && (p.ch_sum != nullptr || p.stat_rows != nullptr);      // (a masked gradient never carries statistics)
   const float sl = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);   // v > 0 ? v : v * sl
   unsigned long long epi_cycles = 0, wait_cycles = 0;
   int st_c = 0;
@@ -410,8 +411,13 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
           }
           const int oc = oc_w + (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r;
           if (c16 == 0) {
-            atomicAdd(p.ch_sum + oc, s);
-            if (p.ch_sumsq != nullptr) atomicAdd(p.ch_sumsq + oc, q);
+            if (p.stat_rows != nullptr) {      // this wave's pixels of this tile are one row of the partial table
+              const size_t row = (size_t)((id.m0 / kTP + p.cls[id.cls].tile_start) * WP + wp_);
+              *reinterpret_cast<float2*>(p.stat_rows + (row * (size_t)(p.n_oc_tiles * TO) + oc) * 2) = float2{s, q};
+            } else {
+              atomicAdd(p.ch_sum + oc, s);
+              if (p.ch_sumsq != nullptr) atomicAdd(p.ch_sumsq + oc, q);
+            }
           }
         }
     }
@@ -492,6 +498,10 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
   WsParams p;
   memset(&p, 0, sizeof(p));
   p.in = g.in; p.wp = g.wp; p.out = g.out; p.bias = g.bias; p.ch_sum = g.ch_sum; p.ch_sumsq = g.ch_sumsq; p.out_bf16 = g.out_bf16;
+  if (g.stat_rows != nullptr) {      // one row per consumer wave's pixel share of a tile (4 or 2 per 128-pixel tile)
+    const int rows = g.n_pix_tiles * (l.to >= 128 ? kNW / 2 : kNW);
+    if (rows <= g.stat_cap) { p.stat_rows = g.stat_rows; *g.stat_written = rows; }
+  }
   p.in_bytes = (int32_t)g.in_bytes; p.w_bytes = (int32_t)g.w_bytes; p.a_bias = g.a_bias;
   p.IH = g.IH; p.IW = g.IW; p.IC = g.IC; p.ICp = g.ICp; p.csteps = g.ICp / kBK; p.OH = g.OH; p.OW = g.OW; p.row_pitch = g.row_pitch;
   p.a = g.a; p.b = g.b;

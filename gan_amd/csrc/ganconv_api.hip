@@ -381,10 +381,15 @@ int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 
 static void fill_epilogue(GatherParams& p, const gc_epilogue* ep) {
   p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.out_bf16 = nullptr; p.mask = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
+  p.stat_rows = nullptr; p.stat_cap = 0; p.stat_written = nullptr;
   if (ep != nullptr) {
     p.bias = ep->bias; p.ch_sum = ep->ch_sum; p.ch_sumsq = ep->ch_sumsq; p.act = ep->act; p.slope = ep->slope;
     p.out_bf16 = (uint16_t*)ep->out_bf16; p.mask = ep->grad_mask;
     if (p.mask != nullptr) { p.mask_slope = ep->slope; p.slope = 0.f; }
+    if (ep->stat_rows != nullptr) {
+      p.stat_rows = ep->stat_rows; p.stat_cap = ep->stat_rows_capacity; p.stat_written = ep->stat_rows_written;
+      *p.stat_written = 0;
+    }
   }
 }
 
@@ -400,6 +405,12 @@ static int check_epilogue(const gc_epilogue* ep) {
   }
   if (reinterpret_cast<uintptr_t>(ep->out_bf16) & 7u) { set_error("out_bf16 must be 8-byte aligned"); return GC_BAD_ARGUMENT; }
   if (ep->ch_sumsq != nullptr && ep->ch_sum == nullptr) { set_error("ch_sumsq needs ch_sum"); return GC_BAD_ARGUMENT; }
+  if (ep->stat_rows != nullptr) {
+    if (ep->stat_rows_written == nullptr || ep->stat_rows_capacity < 0 || (reinterpret_cast<uintptr_t>(ep->stat_rows) & 7u)) {
+      set_error("stat_rows needs stat_rows_written, a capacity >= 0 and 8-byte alignment"); return GC_BAD_ARGUMENT;
+    }
+    if (ep->ch_sum != nullptr || ep->grad_mask != nullptr) { set_error("stat_rows excludes ch_sum and grad_mask"); return GC_BAD_ARGUMENT; }
+  }
   return GC_OK;
 }
 

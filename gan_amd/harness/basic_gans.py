@@ -40,6 +40,8 @@ class Generator(torch.nn.Module):
                                        out_dtype=torch.float32 if last else (activation_dtype if first else None))
             layers.append(_seq(conv) if last else _seq(conv, gnn.BatchNormAct2d(cout, activation="relu")))
         self.main = _seq(*layers)
+        if fused_batchnorm_statistics:
+            gnn.fuse_batchnorm_statistics(self)      # the BatchNorm layers take their batch statistics from the convolutions' epilogues
 
     def forward(self, noise_vector):
         return self.main(noise_vector)
@@ -68,6 +70,8 @@ class Discriminator(torch.nn.Module):
                 ops.append(gnn.BatchNormAct2d(cout, activation="leaky_relu", negative_slope=0.2))
             layers.append(_seq(*ops))
         self.main = _seq(*layers)
+        if fused_batchnorm_statistics:
+            gnn.fuse_batchnorm_statistics(self)
 
     def forward(self, x):
         return self.main(x)
@@ -86,6 +90,7 @@ def weights_init(m):
 _side_streams = {}
 
 
+fused_batchnorm_statistics = True     # networks built while this is set: see gan_amd.nn.fuse_batchnorm_statistics
 flush_lanes = 2              # side streams that share the layers' weight-gradient launches with the calling stream
 serialize_chains = False     # True: the chains run one after the other on the calling stream (same kernels; for per-kernel timing)
 

@@ -36,7 +36,7 @@ def _batch_norm(ch, activation=None):
 class DownSample(torch.nn.Module):
     def __init__(self, in_ch, out_ch, inplace=False, use_bn=True):
         super().__init__()
-        self.downsample = gnn.Conv2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1)
+        self.downsample = gnn.Conv2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1, channel_statistics=use_bn and _FUSED_NORM)
         self.relu = torch.nn.LeakyReLU(0.2, inplace=inplace)
         self.batch_norm = _batch_norm(out_ch) if use_bn else torch.nn.Identity()
 
@@ -51,7 +51,7 @@ class UpSample(torch.nn.Module):
             raise RuntimeError("the bilinear-upsample variant is not on the reference's path (Generator never enables it)")
         # (the last block, without BatchNorm, feeds tanh: fused into its epilogue, image in float32)
         self.up_sample = gnn.ConvTranspose2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1, activation=None if use_bn else "tanh",
-                                             out_dtype=None if use_bn else torch.float32)
+                                             out_dtype=None if use_bn else torch.float32, channel_statistics=use_bn and _FUSED_NORM)
         self.batch_norm = _batch_norm(out_ch) if use_bn else torch.nn.Identity()
         self.leaky_relu = torch.nn.ReLU()
 
@@ -166,11 +166,11 @@ class Discriminator(torch.nn.Module):
         super().__init__()
         self.fused = _FUSED_NORM
         self.conv_1 = gnn.Conv2d(image_dim, ch, 4, 2, 1, activation="relu", out_dtype=_ACT_DTYPE)      # ReLU in the epilogue
-        self.conv_2 = gnn.Conv2d(ch, ch * 2, 4, 2, 1)
+        self.conv_2 = gnn.Conv2d(ch, ch * 2, 4, 2, 1, channel_statistics=_FUSED_NORM)
         self.batch_norm_1 = _batch_norm(ch * 2, "relu")
-        self.conv_3 = gnn.Conv2d(ch * 2, ch * 4, 4, 2, 1)
+        self.conv_3 = gnn.Conv2d(ch * 2, ch * 4, 4, 2, 1, channel_statistics=_FUSED_NORM)
         self.batch_norm_2 = _batch_norm(ch * 4, "relu")
-        self.conv_4 = gnn.Conv2d(ch * 4, ch * 8, 4, 1, 1)
+        self.conv_4 = gnn.Conv2d(ch * 4, ch * 8, 4, 1, 1, channel_statistics=_FUSED_NORM)
         self.batch_norm_3 = _batch_norm(ch * 8, "relu")
         self.conv_5 = gnn.Conv2d(ch * 8, 1, 4, 1, 1, out_dtype=torch.float32)
 

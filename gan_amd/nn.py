@@ -9,12 +9,32 @@ the functional form with a transformed weight (BigGAN/model.py:48-58) keep worki
 
 Reference call sites: BasicGANs/models.py:35,77; Pix2Pix/models.py:17,83,123-124,225-232; StyleGAN/model.py:72.
 """
+import contextlib
 import weakref
 
 import torch
 
 from . import functional as F
 from . import ops
+
+
+_NO_CONTEXT = contextlib.nullcontext()
+
+
+def fuse_batchnorm_statistics(module, on=True):
+    """Marks every Conv2d / ConvTranspose2d of this package that sits right in front of a training-mode BatchNormAct2d
+    (non-conditional, statistics per rank) inside a torch.nn.Sequential of `module`: its kernel then also writes the rows of
+    per-channel sums the BatchNorm needs, and the BatchNorm skips its own statistics sweep over the tensor
+    (BasicGANs/models.py:35-37,77-79; Pix2Pix/models.py:83-86,123-127).  Returns the number of pairs found."""
+    n = 0
+    for seq in module.modules():
+        if isinstance(seq, torch.nn.Sequential):
+            kids = list(seq.children())
+            for a, b in zip(kids, kids[1:]):
+                if isinstance(a, (Conv2d, ConvTranspose2d)) and isinstance(b, BatchNormAct2d) and not getattr(b, "sync_stats", False):
+                    a.channel_statistics = bool(on)
+                    n += 1
+    return n
 
 
 class _KeyedWeight:
@@ -53,24 +73,27 @@ class Conv2d(_FusedActivation, _KeyedWeight, torch.nn.Conv2d):
     with a ReLU or LeakyReLU between them, the consumer being the activated tensor's only reader)."""
 
     def __init__(self, *args, activation=None, negative_slope=0.2, out_dtype=None, defer_activation_grad=False,
-                 input_activation_slope=None, **kwargs):
+                 input_activation_slope=None, channel_statistics=False, **kwargs):
         super().__init__(*args, **kwargs)
         self._init_activation(activation, negative_slope, out_dtype)
         self.defer_activation_grad, self.input_activation_slope = defer_activation_grad, input_activation_slope
+        self.channel_statistics = channel_statistics      # True: a BatchNormAct2d reads the output next (fuse_batchnorm_statistics)
 
     def _conv_forward(self, input, weight, bias):
         if self.padding_mode != "zeros":
             raise RuntimeError("ganconv: only zero padding is supported")
         key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
-        return F.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key,
-                        activation=self.activation, negative_slope=self.negative_slope, out_dtype=self.out_dtype,
-                        defer_activation_grad=self.defer_activation_grad, input_activation_slope=self.input_activation_slope)
+        with ops.channel_statistics_request() if (self.channel_statistics and self.training) else _NO_CONTEXT:
+            return F.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key,
+                            activation=self.activation, negative_slope=self.negative_slope, out_dtype=self.out_dtype,
+                            defer_activation_grad=self.defer_activation_grad, input_activation_slope=self.input_activation_slope)
 
 
 class ConvTranspose2d(_FusedActivation, _KeyedWeight, torch.nn.ConvTranspose2d):
-    def __init__(self, *args, activation=None, negative_slope=0.2, out_dtype=None, **kwargs):
+    def __init__(self, *args, activation=None, negative_slope=0.2, out_dtype=None, channel_statistics=False, **kwargs):
         super().__init__(*args, **kwargs)
         self._init_activation(activation, negative_slope, out_dtype)
+        self.channel_statistics = channel_statistics
 
     def forward(self, input, output_size=None):
         if self.padding_mode != "zeros":
@@ -79,9 +102,10 @@ class ConvTranspose2d(_FusedActivation, _KeyedWeight, torch.nn.ConvTranspose2d):
             raise RuntimeError("ganconv: output_size is not supported; use output_padding")
         weight = self.weight
         key = self._wkey_for(weight) if weight is self._parameters.get("weight") else 0
-        return F.conv_transpose2d(input, weight, self.bias, self.stride, self.padding, self.output_padding, self.groups,
-                                  self.dilation, _wkey=key, activation=self.activation, negative_slope=self.negative_slope,
-                                  out_dtype=self.out_dtype)
+        with ops.channel_statistics_request() if (self.channel_statistics and self.training) else _NO_CONTEXT:
+            return F.conv_transpose2d(input, weight, self.bias, self.stride, self.padding, self.output_padding, self.groups,
+                                      self.dilation, _wkey=key, activation=self.activation, negative_slope=self.negative_slope,
+                                      out_dtype=self.out_dtype)
 
 
 class ModulatedConv2d(_KeyedWeight, torch.nn.Module):
@@ -239,4 +263,6 @@ def convert_sync_batchnorm(module, process_group=None):
     for m in module.modules():
         if isinstance(m, BatchNormAct2d):
             m.sync_stats, m.process_group = True, process_group
+        elif isinstance(m, (Conv2d, ConvTranspose2d)):
+            m.channel_statistics = False       # (rows of one rank's sums are of no use to statistics over all ranks)
     return module

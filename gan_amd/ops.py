@@ -15,6 +15,7 @@ include/ganconv.h.  There is no fallback: on a CPU tensor, a missing library or 
 raise RuntimeError.
 """
 import ctypes
+import os
 import threading
 import weakref
 from typing import Optional
@@ -362,6 +363,47 @@ def _bf16_twin(t):
     return tb
 
 
+# ---- batch statistics from the convolution in front of a BatchNorm -------------------------------------------------
+# A convolution called inside channel_statistics_request() asks its kernel for rows of per-channel (sum, sum of squares)
+# of the values it stores (gc_epilogue.stat_rows).  When the kernel chosen for the problem provides them, the rows are
+# remembered under the output tensor, and the training-mode BatchNorm that reads this tensor next takes its batch
+# statistics from them (gc_batchnorm_act_fwd_rows) instead of from a sweep of its own over the tensor.
+_want_rows = [False]
+_row_cache = {}       # (data_ptr, shape) -> (output tensor, rows, number of rows): consumed once
+_ROW_CACHE_MAX = 8
+
+
+class channel_statistics_request:
+    def __enter__(self):
+        self.was, _want_rows[0] = _want_rows[0], True
+
+    def __exit__(self, *exc):
+        _want_rows[0] = self.was
+
+
+def _rows_for(ep, out, C):
+    """Adds a request for statistics rows to the epilogue descriptor (created when there was none) if one is pending and
+    the output qualifies; returns (descriptor, (rows, counter) or None)."""
+    P = out.numel() // max(C, 1)
+    if not _want_rows[0] or C % 4 or P <= 1024 or (ep is not None and ep.grad_mask):
+        return ep, None
+    if ep is None:
+        ep = Epilogue()
+    cap = 4 * ((P + 127) // 128 + 16)
+    rows = torch.empty(cap * C * 2, dtype=torch.float32, device=out.device)
+    written = ctypes.c_int32(0)
+    ep.stat_rows, ep.stat_rows_capacity, ep.stat_rows_written = rows.data_ptr(), cap, ctypes.pointer(written)
+    return ep, (rows, written)
+
+
+def _remember_rows(out, got):
+    if got is not None and got[1].value > 0:
+        with _lock:
+            if len(_row_cache) >= _ROW_CACHE_MAX:
+                _row_cache.pop(next(iter(_row_cache)), None)
+            _row_cache[(out.data_ptr(), tuple(out.shape))] = (out, got[0], got[1].value)
+
+
 def _optr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -373,10 +415,13 @@ def _out_dtype(t, code):
     return t.dtype if code == _OUT_SAME else (torch.bfloat16 if code == _OUT_BF16 else torch.float32)
 
 
+_SPLIT_MAX_OUT = int(os.environ.get("GC_SPLIT_MAX_OUT", 65536))
+
+
 def _small_output_in_f32(numel, dtype, act):
     """Small outputs with long reductions run as split reductions, which add fp32 partial tiles into the output: a bf16
     result of that size is computed in fp32 and rounded afterwards (a few KB)."""
-    return dtype == torch.bfloat16 and act == 0 and numel <= 65536
+    return dtype == torch.bfloat16 and act == 0 and numel <= _SPLIT_MAX_OUT
 
 
 def _code_of(dtype):
@@ -535,9 +580,11 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(y))
     wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey, alpha)
     ep, keep = _epilogue(bias, act, slope, y if (act != 0 and y.dtype == torch.float32) else None)
+    ep, rows = (ep, None) if narrow else _rows_for(ep, y, Cout)
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_fprop")
+    _remember_rows(y, rows)
     return y.to(want) if narrow else y
 
 
@@ -577,9 +624,11 @@ def _dgrad_launch(gy, w, bias, H, W, stride, padding, precision, wkey, act, slop
             raise RuntimeError("ganconv: a masked data gradient takes no bias")
     else:
         ep, keep = _epilogue(bias, act, slope, gx if (act != 0 and gx.dtype == torch.float32) else None)
+    ep, rows = (ep, None) if narrow else _rows_for(ep, gx, Cin)
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(gx.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_dgrad")
+    _remember_rows(gx, rows)
     return gx.to(want) if narrow else gx
 
 
@@ -1110,6 +1159,14 @@ def _bn_forward_launch(x, weight, bias, running_mean, running_var, num_batches_t
                    "gc_cond_batchnorm_act_fwd")
         return y, mean, rstd, var
     ws = torch.empty(max(L.gc_batchnorm_workspace_bytes(P, C), 16), dtype=torch.uint8, device=x.device)
+    with _lock:
+        ent = _row_cache.pop((x.data_ptr(), tuple(x.shape)), None)
+    if ent is not None and training and ent[0].dtype == x.dtype and ent[0]._version == x._version:
+        _lib.check(L.gc_batchnorm_act_fwd_rows(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _optr(running_mean),
+                                               _optr(running_var), _optr(num_batches_tracked), _ptr(mean), _ptr(rstd), _ptr(var),
+                                               _ptr(ent[1]), ent[2], _ptr(ws), ws.numel(), P, C, dt, eps, momentum, act, slope, _stream()),
+                   "gc_batchnorm_act_fwd_rows")
+        return y, mean, rstd, var
     _lib.check(L.gc_batchnorm_act_fwd(_ptr(x), _ptr(y), _optr(_bf16_twin(y)), _optr(weight), _optr(bias), _optr(running_mean),
                                       _optr(running_var), _optr(num_batches_tracked), _ptr(mean), _ptr(rstd), _ptr(var), _ptr(ws),
                                       ws.numel(), P, C, dt, eps, momentum, act, slope, 1 if training else 0, _stream()),

@@ -93,6 +93,15 @@ typedef struct gc_epilogue {
                              kernel that computes the gradient instead of by aten::leaky_relu_backward /
                              threshold_backward behind it (BasicGANs/models.py:78, the critic's first LeakyReLU).  Needs
                              act == GC_ACT_NONE, no statistics and no out_bf16. */
+  float* stat_rows;       /* NULL, or float[stat_rows_capacity][C][2]: the kernel MAY write, per row of output pixels it
+                             chooses (one wave's share of a tile), the pair (sum, sum of squares) of the stored values of
+                             every output channel -- plain stores in a fixed layout, so that a fixed-order reduction of the
+                             rows gives the batch statistics BatchNorm2d needs right behind the conv, bit-wise reproducibly
+                             (gc_batchnorm_act_fwd_rows; BasicGANs/models.py:35-37,77-79, Pix2Pix/models.py:83-86,123-127).
+                             Unlike ch_sum / ch_sumsq nothing is zeroed by the caller and no float atomics are used. */
+  int32_t stat_rows_capacity;
+  int32_t* stat_rows_written; /* host int, required with stat_rows: the number of rows written; 0 when the kernel chosen for
+                             this problem does not produce them (the caller then computes the statistics from the output) */
 } gc_epilogue;
 
 int gc_version(void);
@@ -195,6 +204,12 @@ int gc_batchnorm_act_fwd(const void* x, void* y, void* y_bf16, const float* gamm
                          float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
                          void* workspace, size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, float eps, float momentum,
                          int32_t act, float slope, int32_t training, void* stream);
+/* gc_batchnorm_act_fwd in training mode with the batch statistics taken from `n_rows` rows of (sum, sum of squares) per
+ * channel that the convolution in front wrote (gc_epilogue.stat_rows) instead of from a sweep over x: two launches. */
+int gc_batchnorm_act_fwd_rows(const void* x, void* y, void* y_bf16, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                              const float* stat_rows, int32_t n_rows, void* workspace, size_t workspace_bytes, int64_t P, int32_t C,
+                              int32_t dtype, float eps, float momentum, int32_t act, float slope, void* stream);
 int gc_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
                          const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
                          size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);
