@@ -573,6 +573,12 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
     x = _nhwc(x)
     want = _out_dtype(x, out_dtype)
+    # A small output with an activation (a critic's score layer with its sigmoid: one pixel tile, 128 reduction steps): the
+    # kernel computes the plain fp32 result, so that its reduction can be split over workgroups, and the activation is
+    # applied to the few KB afterwards.
+    act_after = act if (act != 0 and N * Cout * Ho * Wo <= _SPLIT_MAX_OUT) else 0
+    if act_after:
+        act = 0
     narrow = _small_output_in_f32(N * Cout * Ho * Wo, want, act)
     y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32 if narrow else want, device=x.device, memory_format=torch.channels_last)
     if _dma_ok(x, Cin, Cout, precision):
@@ -580,11 +586,14 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(y))
     wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey, alpha)
     ep, keep = _epilogue(bias, act, slope, y if (act != 0 and y.dtype == torch.float32) else None)
-    ep, rows = (ep, None) if narrow else _rows_for(ep, y, Cout)
+    ep, rows = (ep, None) if (narrow or act_after) else _rows_for(ep, y, Cout)
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_fprop")
     _remember_rows(y, rows)
+    if act_after:
+        y = (torch.relu_(y) if act_after == _lib.GC_ACT_RELU else torch.nn.functional.leaky_relu_(y, slope) if act_after == _lib.GC_ACT_LRELU
+             else torch.tanh_(y) if act_after == _lib.GC_ACT_TANH else torch.sigmoid_(y))
     return y.to(want) if narrow else y
 
 
