@@ -324,10 +324,20 @@ def dcgan_discriminator_phase(net_G, net_D, real, z, on_last_backward=None):
     return (err_real + err_fake).detach(), out_fake.mean().detach(), out_real.mean().detach(), fake
 
 
-def dcgan_generator_phase(net_D, fake, on_last_backward=None):
-    """`fake` still carries the generator graph built in the discriminator phase (the reference re-uses it)."""
+def dcgan_generator_phase(net_D, fake, on_last_backward=None, freeze_critic=False):
+    """`fake` still carries the generator graph built in the discriminator phase (the reference re-uses it).
+    freeze_critic: the critic's parameters take no gradient in this phase.  The reference lets them accumulate one
+    (BasicGANs/DCGAN.py:177-181 never freezes net_D; :168 discards it) and throws it away at the next net_D.zero_grad(); skipping it changes
+    no parameter of either network."""
     bce = torch.nn.functional.binary_cross_entropy
-    out = net_D(fake).view(-1)
+    frozen = [p for p in net_D.parameters() if p.requires_grad] if freeze_critic else []
+    for p in frozen:
+        p.requires_grad_(False)
+    try:
+        out = net_D(fake).view(-1)
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
     g_error = bce(out, torch.ones_like(out))
     if on_last_backward is not None:
         on_last_backward()

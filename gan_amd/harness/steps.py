@@ -30,11 +30,11 @@ def dcgan(device, batch=128):
     z = torch.randn(batch, 100, 1, 1, device=device)
 
     def step():
-        oD.zero_grad(set_to_none=False)
+        oD.zero_grad(set_to_none=True)       # (the first backward pass of a phase then writes its gradients instead of adding)
         *_, fake = basic_gans.dcgan_discriminator_phase(G, D, real, z)
         oD.step()
-        oG.zero_grad(set_to_none=False)
-        basic_gans.dcgan_generator_phase(D, fake)
+        oG.zero_grad(set_to_none=True)
+        basic_gans.dcgan_generator_phase(D, fake)      # (freeze_critic=True would skip the critic gradients this phase throws away: 1.84 instead of 2.01 ms; kept as the reference computes them)
         oG.step()
         ops.clear_cast_cache()
 
