@@ -37,7 +37,8 @@ class ConvDesc(ctypes.Structure):
 class Epilogue(ctypes.Structure):
     _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("bias", ctypes.c_void_p), ("ch_sum", ctypes.c_void_p),
                 ("ch_sumsq", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("grad_mask", ctypes.c_void_p),
-                ("stat_rows", ctypes.c_void_p), ("stat_rows_capacity", ctypes.c_int32), ("stat_rows_written", ctypes.POINTER(ctypes.c_int32))]
+                ("stat_rows", ctypes.c_void_p), ("stat_rows_capacity", ctypes.c_int32), ("stat_rows_written", ctypes.POINTER(ctypes.c_int32)),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
 _lib = None

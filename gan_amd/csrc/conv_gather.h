@@ -28,6 +28,8 @@ struct GatherParams {
   float* stat_rows;    // null, or [stat_cap][OC][2] row partials (sum, sum of squares); stat_written: host int, rows written
   int32_t stat_cap;
   int32_t* stat_written;
+  void* split_ws;      // null, or scratch memory the kernels may use to split long reductions of small outputs over workgroups
+  size_t split_ws_bytes;
   uint16_t* out_bf16;  // null, or a bf16 copy of the fp32 output (same indexing)
   const void* mask;    // null, or a tensor indexed like `out` (same element type): out *= mask > 0 ? 1 : slope
   int32_t N, IH, IW, IC, ICp, OH, OW, OC, T;

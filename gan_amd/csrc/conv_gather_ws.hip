@@ -64,6 +64,12 @@ struct WsParams {
   int32_t act;
   float slope, mask_slope;
   int32_t n_tiles, n_oc_tiles, n_classes, cls_interleave;
+  // split reduction (SPLIT variants): a tile's steps are dealt to `ksplit` workgroups, each writing its accumulators to
+  // `part` in fragment order; a second launch of the same kernel (`nsum` = the number of splits, ksplit = 1) adds them
+  // in a fixed order and runs the ordinary epilogue
+  int32_t ksplit, steps_per_split, nsum;
+  float* part;
+  uint32_t ks_mul, ks_shift;        // division by ksplit
   uint32_t oct_mul, oct_shift;      // division by n_oc_tiles
   uint32_t ncls_mul, ncls_shift;    // division by n_classes
   WsClass cls[kMaxClasses];
@@ -91,15 +97,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 struct TileId {
-  int cls, m0, oc0;
+  int cls, m0, oc0, tile, split;
 };
 
+template <bool SPLIT>
 __device__ __forceinline__ bool tile_of(const WsParams& p, int k, TileId& id) {
   const int G = (int)gridDim.x;
   const int base = k * G;
-  const int nr = min(G, p.n_tiles - base);            // tiles of this round
+  const int units = SPLIT ? p.n_tiles * p.ksplit : p.n_tiles;
+  const int nr = min(G, units - base);            // tiles (or tile parts) of this round
   if ((int)blockIdx.x >= nr) return false;
-  const uint32_t lid = (uint32_t)base + xcd_remap(blockIdx.x, (uint32_t)nr);
+  uint32_t lid = (uint32_t)base + xcd_remap(blockIdx.x, (uint32_t)nr);
+  id.split = 0;
+  if (SPLIT) {                 // the parts of one tile are neighbours: they read the same pixels and weights
+    const uint32_t q = wdiv(lid, p.ks_mul, p.ks_shift);
+    id.split = (int)(lid - q * (uint32_t)p.ksplit);
+    lid = q;
+  }
+  id.tile = (int)lid;
   const uint32_t pix_tile = wdiv(lid, p.oct_mul, p.oct_shift);
   id.oc0 = (int)(lid - pix_tile * (uint32_t)p.n_oc_tiles);
   if (p.cls_interleave) {       // equal-sized classes in (tile, class) order: the classes of one image region are neighbours
@@ -116,9 +131,20 @@ __device__ __forceinline__ bool tile_of(const WsParams& p, int k, TileId& id) {
   return true;
 }
 
+// first step and number of steps of a tile (or of one part of it)
+template <bool SPLIT>
+__device__ __forceinline__ int steps_of(const WsParams& p, uint32_t ph_pw_taps, int split, int& s0) {
+  const int total = (int)((ph_pw_taps >> 24) - ((ph_pw_taps >> 16) & 0xff)) * p.csteps;
+  s0 = 0;
+  if (!SPLIT) return total;
+  if (p.nsum > 0) return 0;             // the adding launch has no steps
+  s0 = split * p.steps_per_split;
+  return min(p.steps_per_split, total - s0);
+}
+
 // MASK: the epilogue scales the stored value by the derivative selected by p.mask (a variant of its own: the extra loads
 // cost the 128-channel tile the register budget of its second workgroup per CU)
-template <typename TOut, int TO, int STAGES, bool MASK = false>
+template <typename TOut, int TO, int STAGES, bool MASK = false, bool SPLIT = false>
 __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsParams p) {
   constexpr int WO = TO >= 128 ? 2 : 1, WP = kNW / WO;
   constexpr int FO = TO / WO / 16, FP = kTP / WP / 16;
@@ -143,6 +169,7 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
 
   if (loader) {
     // ================================================================ loader waves
+    if (SPLIT && p.nsum > 0) return;      // the adding launch loads nothing (and has no barriers: its tiles have no steps)
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.in)) - p.a_bias, 0, p.in_bytes + p.a_bias, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wp), 0, p.w_bytes, 0x00020000);
@@ -151,7 +178,7 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
     // ---- issue cursor: (tile k_i, tap, channel step) of the next step to load, with the tile's per-lane rows
     uint32_t a_off[AJ], w_voff[WJ];
     int a_ih[AJ], a_iw[AJ], a_chunk[AJ];
-    int k_i = 0, tap_i = 0, tap_end_i = 0, cs_i = 0;
+    int k_i = 0, tap_i = 0, cs_i = 0, left_i = 0;
     int s_dh = 0, s_dw = 0;
     uint32_t s_aoff = 0, s_woff = 0;
     bool have = false;
@@ -164,13 +191,15 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
     };
     auto setup_tile = [&](int k) {
       TileId id;
-      have = tile_of(p, k, id);
+      have = tile_of<SPLIT>(p, k, id);
       if (!have) return;
       const WsClass c = p.cls[id.cls];
       const int OHc = (int)(c.oh_ow & 0xffff), OWc = (int)(c.oh_ow >> 16);
-      tap_i = (int)((c.ph_pw_taps >> 16) & 0xff);
-      tap_end_i = (int)(c.ph_pw_taps >> 24);
-      cs_i = 0;
+      int s0;
+      left_i = steps_of<SPLIT>(p, c.ph_pw_taps, id.split, s0);
+      const int t0 = SPLIT ? s0 / p.csteps : 0;
+      tap_i = (int)((c.ph_pw_taps >> 16) & 0xff) + t0;
+      cs_i = SPLIT ? s0 - t0 * p.csteps : 0;
 #pragma unroll
       for (int j = 0; j < AJ; j++) {
         const int row = (wave * AJ + j) * 8 + sub_row;
@@ -195,10 +224,11 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
     int st_i = 0, issued = 0;
     auto advance = [&]() {
       issued++;
-      if (++cs_i == p.csteps) {
+      if (--left_i == 0) {
+        setup_tile(++k_i);
+      } else if (++cs_i == p.csteps) {
         cs_i = 0;
-        if (++tap_i < tap_end_i) load_tap(tap_i);
-        else setup_tile(++k_i);
+        load_tap(++tap_i);
       }
     };
     setup_tile(0);
@@ -232,9 +262,9 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
       const bool dg = p.diag_buf != nullptr;
       for (int k = 0;; k++) {
         TileId id;
-        if (!tile_of(p, k, id)) break;
-        const uint32_t taps = p.cls[id.cls].ph_pw_taps;
-        const int nsteps = (int)((taps >> 24) - ((taps >> 16) & 0xff)) * p.csteps;
+        if (!tile_of<SPLIT>(p, k, id)) break;
+        int s0;
+        const int nsteps = steps_of<SPLIT>(p, p.cls[id.cls].ph_pw_taps, id.split, s0);
         for (int it = 0; it < nsteps; it++, done++) {
           const int younger = issued - done - 1;      // steps issued behind step `done`: they may stay in flight
           const unsigned long long q0 = dg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -269,9 +299,10 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
 
   for (int k = 0;; k++) {
     TileId id;
-    if (!tile_of(p, k, id)) break;
+    if (!tile_of<SPLIT>(p, k, id)) break;
     const WsClass c = p.cls[id.cls];
-    const int nsteps = (int)((c.ph_pw_taps >> 24) - ((c.ph_pw_taps >> 16) & 0xff)) * p.csteps;
+    int s0_unused;
+    const int nsteps = steps_of<SPLIT>(p, c.ph_pw_taps, id.split, s0_unused);
 
     f32x4 acc[FO][FP];
 #pragma unroll
@@ -322,6 +353,26 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
       }
       st_c = next_stage(st_c);
       __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (SPLIT) {
+      // fragment-order table: [tile][part][fragment][consumer thread] x 4 floats, i.e. 1 KB per store instruction
+      constexpr int NF = FO * FP;
+      if (p.nsum == 0) {          // a part of the reduction: the accumulators as they are, no epilogue
+        float* dst = p.part + (((size_t)id.tile * p.ksplit + id.split) * NF * (kNW * 64) + (size_t)t) * 4;
+#pragma unroll
+        for (int i = 0; i < FO; i++)
+#pragma unroll
+          for (int j = 0; j < FP; j++) *reinterpret_cast<f32x4*>(dst + (size_t)(i * FP + j) * (kNW * 64) * 4) = acc[i][j];
+        continue;
+      }
+      for (int sp = 0; sp < p.nsum; sp++) {       // the adding launch: the parts in their order, then the ordinary epilogue
+        const float* src = p.part + (((size_t)id.tile * p.nsum + sp) * NF * (kNW * 64) + (size_t)t) * 4;
+#pragma unroll
+        for (int i = 0; i < FO; i++)
+#pragma unroll
+          for (int j = 0; j < FP; j++) acc[i][j] += *reinterpret_cast<const f32x4*>(src + (size_t)(i * FP + j) * (kNW * 64) * 4);
+      }
     }
 
     // ---- epilogue of this tile
@@ -436,10 +487,10 @@ void ws_div(uint32_t d, uint32_t* mul, uint32_t* shift) {
   *shift = f.shift;
 }
 
-template <typename TOut, int TO, int STAGES, bool MASK = false>
+template <typename TOut, int TO, int STAGES, bool MASK = false, bool SPLIT = false>
 int launch_one(const WsParams& p, int grid, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * (TO + kTP) * 128 + kMaxTaps * 4;
-  auto kern = conv_gather_ws_kernel<TOut, TO, STAGES, MASK>;
+  auto kern = conv_gather_ws_kernel<TOut, TO, STAGES, MASK, SPLIT>;
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [&]() {
@@ -448,8 +499,8 @@ int launch_one(const WsParams& p, int grid, double flops, hipStream_t stream) {
   });
   if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
   char name[96];
-  snprintf(name, sizeof(name), "gc::conv_gather_ws_kernel<%s, %d, %d, %s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, STAGES,
-           MASK ? "true" : "false");
+  snprintf(name, sizeof(name), "gc::conv_gather_ws_kernel<%s, %d, %d, %s>%s", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, STAGES,
+           MASK ? "true" : "false", !SPLIT ? "" : (p.nsum > 0 ? " (adding the parts)" : " (split reduction)"));
   static const bool stamps = getenv("GC_DIAG_STAMPS") != nullptr;
   if (stamps) {   // diagnostic: synchronous launches with cycle stamps per workgroup, summary on stderr
     static unsigned long long* dbuf = nullptr;
@@ -535,6 +586,48 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
   const int slots = force_slots ? force_slots : 256 * per_cu;
   const int rounds = (p.n_tiles + slots - 1) / slots;
   const int grid = (p.n_tiles + rounds - 1) / rounds;
+  // Few tiles with long reductions (512-channel layers on 8 x 8 images and smaller: a handful of workgroups walking 128
+  // steps each on a 256-CU chip): deal each tile's steps to several workgroups when the caller offered scratch memory.
+  if (p.mask == nullptr && g.split_ws != nullptr && !force_stages && p.n_tiles < 128) {
+    int total = -1;
+    bool same = true;
+    for (int c = 0; c < g.tt.n_classes; c++) {
+      const int st = (g.tt.cls_tap_start[c + 1] - g.tt.cls_tap_start[c]) * p.csteps;
+      if (total >= 0 && st != total) same = false;
+      total = st;
+    }
+    long want = (512 + p.n_tiles - 1) / p.n_tiles;
+    if (want > total / 8) want = total / 8;                // at least 8 steps per part
+    if (want > 32) want = 32;
+    const size_t unit_bytes = (size_t)l.to * kTP * sizeof(float);
+    const long fit = (long)(g.split_ws_bytes / (unit_bytes * (size_t)p.n_tiles));
+    if (want > fit) want = fit;
+    if (same && want > 1 && (reinterpret_cast<uintptr_t>(g.split_ws) & 15u) == 0) {
+      WsParams q = p;
+      q.steps_per_split = (total + (int)want - 1) / (int)want;
+      q.ksplit = (total + q.steps_per_split - 1) / q.steps_per_split;
+      q.nsum = 0;
+      q.part = reinterpret_cast<float*>(g.split_ws);
+      ws_div((uint32_t)q.ksplit, &q.ks_mul, &q.ks_shift);
+      q.stat_rows = nullptr;                               // (statistics belong to the launch that stores the output)
+      const int units = q.n_tiles * q.ksplit;
+      const int r1 = (units + slots - 1) / slots, grid1 = (units + r1 - 1) / r1;
+      WsParams a = p;
+      a.ksplit = 1; a.nsum = q.ksplit; a.part = q.part; a.steps_per_split = 0;
+      ws_div(1u, &a.ks_mul, &a.ks_shift);
+      int rc;
+#define WS_SPLIT(TO_, ST_)                                                                                                        \
+      if (l.to == TO_) {                                                                                                            \
+        rc = out_f32 ? launch_one<float, TO_, ST_, false, true>(q, grid1, l.flops, stream)                                          \
+                     : launch_one<uint16_t, TO_, ST_, false, true>(q, grid1, l.flops, stream);                                      \
+        if (rc != GC_OK) return rc;                                                                                                 \
+        return out_f32 ? launch_one<float, TO_, ST_, false, true>(a, grid, 0.0, stream)                                             \
+                       : launch_one<uint16_t, TO_, ST_, false, true>(a, grid, 0.0, stream);                                         \
+      }
+      WS_SPLIT(64, 3) WS_SPLIT(128, 2)
+#undef WS_SPLIT
+    }
+  }
   if (p.mask != nullptr) {       // masked variants exist for the default ring depths only
     if (l.to == 64) return out_f32 ? launch_one<float, 64, 3, true>(p, grid, l.flops, stream) : launch_one<uint16_t, 64, 3, true>(p, grid, l.flops, stream);
     return out_f32 ? launch_one<float, 128, 2, true>(p, grid, l.flops, stream) : launch_one<uint16_t, 128, 2, true>(p, grid, l.flops, stream);

@@ -352,6 +352,20 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
   const int64_t limit = (1ll << 31) - (1 << 20);
   const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 256 || l.to == 128 || l.to == 64) &&
                    p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
+  if (!dma && p.ksplit > 1 && p.split_ws != nullptr && l.in_bf16 && l.mode == kVecLoads && (l.to == 128 || l.to == 64) &&
+      p.in_bytes + p.a_bias < limit && p.w_bytes < limit &&
+      p.split_ws_bytes >= (size_t)p.n_pix_tiles * p.n_oc_tiles * l.to * 128 * sizeof(float) * 8) {
+    // a small output planned as a split reduction with atomic adds: with scratch memory on offer the wave-specialised
+    // kernel splits it instead (partial tiles added in a fixed order: faster, and reproducible)
+    GatherParams q = p;
+    q.ksplit = 1;
+    if (plan_ws(q, l)) {
+      p.ksplit = 1;
+      const int rc = launch_ws(p, l, out_dt == GC_F32, stream);
+      p.mask = nullptr;
+      return rc;
+    }
+  }
   if (dma && patch_kernel_allowed() && plan_patch(p, l)) return launch_patch(p, l, out_dt == GC_F32, stream);
   if (dma && plan_ws(p, l)) {
     const int rc = launch_ws(p, l, out_dt == GC_F32, stream);    // applies grad_mask in its epilogue
@@ -381,11 +395,12 @@ int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 
 static void fill_epilogue(GatherParams& p, const gc_epilogue* ep) {
   p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.out_bf16 = nullptr; p.mask = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
-  p.stat_rows = nullptr; p.stat_cap = 0; p.stat_written = nullptr;
+  p.stat_rows = nullptr; p.stat_cap = 0; p.stat_written = nullptr; p.split_ws = nullptr; p.split_ws_bytes = 0;
   if (ep != nullptr) {
     p.bias = ep->bias; p.ch_sum = ep->ch_sum; p.ch_sumsq = ep->ch_sumsq; p.act = ep->act; p.slope = ep->slope;
     p.out_bf16 = (uint16_t*)ep->out_bf16; p.mask = ep->grad_mask;
     if (p.mask != nullptr) { p.mask_slope = ep->slope; p.slope = 0.f; }
+    p.split_ws = ep->workspace; p.split_ws_bytes = ep->workspace != nullptr ? ep->workspace_bytes : 0;
     if (ep->stat_rows != nullptr) {
       p.stat_rows = ep->stat_rows; p.stat_cap = ep->stat_rows_capacity; p.stat_written = ep->stat_rows_written;
       *p.stat_written = 0;

@@ -396,6 +396,19 @@ def _rows_for(ep, out, C):
     return ep, (rows, written)
 
 
+def _offer_scratch(ep, out, reduction):
+    """Scratch memory for a split reduction (gc_epilogue.workspace) when the output is small and the reduction long;
+    returns (descriptor, tensor to keep alive)."""
+    n = out.numel()
+    if n == 0 or n > (1 << 20) or reduction < 2048:
+        return ep, None
+    if ep is None:
+        ep = Epilogue()
+    ws = torch.empty(min(n * 4 * 32, 32 << 20), dtype=torch.uint8, device=out.device)
+    ep.workspace, ep.workspace_bytes = ws.data_ptr(), ws.numel()
+    return ep, ws
+
+
 def _remember_rows(out, got):
     if got is not None and got[1].value > 0:
         with _lock:
@@ -587,6 +600,7 @@ def conv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, paddin
     wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey, alpha)
     ep, keep = _epilogue(bias, act, slope, y if (act != 0 and y.dtype == torch.float32) else None)
     ep, rows = (ep, None) if (narrow or act_after) else _rows_for(ep, y, Cout)
+    ep, scratch = _offer_scratch(ep, y, Cin * kh * kw)
     _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_fprop")
@@ -634,6 +648,7 @@ def _dgrad_launch(gy, w, bias, H, W, stride, padding, precision, wkey, act, slop
     else:
         ep, keep = _epilogue(bias, act, slope, gx if (act != 0 and gx.dtype == torch.float32) else None)
     ep, rows = (ep, None) if narrow else _rows_for(ep, gx, Cin)
+    ep, scratch = _offer_scratch(ep, gx, Cout * kh * kw // max(stride * stride, 1))
     _lib.check(_lib.lib().gc_conv2d_dgrad(ctypes.byref(d), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
                                           ctypes.c_void_p(gx.data_ptr()), ctypes.byref(ep) if ep is not None else None, _stream()),
                "gc_conv2d_dgrad")

@@ -102,6 +102,11 @@ typedef struct gc_epilogue {
   int32_t stat_rows_capacity;
   int32_t* stat_rows_written; /* host int, required with stat_rows: the number of rows written; 0 when the kernel chosen for
                              this problem does not produce them (the caller then computes the statistics from the output) */
+  void* workspace;        /* NULL, or scratch memory (16-byte aligned) the call MAY use: a problem with few output tiles and a
+                             long reduction (512-channel layers on 8 x 8 images and smaller, Pix2Pix/models.py:100-118) is then
+                             split over more workgroups, whose fp32 partial tiles meet here and are added in a fixed order by a
+                             second launch (bit-wise reproducible).  4 * 32 bytes per output element is always enough. */
+  size_t workspace_bytes;
 } gc_epilogue;
 
 int gc_version(void);

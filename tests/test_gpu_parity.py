@@ -1553,3 +1553,37 @@ def test_one_module_at_two_input_sizes_keeps_one_image_per_layout(gan):
             assert rel(yg, yr) < TOL_X3 and rel(gx, rx) < TOL_X3 and rel(gw, rw) < TOL_X3, size
     finally:
         gan.set_precision("bf16")
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, H, Cout, k, stride, pad, transposed
+    (8, 512, 16, 512, 4, 2, 1, False),       # Pix2Pix/models.py:100-104: 512 -> 512 at 16 x 16 -> 8 x 8: 32 tiles of 128 steps
+    (8, 512, 8, 1024, 4, 2, 1, False),       # the input gradient of a decoder block, 128 output pixels
+    (8, 1024, 4, 512, 4, 2, 1, True),        # decoder block 1024 -> 512 at 4 x 4 -> 8 x 8
+    (8, 256, 16, 256, 3, 1, 1, False),
+])
+def test_split_reduction_of_small_outputs_is_exact_on_small_integers(gan, case):
+    """Few output tiles with a long reduction: the wave-specialised kernel deals each tile's steps to several workgroups
+    (scratch offered through gc_epilogue.workspace) and a second launch adds the parts.  On small integers every partial
+    sum is exact, so the result must equal torch's CPU convolution bit for bit -- and the split launches must have run."""
+    N, Cin, H, Cout, k, stride, pad, transposed = case
+    g = torch.Generator().manual_seed(17)
+    x = torch.randint(-2, 3, (N, Cin, H, H), generator=g).float()
+    wshape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    w = torch.randint(-1, 2, wshape, generator=g).float()
+    b = torch.randint(-3, 4, (Cout,), generator=g).float()
+    if transposed:
+        want = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride, pad)
+    else:
+        want = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride, pad)
+    xb = x.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    fn = gan.functional.conv_transpose2d if transposed else gan.functional.conv2d
+    gan._lib.profile_enable(True)
+    y = fn(xb, w.cuda(), b.cuda(), stride, pad, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    names = set(gan._lib.profile_collect())
+    gan._lib.profile_enable(False)
+    assert any("(split reduction)" in n for n in names) and any("(adding the parts)" in n for n in names), sorted(names)
+    assert torch.equal(y.double().cpu(), want)
+    y2 = fn(xb, w.cuda(), b.cuda(), stride, pad, out_dtype=torch.float32)
+    assert torch.equal(y, y2)
