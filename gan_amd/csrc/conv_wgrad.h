@@ -16,6 +16,7 @@ struct WgradParams {
   int32_t k_per_split;   // multiple of the reduction step
   int32_t n_co_tiles, n_ci_tiles, splits;
   int32_t y_elem;        // register-staged kernel, vector instantiation: the gy side still needs element loads (odd Cout)
+  int32_t image;         // 1: geometry of the image-layer kernel (conv_wgrad_image.hip); splits start on its 128-pixel rectangles
   int32_t thin;          // 1: Cin <= 32; the tile's columns run over (tap, channel) jointly, channel padded to ICp
   int32_t ICp, icp_log2, ncols;   // thin mode: padded channels per tap, its log2, T * ICp
   int32_t n_tap_groups, tpt, cw_log2;   // LDS-DMA kernel: a 128-column tile holds tpt taps of (1 << cw_log2) channels
@@ -74,6 +75,9 @@ struct WgradReduceParams {
 void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma);
 int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
 int launch_wgrad_dma(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
+bool wgrad_image_geometry(const WgradParams& p);
+bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l);
+int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream);
 int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream);
 

@@ -363,6 +363,7 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(const T* gy, float* gb
 void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
   l.to = p.Cout <= 64 ? 64 : 128;
   p.thin = p.Cin <= 32;
+  p.image = 0;
   p.n_tap_groups = p.kh * p.kw; p.tpt = 1; p.cw_log2 = 7;
   l.dma = allow_dma && l.bf16 && !l.x3 && !p.thin && p.Cin % 8 == 0 && p.Cout % 8 == 0 && p.x_cstride % 8 == 0 &&
           p.x_coff % 8 == 0 && p.y_cstride % 8 == 0 && p.y_coff % 8 == 0;
@@ -382,6 +383,7 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
     static const int force256 = getenv("GC_WGRAD_TO256") ? atoi(getenv("GC_WGRAD_TO256")) : 0;
     if (p.Cout % 256 == 0 && (force256 || p.K >= 65536 || (long)(p.Cout / 256) * p.n_ci_tiles * p.n_tap_groups >= 256)) l.to = 256;
   } else if (p.thin) {
+    p.image = wgrad_image_geometry(p) ? 1 : 0;
     p.ICp = 4;
     while (p.ICp < p.Cin) p.ICp *= 2;
     for (p.icp_log2 = 0; (1 << p.icp_log2) < p.ICp; p.icp_log2++) {}
@@ -404,7 +406,8 @@ void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma) {
   static const int max_want = getenv("GC_WGRAD_MAX_SPLITS") ? atoi(getenv("GC_WGRAD_MAX_SPLITS")) : 512;
   if (want > max_want) want = max_want;
   long kps = (p.K + want - 1) / want;
-  kps = (kps + kWBK - 1) / kWBK * kWBK;
+  const int step = p.image ? 128 : kWBK;
+  kps = (kps + step - 1) / step * step;
   p.k_per_split = (int)kps;
   p.splits = (int)((p.K + kps - 1) / kps);
 }
@@ -436,6 +439,7 @@ static int launch_tile(const WgradParams& p, const WgradLaunch& l, hipStream_t s
 
 int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
   if (p.K <= 0 || p.Cout <= 0 || p.Cin <= 0) return GC_OK;
+  if (wgrad_image_applies(p, l)) return launch_wgrad_image(p, l, s);
   if (l.bf16) return l.aligned ? launch_tile<uint16_t, false, true>(p, l, s) : launch_tile<uint16_t, false, false>(p, l, s);
   if (l.x3) return l.aligned ? launch_tile<float, true, true>(p, l, s) : launch_tile<float, true, false>(p, l, s);
   return l.aligned ? launch_tile<float, false, true>(p, l, s) : launch_tile<float, false, false>(p, l, s);

@@ -1,0 +1,187 @@
+// Weight gradient of the critics' first layer: Conv2d(<= 4 channels -> up to 64, kernel 4, stride 2, padding 1) on
+// 64-pixel-wide images (reference BasicGANs/models.py:52-56,77), bf16 operands.  3 MFLOP per sample against 270 KB of
+// gy and image: memory-bound, so gy and the image are each read once and the per-pixel instruction count is kept low
+// (the general thin-input kernel gathers every (tap, channel) element of its x tile with a 2-byte load of its own).
+//
+// A workgroup walks the rectangles (4 output rows x 32 = one 128-pixel run of the reduction index) of its split.  Per
+// rectangle it stages, as the forward kernel of this layer does, the 10 x 66 input patch as channel-padded bf16 -- the 4
+// taps x 4 channels of one filter row are then 32 contiguous bytes per output pixel, so the x operand of an MFMA whose
+// reduction runs over 32 pixels is two transposing LDS reads straight from the patch, no im2col tile -- and the 128 x 64
+// gy tile (16-byte loads, rows swizzled in 32-byte segments for the transposing reads).  Wave w owns output row w of the
+// rectangle: 16 MFMAs (4 blocks of 16 output channels x 4 filter rows) per rectangle into 64 accumulator registers that
+// live across the whole split.  Loads of rectangle i + 1 are in flight while rectangle i is multiplied (two LDS
+// buffers).  At the end the four waves' tiles are added through LDS and leave as one partial tile in the layout of the
+// thin-input kernel ([split][Cout][tap][4 channels]); the common split reduction follows.
+#include "conv_wgrad.h"
+
+namespace gc {
+namespace {
+
+constexpr int kTH = 4, kTW = 32, kUnit = kTH * kTW;      // output rectangle = 128 consecutive values of the reduction index
+constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
+constexpr int kPatchBytes = kPH * kPW * 8, kGyBytes = kUnit * 128;
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int gy_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+__device__ __forceinline__ bf16x8 read_tr(const char* a0, int second_offset) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + second_offset));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (kPatchBytes + kGyBytes)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int split = blockIdx.x;
+  const WgradRange rg = wgrad_range(p, split);
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(rg.x);
+  const uint16_t* gy = reinterpret_cast<const uint16_t*>(rg.gy);
+  const int u0 = rg.kb0 / kUnit, u1 = rg.kend > rg.kb0 ? (rg.kend + kUnit - 1) / kUnit : u0;
+  const int units_per_sample = p.Ho / kTH;
+  const int ychunks = p.Cout / 8;                    // 16-byte chunks of a gy pixel
+
+  // ---- what this thread loads per rectangle: 4 chunks of gy, up to 3 patch pixels
+  u32x4 yreg[4];
+  u32x2 xreg[3];
+  int ppr[3], ppc[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int e = t + i * kThreads;
+    ppr[i] = e / kPW;
+    ppc[i] = e - ppr[i] * kPW;
+  }
+  auto load_unit = [&](int u) {
+    const int n = u / units_per_sample, th = u - n * units_per_sample;
+    const size_t k0 = (size_t)u * kUnit;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int idx = t + i * kThreads, row = idx >> 3, ch = idx & 7;
+      yreg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (ch < ychunks) yreg[i] = *reinterpret_cast<const u32x4*>(gy + (k0 + row) * p.y_cstride + p.y_coff + ch * 8);
+    }
+    const uint16_t* img = x + (size_t)n * p.H * p.W * p.Cin;
+    const int ih0 = 2 * kTH * th - 1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int ih = ih0 + ppr[i], iw = ppc[i] - 1;
+      uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+        const uint16_t* src = img + (uint32_t)((ih * p.W + iw) * p.Cin);
+        c0 = src[0];
+        if (p.Cin > 1) c1 = src[1];
+        if (p.Cin > 2) c2 = src[2];
+        if (p.Cin > 3) c3 = src[3];
+      }
+      xreg[i] = u32x2{c0 | (c1 << 16), c2 | (c3 << 16)};
+    }
+  };
+  auto store_unit = [&](int buf) {
+    char* pb = smem + buf * (kPatchBytes + kGyBytes);
+    char* yb = pb + kPatchBytes;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int idx = t + i * kThreads, row = idx >> 3, ch = idx & 7;
+      *reinterpret_cast<u32x4*>(yb + row * 128 + (((ch >> 1) ^ gy_swz(row)) << 5) + (ch & 1) * 16) = yreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (t + i * kThreads < kPH * kPW) *reinterpret_cast<u32x2*>(pb + (t + i * kThreads) * 8) = xreg[i];
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[i][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposing read: lane (g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3) addresses row 8g + q (and + 4), columns
+  // 4pp .. 4pp + 3 of a 16-column block and receives, for column lane & 15, the rows 8g .. 8g + 7
+  const int k0 = 8 * (lane >> 4) + ((lane >> 2) & 3), pp8 = (lane & 3) * 8;
+  const int co_blocks = p.Cout / 16;
+
+  if (u0 < u1) {
+    load_unit(u0);
+    store_unit(0);
+  }
+  __syncthreads();
+  for (int u = u0; u < u1; u++) {
+    const int buf = (u - u0) & 1;
+    const bool more = u + 1 < u1;
+    if (more) load_unit(u + 1);
+    const char* pb = smem + buf * (kPatchBytes + kGyBytes);
+    const char* yb = pb + kPatchBytes;
+    bf16x8 a[4], b[4];
+    const int yrow = wave * kTW + k0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < co_blocks) a[i] = read_tr(yb + yrow * 128 + ((i ^ gy_swz(k0)) << 5) + pp8, 4 * 128);
+#pragma unroll
+    for (int r = 0; r < 4; r++) b[r] = read_tr(pb + ((2 * wave + r) * kPW + 2 * k0) * 8 + pp8, 4 * 16);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < co_blocks)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[i][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[r], acc[i][r], 0, 0, 0);
+    if (more) store_unit(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- the four waves' tiles -> one: waves 2, 3 hand theirs to waves 0, 1, then wave 1 to wave 0
+  float* red = reinterpret_cast<float*>(smem);          // two slots of 16 fragments x 64 lanes x 4 floats (16 KB each)
+  auto slot_io = [&](int slot, bool write) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        f32x4* q = reinterpret_cast<f32x4*>(red + ((size_t)slot * 16 + i * 4 + r) * 256 + lane * 4);
+        if (write) *q = acc[i][r];
+        else acc[i][r] += *q;
+      }
+  };
+  if (wave >= 2) slot_io(wave - 2, true);
+  __syncthreads();
+  if (wave < 2) slot_io(wave, false);
+  __syncthreads();
+  if (wave == 1) slot_io(0, true);
+  __syncthreads();
+  if (wave != 0) return;
+  slot_io(0, false);
+  float* part = p.part + (size_t)split * p.Cout * 64;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int co = i * 16 + (lane >> 4) * 4 + e;
+        if (co < p.Cout) part[(size_t)co * 64 + r * 16 + (lane & 15)] = acc[i][r][e];
+      }
+}
+
+}  // namespace
+
+// bf16 operands, dense image of at most 4 channels, 4 x 4 / stride 2 / padding 1, 32 output columns, output rows in
+// fours, 16 / 32 / 48 / 64 output channels with 16-byte aligned gy pixels; splits that start on a rectangle.
+bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l) {
+  if (!p.image || !l.bf16 || l.x3 || !l.aligned) return false;
+  return p.k_per_split % kUnit == 0 && p.y_cstride % 8 == 0 && p.y_coff % 8 == 0;
+}
+
+bool wgrad_image_geometry(const WgradParams& p) {
+  return p.thin && p.Cin <= 4 && p.kh == 4 && p.kw == 4 && p.sh == 2 && p.sw == 2 && p.ph == 1 && p.pw == 1 && p.Wo == kTW &&
+         p.Ho % kTH == 0 && p.H == 2 * p.Ho && p.W == 2 * p.Wo && p.Cout % 16 == 0 && p.Cout <= 64 && p.x_cstride == p.Cin &&
+         p.x_coff == 0 && (long)p.H * p.W * p.Cin < (1l << 31);
+}
+
+int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t stream) {
+  if (p.K <= 0 || p.splits <= 0) return GC_OK;
+  ProfScope ps("gc::conv_wgrad_image_kernel", l.flops, stream);
+  hipLaunchKernelGGL(conv_wgrad_image_kernel, dim3((unsigned)p.splits), dim3(kThreads), 0, stream, p);
+  return check_hip(hipGetLastError(), "conv_wgrad_image launch");
+}
+
+}  // namespace gc

@@ -1587,3 +1587,30 @@ def test_split_reduction_of_small_outputs_is_exact_on_small_integers(gan, case):
     assert torch.equal(y.double().cpu(), want)
     y2 = fn(xb, w.cuda(), b.cuda(), stride, pad, out_dtype=torch.float32)
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("cin,cout,N", [(3, 64, 8), (1, 16, 5), (4, 48, 3), (3, 32, 16)])
+def test_image_layer_weight_gradient_is_exact_on_small_integers(gan, cin, cout, N):
+    """The weight-gradient kernel of the critics' first layer (<= 4 channels -> <= 64, 4 x 4 / stride 2 / padding 1, 64-pixel
+    wide images, bf16 operands): on small integers every sum is exact, so it must equal torch's CPU gradient bit for bit,
+    alone and as two segments of one launch."""
+    from gan_amd import ops, _lib
+    g = torch.Generator().manual_seed(23 + cin)
+    x = torch.randint(-2, 3, (N, cin, 64, 64), generator=g).float()
+    gy = torch.randint(-2, 3, (N, cout, 32, 32), generator=g).float()
+    xr = x.double().requires_grad_(False)
+    w = torch.zeros(cout, cin, 4, 4, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xr, w, None, 2, 1).backward(gy.double())
+    xb = x.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gb = gy.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    _lib.profile_enable(True)
+    gw = ops.conv_wgrad(xb, gb, 4, 4, 2, 1, _lib.GC_PREC_BF16)
+    torch.cuda.synchronize()
+    names = set(_lib.profile_collect())
+    _lib.profile_enable(False)
+    assert "gc::conv_wgrad_image_kernel" in names, sorted(names)
+    assert torch.equal(gw.double().cpu(), w.grad)
+    if N >= 5:
+        buf = torch.empty_like(gw)
+        ops._wgrad_launch_multi([(xb[:3], gb[:3]), (xb[3:], gb[3:])], buf, 4, 4, 2, 1, _lib.GC_PREC_BF16, 1.0, accumulate=False)
+        assert torch.equal(buf.double().cpu(), w.grad)
