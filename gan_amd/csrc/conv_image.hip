@@ -7,6 +7,8 @@
 // filter row are 32 contiguous bytes for every output pixel: the B operand of a 16x16x32 MFMA (two filter rows) is
 // one 16-byte LDS read per lane, with no address arithmetic per tap.  The packed weights ([oc][tap][4 channels],
 // 64 reduction elements per row) stay in registers as A operands.
+#include <stdlib.h>
+
 #include "conv_gather.h"
 
 namespace gc {
@@ -16,14 +18,17 @@ constexpr int kTH = 4, kTW = 32;                 // output rectangle of a workgr
 constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 
 // LEAN: the epilogue's activation is none / ReLU / LeakyReLU with a slope in [0, 1], i.e. max(v, s v) with s = 1 / 0 / slope
+//
+// A workgroup walks a run of consecutive rectangles (units: sample-major, then rows of rectangles, then columns): the
+// weights and the bias are fetched once, and the image loads of rectangle i + 1 are in flight while rectangle i is
+// multiplied and stored (two patch buffers, the raw floats wait in registers).
 template <typename TOut, bool LEAN>
-__global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p) {
-  __shared__ __attribute__((aligned(16))) uint16_t patch[kPH * kPW * 4];
+__global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p, int units, int units_per_wg) {
+  __shared__ __attribute__((aligned(16))) uint16_t patch[2][kPH * kPW * 4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c16 = lane & 15;
-  const int tiles_w = p.OW / kTW;
-  const int n = blockIdx.y, th = (int)blockIdx.x / tiles_w, tw = (int)blockIdx.x - th * tiles_w;
-  const int oh0 = th * kTH, ow0 = tw * kTW;
-  const int ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;   // input coordinates of patch element (0, 0)
+  const int tiles_w = p.OW / kTW, tiles = tiles_w * (p.OH / kTH);
+  const int u0 = (int)blockIdx.x * units_per_wg, u1 = min(units, u0 + units_per_wg);
+  if (u0 >= u1) return;
 
   // weights: A fragments of up to four 16-channel blocks, two reduction steps (filter rows 0-1, 2-3)
   bf16x8 wa[4][2];
@@ -36,27 +41,6 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
       if (ob * 16 < p.OC) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)(ob * 16 + c16) * p.row_pitch + ks * 32 + g * 8);
       wa[ob][ks] = __builtin_bit_cast(bf16x8, v);
     }
-
-  // stage the patch: one thread per pixel, channels padded to 4 (row / column of the walk kept incrementally)
-  const float* img = reinterpret_cast<const float*>(p.in) + (size_t)n * p.IH * p.IW * p.IC;
-  int pr = t / kPW, pc = t - pr * kPW;
-  for (int e = t; e < kPH * kPW; e += kThreads) {
-    const int ih = ih0 + pr, iw = iw0 + pc;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
-      const float* src = img + (uint32_t)((ih * p.IW + iw) * p.IC);
-      v[0] = src[0];
-      if (p.IC > 1) v[1] = src[1];
-      if (p.IC > 2) v[2] = src[2];
-      if (p.IC > 3) v[3] = src[3];
-    }
-    *reinterpret_cast<u32x2*>(patch + e * 4) = cvt_bf16x4(v);
-    pr += kThreads / kPW;
-    pc += kThreads % kPW;
-    if (pc >= kPW) { pc -= kPW; pr++; }
-  }
-  __syncthreads();
-
   f32x4 bias_v[4];
 #pragma unroll
   for (int ob = 0; ob < 4; ob++) {
@@ -65,39 +49,84 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
   }
   const float sl = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);
 
-  // wave w: output rows RW * w .. of the rectangle, each in two groups of 16 pixels
-  constexpr int RW = kTH / 4;
+  // ---- the up to three patch pixels of this thread (channels padded to 4)
+  constexpr int NP = (kPH * kPW + kThreads - 1) / kThreads;
+  int ppr[NP], ppc[NP];
 #pragma unroll
-  for (int grp = 0; grp < 2 * RW; grp++) {
-    const int oh_l = RW * wave + (grp >> 1), ow_l = (grp & 1) * 16 + c16;
-    f32x4 acc[4];
+  for (int i = 0; i < NP; i++) {
+    const int e = t + i * kThreads;
+    ppr[i] = e / kPW;
+    ppc[i] = e - ppr[i] * kPW;
+  }
+  f32x4 raw[NP];
+  auto load_unit = [&](int u) {
+    const int n = u / tiles, r = u - n * tiles, th = r / tiles_w, tw = r - th * tiles_w;
+    const int ih0 = 2 * kTH * th - 1, iw0 = 2 * kTW * tw - 1;       // input coordinates of patch element (0, 0)
+    const float* img = reinterpret_cast<const float*>(p.in) + (size_t)n * p.IH * p.IW * p.IC;
 #pragma unroll
-    for (int ob = 0; ob < 4; ob++) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const int pr = 2 * oh_l + 2 * ks + (g >> 1), pc = 2 * ow_l + 2 * (g & 1);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(patch + (pr * kPW + pc) * 4);
-#pragma unroll
-      for (int ob = 0; ob < 4; ob++)
-        if (ob * 16 < p.OC) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
-    }
-    const uint32_t pix = (uint32_t)((oh0 + oh_l) * p.OW + ow0 + ow_l);
-    const size_t o0 = ((size_t)n * p.OH * p.OW + pix) * p.out_cstride + p.out_coff + 4 * g;
-#pragma unroll
-    for (int ob = 0; ob < 4; ob++) {
-      if (ob * 16 >= p.OC) continue;
-      f32x4 v = acc[ob] + bias_v[ob];
-      if (LEAN) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], v[e] * sl);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act, p.slope);
+    for (int i = 0; i < NP; i++) {
+      const int ih = ih0 + ppr[i], iw = iw0 + ppc[i];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+        const float* src = img + (uint32_t)((ih * p.IW + iw) * p.IC);
+        v[0] = src[0];
+        if (p.IC > 1) v[1] = src[1];
+        if (p.IC > 2) v[2] = src[2];
+        if (p.IC > 3) v[3] = src[3];
       }
-      const size_t o = o0 + ob * 16;
-      if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-      else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v);
+      raw[i] = v;
     }
+  };
+  auto store_unit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+      if (t + i * kThreads < kPH * kPW) *reinterpret_cast<u32x2*>(patch[buf] + (t + i * kThreads) * 4) = cvt_bf16x4(raw[i]);
+  };
+
+  load_unit(u0);
+  store_unit(0);
+  __syncthreads();
+  constexpr int RW = kTH / 4;       // wave w: output rows RW * w .. of the rectangle, each in two groups of 16 pixels
+  for (int u = u0; u < u1; u++) {
+    const int buf = (u - u0) & 1;
+    const bool more = u + 1 < u1;
+    if (more) load_unit(u + 1);
+    const int n = u / tiles, r = u - n * tiles, th = r / tiles_w, tw = r - th * tiles_w;
+    const int oh0 = th * kTH, ow0 = tw * kTW;
+#pragma unroll
+    for (int grp = 0; grp < 2 * RW; grp++) {
+      const int oh_l = RW * wave + (grp >> 1), ow_l = (grp & 1) * 16 + c16;
+      f32x4 acc[4];
+#pragma unroll
+      for (int ob = 0; ob < 4; ob++) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int pr = 2 * oh_l + 2 * ks + (g >> 1), pc = 2 * ow_l + 2 * (g & 1);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(patch[buf] + (pr * kPW + pc) * 4);
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++)
+          if (ob * 16 < p.OC) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
+      }
+      const uint32_t pix = (uint32_t)((oh0 + oh_l) * p.OW + ow0 + ow_l);
+      const size_t o0 = ((size_t)n * p.OH * p.OW + pix) * p.out_cstride + p.out_coff + 4 * g;
+#pragma unroll
+      for (int ob = 0; ob < 4; ob++) {
+        if (ob * 16 >= p.OC) continue;
+        f32x4 v = acc[ob] + bias_v[ob];
+        if (LEAN) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], v[e] * sl);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act, p.slope);
+        }
+        const size_t o = o0 + ob * 16;
+        if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+        else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v);
+      }
+    }
+    if (more) store_unit(buf ^ 1);
+    __syncthreads();
   }
 }
 
@@ -113,22 +142,28 @@ bool plan_image(const GatherParams& p, const GatherLaunch& l) {
   if (p.OC % 16 != 0 || p.OC > 64 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
   if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
   if ((reinterpret_cast<uintptr_t>(p.bias) & 15u) != 0) return false;
-  if ((long)p.IH * p.IW * p.IC >= (1l << 31) || p.N > 65535) return false;      // 32-bit offsets inside a sample; samples on grid.y
-  return (long)(p.OH / kTH) * (p.OW / kTW) < (1l << 31);
+  if ((long)p.IH * p.IW * p.IC >= (1l << 31)) return false;      // 32-bit offsets inside a sample
+  return (long)p.N * (p.OH / kTH) * (p.OW / kTW) < (1l << 31);
 }
 
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
-  const unsigned blocks = (unsigned)((p.OH / kTH) * (p.OW / kTW));
-  if (blocks == 0 || p.N == 0) return GC_OK;
+  const long units_l = (long)p.N * (p.OH / kTH) * (p.OW / kTW);
+  if (units_l == 0) return GC_OK;
+  const int units = (int)units_l;
+  // about four workgroups per CU, each with at least two rectangles so that the loads of one overlap the other
+  static const int wgs = getenv("GC_IMAGE_WGS") ? atoi(getenv("GC_IMAGE_WGS")) : 1024;
+  int per = (units + wgs - 1) / wgs;
+  if (per < 2) per = units >= 2 ? 2 : 1;
+  const unsigned blocks = (unsigned)((units + per - 1) / per);
   ProfScope ps("gc::conv_image_kernel", l.flops, stream);
   const bool lean = p.act == GC_ACT_NONE || p.act == GC_ACT_RELU || (p.act == GC_ACT_LRELU && p.slope >= 0.f && p.slope <= 1.f);
-  const dim3 grid(blocks, p.N);
+  const dim3 grid(blocks);
   if (out_f32) {
-    if (lean) hipLaunchKernelGGL((conv_image_kernel<float, true>), grid, dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL((conv_image_kernel<float, false>), grid, dim3(kThreads), 0, stream, p);
+    if (lean) hipLaunchKernelGGL((conv_image_kernel<float, true>), grid, dim3(kThreads), 0, stream, p, units, per);
+    else hipLaunchKernelGGL((conv_image_kernel<float, false>), grid, dim3(kThreads), 0, stream, p, units, per);
   } else {
-    if (lean) hipLaunchKernelGGL((conv_image_kernel<uint16_t, true>), grid, dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL((conv_image_kernel<uint16_t, false>), grid, dim3(kThreads), 0, stream, p);
+    if (lean) hipLaunchKernelGGL((conv_image_kernel<uint16_t, true>), grid, dim3(kThreads), 0, stream, p, units, per);
+    else hipLaunchKernelGGL((conv_image_kernel<uint16_t, false>), grid, dim3(kThreads), 0, stream, p, units, per);
   }
   return check_hip(hipGetLastError(), "conv_image launch");
 }
