@@ -392,7 +392,7 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   if (l.to == 128) {   // too few 128-channel tiles to cover the CUs: halve the channel tile
     long pix_tiles = 0;
     for (int c = 0; c < p.tt.n_classes; c++) pix_tiles += ((long)p.N * p.tt.cls_oh[c] * p.tt.cls_ow[c] + l.tp - 1) / l.tp;
-    static const long to64_max = getenv("GC_TO64_MAX_TILES") ? atol(getenv("GC_TO64_MAX_TILES")) : 300;
+    static const long to64_max = getenv("GC_TO64_MAX_TILES") ? atol(getenv("GC_TO64_MAX_TILES")) : 128;
     if (pix_tiles * ((p.OC + 127) / 128) <= to64_max) l.to = 64;
   }
   p.n_oc_tiles = (p.OC + l.to - 1) / l.to;

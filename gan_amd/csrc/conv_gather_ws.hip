@@ -578,7 +578,11 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
   // trimmed so that every workgroup gets the same number of tiles where that is possible.
   static const int force_stages = getenv("GC_WS_STAGES") ? atoi(getenv("GC_WS_STAGES")) : 0;
   static const int force_slots = getenv("GC_WS_SLOTS") ? atoi(getenv("GC_WS_SLOTS")) : 0;
-  const int stages = (force_stages && p.mask == nullptr) ? force_stages : (l.to == 128 ? 2 : 3);
+  // 128-channel tiles: two ring buffers leave room for two workgroups per CU; with at most one tile per CU a second
+  // workgroup has nothing to do and a deeper ring hides more of the load latency instead
+  static const int deep_ring = getenv("GC_WS_DEEP_RING") ? atoi(getenv("GC_WS_DEEP_RING")) : 1;
+  const int stages = (force_stages && p.mask == nullptr) ? force_stages
+                     : (l.to == 128 ? ((deep_ring && p.mask == nullptr && p.n_tiles <= 256) ? 3 : 2) : 3);
   const int lds = stages * (l.to + kTP) * 128 + kMaxTaps * 4;
   int per_cu = (160 * 1024) / lds;
   if (per_cu > 2) per_cu = 2;
