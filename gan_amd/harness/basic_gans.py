@@ -91,6 +91,7 @@ _side_streams = {}
 
 
 fused_batchnorm_statistics = True     # networks built while this is set: see gan_amd.nn.fuse_batchnorm_statistics
+early_weight_gradients = 1   # > 0: a layer's weight-gradient launch starts on one of this many streams as soon as its last contribution exists
 flush_lanes = 2              # side streams that share the layers' weight-gradient launches with the calling stream
 serialize_chains = False     # True: the chains run one after the other on the calling stream (same kernels; for per-kernel timing)
 
@@ -229,7 +230,9 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
         # over the pixels of all of them: a third of the weight-gradient launches and split reductions, no additions.
         bufs = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params]
         lanes = [] if serialize_chains else [_side_stream(real.device, i) for i in range(flush_lanes)]
-        with gops.weight_gradient_sink(params, bufs, defer=True, flush_streams=lanes) as sink:
+        early = [] if (serialize_chains or not early_weight_gradients) else [_side_stream(real.device, 8 + i) for i in range(early_weight_gradients)]
+        with gops.weight_gradient_sink(params, bufs, defer=True, flush_streams=lanes, expected=len(rf_chains) + 2,
+                                       early_streams=early) as sink:
             run_chains()
         g_main = []
         for i, (p, b) in enumerate(zip(params, bufs)):

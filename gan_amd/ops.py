@@ -187,8 +187,12 @@ class weight_gradient_sink:
     those take the ordinary path.  Process-wide like the other switches: one sink at a time."""
     active = None
 
-    def __init__(self, params, buffers, fork=False, defer=False, flush_streams=()):
+    def __init__(self, params, buffers, fork=False, defer=False, flush_streams=(), expected=0, early_streams=()):
         self.flush_streams = list(flush_streams)     # deferred mode: the weights' launches are dealt out over these streams and the calling one
+        # deferred mode, optional: a weight whose `expected`-th contribution has arrived is launched right away on one of
+        # `early_streams` (which waits for the streams that produced the contributions), beside the rest of the passes
+        self.expected, self.early_streams = int(expected), list(early_streams)
+        self.events, self.early_used, self.n_early = {}, [], 0
         self.buffers = {p.data_ptr(): (p, b) for p, b in zip(params, buffers)}
         self.touched = set()
         self.fork = fork
@@ -210,6 +214,9 @@ class weight_gradient_sink:
                     self.side = _sink_streams.get(dev)
                     if self.side is None:
                         self.side = _sink_streams[dev] = torch.cuda.Stream(dev)
+        if self.early_streams and dev is not None:
+            self.fork0 = torch.cuda.Event()
+            self.fork0.record(self.main)
         weight_gradient_sink.active = self
         return self
 
@@ -219,9 +226,34 @@ class weight_gradient_sink:
             self.flush()
         if self.forked:
             self.main.wait_stream(self.side)
+        for st in self.early_used:
+            self.main.wait_stream(st)
         self.keep.clear()
         self.pending.clear()
+        self.events.clear()
         return False
+
+    def contribution(self, key, item):
+        """Deferred mode: one (x, gy, geometry) pair for the weight `key`, produced on the current stream."""
+        items = self.pending.setdefault(key, [])
+        items.append(item)
+        if not (self.early_streams and self.expected):
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.events.setdefault(key, []).append(ev)
+        if len(items) == self.expected:
+            lane = self.early_streams[self.n_early % len(self.early_streams)]
+            self.n_early += 1
+            if lane not in self.early_used:
+                lane.wait_event(self.fork0)       # the lane joins a running capture from the stream the capture started on
+                self.early_used.append(lane)
+            for e in self.events.pop(key):
+                lane.wait_event(e)
+            self.keep.extend(items)               # the operands stay allocated until the calling stream has joined the lane
+            del self.pending[key]
+            with torch.cuda.stream(lane):
+                self._flush_weight(key, list(items))
 
     def flush(self):
         """Deferred mode: launches what was collected, on the current stream -- per weight one kernel that reduces over
@@ -760,7 +792,7 @@ def _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
         raise RuntimeError("ganconv: weight_gradient_sink buffers must be contiguous float32 tensors")
     if sink.defer:      # operands in their kernel form now (on the stream that produced them), the launch at flush()
         xo, gyo = _wgrad_operands(x, gy, precision)
-        sink.pending.setdefault(w.data_ptr(), []).append((xo, gyo, (w.shape[2], w.shape[3], stride, padding, precision, alpha)))
+        sink.contribution(w.data_ptr(), (xo, gyo, (w.shape[2], w.shape[3], stride, padding, precision, alpha)))
         return True
     _wgrad_launch(x, gy, buf, w.shape[2], w.shape[3], stride, padding, precision, alpha, accumulate, lambda *keep: sink.stream_for(w, *keep))
     return True
