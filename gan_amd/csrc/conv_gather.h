@@ -78,6 +78,8 @@ int launch_gather(const GatherParams& p, const GatherLaunch& l, hipStream_t stre
 bool plan_scatter(GatherParams& p, const GatherLaunch& l);
 int launch_scatter(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // Image layer (<= 4 fp32 input channels, 4x4 stride-2 forward): patch staged once, see conv_image.hip.
+bool plan_dot(const GatherParams& p, const GatherLaunch& l);
+int launch_dot(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 bool plan_image(const GatherParams& p, const GatherLaunch& l);
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // Patch-resident kernel (stride-1 gathers with >= 4 taps per class on large images, see conv_patch.hip); plan_patch

@@ -330,6 +330,7 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
     set_error("out_bf16 needs an fp32 output whose channel slice is a multiple of 4 channels at a multiple of 4");
     return GC_UNSUPPORTED_GEOMETRY;
   }
+  if (plan_dot(p, l)) return launch_dot(p, l, out_dt == GC_F32, stream);
   if (plan_image(p, l)) return launch_image(p, l, out_dt == GC_F32, stream);
   if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   l.big_tile_ok = true;

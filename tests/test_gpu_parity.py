@@ -1614,3 +1614,24 @@ def test_image_layer_weight_gradient_is_exact_on_small_integers(gan, cin, cout, 
         buf = torch.empty_like(gw)
         ops._wgrad_launch_multi([(xb[:3], gb[:3]), (xb[3:], gb[3:])], buf, 4, 4, 2, 1, _lib.GC_PREC_BF16, 1.0, accumulate=False)
         assert torch.equal(buf.double().cpu(), w.grad)
+
+
+@pytest.mark.parametrize("cin,cout,hw,dt", [(512, 1, 4, torch.bfloat16), (512, 1, 4, torch.float32), (128, 3, 2, torch.bfloat16),
+                                            (64, 4, 8, torch.bfloat16)])
+def test_score_layer_dot_kernel_is_exact_on_small_integers(gan, cin, cout, hw, dt):
+    """A window that is the whole input, up to four output channels (the critics' score layer, BasicGANs/models.py:77): one
+    dot product per sample and channel.  Exact on small integers, reproducible, with bias and activation."""
+    g = torch.Generator().manual_seed(31)
+    N = 37
+    x = torch.randint(-2, 3, (N, cin, hw, hw), generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin, hw, hw), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double()), 0.25)
+    xg = x.cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    gan._lib.profile_enable(True)
+    y = gan.functional.conv2d(xg, w.cuda(), b.cuda(), activation="leaky_relu", negative_slope=0.25, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    names = set(gan._lib.profile_collect())
+    gan._lib.profile_enable(False)
+    assert "gc::conv_dot_kernel" in names, sorted(names)
+    assert torch.equal(y.double().cpu(), want)
