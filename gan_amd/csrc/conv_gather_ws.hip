@@ -176,7 +176,8 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
     const int sub_row = lane >> 3, pos = lane & 7;
 
     // ---- issue cursor: (tile k_i, tap, channel step) of the next step to load, with the tile's per-lane rows
-    uint32_t a_off[AJ], w_voff[WJ];
+    uint32_t a_off[AJ], a_voff[AJ], w_voff[WJ];     // a_voff: a_off, or out of range where the current tap leaves the image
+    const bool full_steps = p.IC % kBK == 0;       // every 64-channel step lies inside the tensor's channels
     int a_ih[AJ], a_iw[AJ], a_chunk[AJ];
     int k_i = 0, tap_i = 0, cs_i = 0, left_i = 0;
     int s_dh = 0, s_dw = 0;
@@ -188,6 +189,13 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
       s_dw = (int)(int8_t)((e >> 8) & 0xff);
       s_aoff = (uint32_t)(((s_dh * p.IW + s_dw) * p.in_cstride) * 2 + p.a_bias);
       s_woff = (uint32_t)((e >> 16) * p.ICp * 2);
+      // which rows the tap keeps inside the image: once per tap, not once per channel step
+#pragma unroll
+      for (int j = 0; j < AJ; j++) {
+        // (bitwise on purpose: a short-circuit would turn into exec-mask branches)
+        const bool ok = ((unsigned)(a_ih[j] + s_dh) < (unsigned)p.IH) & ((unsigned)(a_iw[j] + s_dw) < (unsigned)p.IW);
+        a_voff[j] = ok ? a_off[j] : kOutOfRange;
+      }
     };
     auto setup_tile = [&](int k) {
       TileId id;
@@ -245,11 +253,9 @@ __global__ __launch_bounds__(2 * kNW * 64) void conv_gather_ws_kernel(const WsPa
                                                    (int)(s_woff + c0 * 2), 0, 0);
 #pragma unroll
         for (int j = 0; j < AJ; j++) {
-          // (bitwise on purpose: a short-circuit would turn into exec-mask branches)
-          const bool ok = ((unsigned)(a_ih[j] + s_dh) < (unsigned)p.IH) & ((unsigned)(a_iw[j] + s_dw) < (unsigned)p.IW) &
-                          ((c0 | a_chunk[j]) < p.IC);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(ab + (wave * AJ + j) * 1024), 16,
-                                                   (int)(ok ? a_off[j] : kOutOfRange), (int)(s_aoff + c0 * 2), 0, 0);
+          const uint32_t voff = (full_steps || (c0 | a_chunk[j]) < p.IC) ? a_voff[j] : kOutOfRange;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(ab + (wave * AJ + j) * 1024), 16, (int)voff,
+                                                   (int)(s_aoff + c0 * 2), 0, 0);
         }
         st_i = next_stage(st_i);
         advance();
