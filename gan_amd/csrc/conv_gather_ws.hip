@@ -504,9 +504,10 @@ int launch_one(const WsParams& p, int grid, double flops, hipStream_t stream) {
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   });
   if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
-  char name[96];
-  snprintf(name, sizeof(name), "gc::conv_gather_ws_kernel<%s, %d, %d, %s>%s", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, STAGES,
-           MASK ? "true" : "false", !SPLIT ? "" : (p.nsum > 0 ? " (adding the parts)" : " (split reduction)"));
+  char name[128];
+  // (the demangled kernel name as a profiler prints it, plus which of its two launches a split reduction is)
+  snprintf(name, sizeof(name), "gc::conv_gather_ws_kernel<%s, %d, %d, %s, %s>%s", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, STAGES,
+           MASK ? "true" : "false", SPLIT ? "true" : "false", !SPLIT ? "" : (p.nsum > 0 ? " (adding the parts)" : " (split reduction)"));
   static const bool stamps = getenv("GC_DIAG_STAMPS") != nullptr;
   if (stamps) {   // diagnostic: synchronous launches with cycle stamps per workgroup, summary on stderr
     static unsigned long long* dbuf = nullptr;
