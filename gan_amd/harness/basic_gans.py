@@ -524,12 +524,9 @@ class WganGpTrainer:
         def gen():
             step_D()
             self.red_G.zero_grad()
-            for p in self.net_D.parameters():
-                p.requires_grad_(False)
-            out = wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], None)
-            for p in self.net_D.parameters():
-                p.requires_grad_(True)
-            return out
+            # (the critic's parameters stay trainable, as in the reference and in the single-graph form: its gradients of this
+            #  phase land in its buckets and are zeroed at the start of the next critic iteration)
+            return wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], None)
         g_fb, out = record(gen)
         g_opt, _ = record(lambda: (self.red_G.average_(), self.opt_G.step(), gops.clear_cast_cache()))
         self.graphs += [(g_fb, self.red_G), (g_opt, None)]
