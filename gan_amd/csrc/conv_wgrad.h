@@ -16,6 +16,7 @@ struct WgradParams {
   int32_t k_per_split;   // multiple of the reduction step
   int32_t n_co_tiles, n_ci_tiles, splits;
   int32_t y_elem;        // register-staged kernel, vector instantiation: the gy side still needs element loads (odd Cout)
+  int32_t x_f32;         // 1: x is fp32 while gy is bf16 (the image-layer kernel rounds it in registers; nothing else takes the mix)
   int32_t image;         // 1: geometry of the image-layer kernel (conv_wgrad_image.hip); splits start on its 128-pixel rectangles
   int32_t thin;          // 1: Cin <= 32; the tile's columns run over (tap, channel) jointly, channel padded to ICp
   int32_t ICp, icp_log2, ncols;   // thin mode: padded channels per tap, its log2, T * ICp

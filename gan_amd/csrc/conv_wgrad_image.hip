@@ -33,12 +33,14 @@ __device__ __forceinline__ bf16x8 read_tr(const char* a0, int second_offset) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// TX: storage type of the image (uint16_t = bf16, float: rounded to bf16 on the way into the patch)
+template <typename TX>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (kPatchBytes + kGyBytes)];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int split = blockIdx.x;
   const WgradRange rg = wgrad_range(p, split);
-  const uint16_t* x = reinterpret_cast<const uint16_t*>(rg.x);
+  const TX* x = reinterpret_cast<const TX*>(rg.x);
   const uint16_t* gy = reinterpret_cast<const uint16_t*>(rg.gy);
   const int u0 = rg.kb0 / kUnit, u1 = rg.kend > rg.kb0 ? (rg.kend + kUnit - 1) / kUnit : u0;
   const int units_per_sample = p.Ho / kTH;
@@ -63,18 +65,19 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
       yreg[i] = u32x4{0u, 0u, 0u, 0u};
       if (ch < ychunks) yreg[i] = *reinterpret_cast<const u32x4*>(gy + (k0 + row) * p.y_cstride + p.y_coff + ch * 8);
     }
-    const uint16_t* img = x + (size_t)n * p.H * p.W * p.Cin;
+    const TX* img = x + (size_t)n * p.H * p.W * p.Cin;
     const int ih0 = 2 * kTH * th - 1;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int ih = ih0 + ppr[i], iw = ppc[i] - 1;
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
       if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-        const uint16_t* src = img + (uint32_t)((ih * p.W + iw) * p.Cin);
-        c0 = src[0];
-        if (p.Cin > 1) c1 = src[1];
-        if (p.Cin > 2) c2 = src[2];
-        if (p.Cin > 3) c3 = src[3];
+        const TX* src = img + (uint32_t)((ih * p.W + iw) * p.Cin);
+        auto bits = [](TX v) -> uint32_t { return sizeof(TX) == 2 ? (uint32_t)v : (uint32_t)float_to_bf16_bits((float)v); };
+        c0 = bits(src[0]);
+        if (p.Cin > 1) c1 = bits(src[1]);
+        if (p.Cin > 2) c2 = bits(src[2]);
+        if (p.Cin > 3) c3 = bits(src[3]);
       }
       xreg[i] = u32x2{c0 | (c1 << 16), c2 | (c3 << 16)};
     }
@@ -180,7 +183,8 @@ bool wgrad_image_geometry(const WgradParams& p) {
 int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t stream) {
   if (p.K <= 0 || p.splits <= 0) return GC_OK;
   ProfScope ps("gc::conv_wgrad_image_kernel", l.flops, stream);
-  hipLaunchKernelGGL(conv_wgrad_image_kernel, dim3((unsigned)p.splits), dim3(kThreads), 0, stream, p);
+  if (p.x_f32) hipLaunchKernelGGL(conv_wgrad_image_kernel<float>, dim3((unsigned)p.splits), dim3(kThreads), 0, stream, p);
+  else hipLaunchKernelGGL(conv_wgrad_image_kernel<uint16_t>, dim3((unsigned)p.splits), dim3(kThreads), 0, stream, p);
   return check_hip(hipGetLastError(), "conv_wgrad_image launch");
 }
 

@@ -640,7 +640,9 @@ static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l, b
   p.x_cstride = x_cs(d); p.x_coff = d->x_coff; p.y_cstride = y_cs(d); p.y_coff = d->y_coff;
   p.K = d->N * d->Ho * d->Wo;
   p.div_wo = make_fastdiv((uint32_t)d->Wo); p.div_ho = make_fastdiv((uint32_t)d->Ho);
-  l.bf16 = d->x_dtype == GC_BF16; l.x3 = d->precision == GC_PREC_F32X3;
+  // an fp32 x with a bf16 gy: planned as bf16 operands; only the image-layer kernel converts x itself (checked in wgrad_run)
+  p.x_f32 = (d->x_dtype == GC_F32 && d->y_dtype == GC_BF16) ? 1 : 0;
+  l.bf16 = d->y_dtype == GC_BF16 && (d->x_dtype == GC_BF16 || p.x_f32); l.x3 = d->precision == GC_PREC_F32X3;
   plan_wgrad(p, l, allow_dma);
 }
 
@@ -700,7 +702,11 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
     p.seg_x_bytes[g] = (int64_t)Ns[g] * d->H * d->W * p.x_cstride * 2;
     p.seg_y_bytes[g] = (int64_t)p.seg_K[g] * p.y_cstride * 2;
   }
-  const int epc = elems_per_chunk(d->x_dtype);
+  if (d->x_dtype != d->y_dtype && !(p.x_f32 && p.image)) {
+    set_error("%s: x and gy must have one dtype (an fp32 image with a bf16 gradient is taken in the image layer's geometry only)", who);
+    return GC_UNSUPPORTED_GEOMETRY;
+  }
+  const int epc = elems_per_chunk(d->y_dtype);
   const bool x_vec = al && (p.x_cstride % epc == 0) && (p.x_coff % epc == 0) && (p.Cin % epc == 0);
   const bool y_vec = al && (p.y_cstride % epc == 0) && (p.y_coff % epc == 0) && (p.Cout % epc == 0);
   // thin input: the template flag is about the gy side (the x side always takes element loads); otherwise it is about the

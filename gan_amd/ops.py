@@ -716,8 +716,21 @@ def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0, out
     return gy.new_empty((gy.shape[0], w.shape[1], H, W), dtype=_out_dtype(gy, out_dtype))
 
 
-def _wgrad_operands(x, gy, precision):
+def _image_layer(x, gy, geom, precision):
+    """fp32 image, bf16 gradient, in the geometry of the image layer's weight-gradient kernel (conv_wgrad_image.hip),
+    which rounds the image to bf16 in registers: no bf16 copy of the image is needed."""
+    if geom is None or x.dtype != torch.float32 or gy.dtype != torch.bfloat16 or precision != _lib.GC_PREC_BF16:
+        return False
+    kh, kw, stride, padding = geom
+    (_, Cin, H, W), (_, Cout, Ho, Wo) = x.shape, gy.shape
+    return (Cin <= 4 and kh == 4 and kw == 4 and stride == 2 and padding == 1 and Wo == 32 and Ho % 4 == 0 and H == 2 * Ho and W == 2 * Wo
+            and Cout % 16 == 0 and Cout <= 64)
+
+
+def _wgrad_operands(x, gy, precision, geom=None):
     x, gy = _nhwc(x), _nhwc(gy)
+    if _image_layer(x, gy, geom, precision):
+        return x, gy
     if x.dtype != gy.dtype:      # mixed storage (e.g. an fp32 image feeding bf16 activations): the operands are bf16 anyway
         x = x if x.dtype == torch.bfloat16 else _to_bf16(x)
         gy = gy if gy.dtype == torch.bfloat16 else _to_bf16(gy)
@@ -736,8 +749,8 @@ def _wgrad_launch(x, gy, gw, kh, kw, stride, padding, precision, alpha, accumula
     N2, Cout, Ho, Wo = gy.shape
     if N2 != N or (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
         raise RuntimeError("ganconv: x and gy shapes are inconsistent with the convolution geometry")
-    x, gy = _wgrad_operands(x, gy, precision)
-    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision)
+    x, gy = _wgrad_operands(x, gy, precision, (kh, kw, stride, padding))
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(gy))
     L = _lib.lib()
     ws_bytes = L.gc_wgrad_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
@@ -764,9 +777,9 @@ def _wgrad_launch_multi(pairs, gw, kh, kw, stride, padding, precision, alpha, ac
     _, Cin, H, W = x0.shape
     _, Cout, Ho, Wo = gy0.shape
     for x, gy in pairs:
-        if x.shape[1:] != x0.shape[1:] or gy.shape[1:] != gy0.shape[1:] or x.shape[0] != gy.shape[0] or x.dtype != x0.dtype or gy.dtype != x0.dtype:
+        if x.shape[1:] != x0.shape[1:] or gy.shape[1:] != gy0.shape[1:] or x.shape[0] != gy.shape[0] or x.dtype != x0.dtype or gy.dtype != gy0.dtype:
             raise RuntimeError("ganconv: the pairs of a multi-segment weight gradient must share geometry and storage type")
-    d = _desc(x0.shape[0], H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x0), precision)
+    d = _desc(x0.shape[0], H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x0), precision, _dtype_code(gy0))
     L = _lib.lib()
     n = len(pairs)
     Ns = (ctypes.c_int32 * n)(*[p[0].shape[0] for p in pairs])
@@ -791,7 +804,7 @@ def _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
     if buf.dtype != torch.float32 or not buf.is_contiguous():
         raise RuntimeError("ganconv: weight_gradient_sink buffers must be contiguous float32 tensors")
     if sink.defer:      # operands in their kernel form now (on the stream that produced them), the launch at flush()
-        xo, gyo = _wgrad_operands(x, gy, precision)
+        xo, gyo = _wgrad_operands(x, gy, precision, (w.shape[2], w.shape[3], stride, padding))
         sink.contribution(w.data_ptr(), (xo, gyo, (w.shape[2], w.shape[3], stride, padding, precision, alpha)))
         return True
     _wgrad_launch(x, gy, buf, w.shape[2], w.shape[3], stride, padding, precision, alpha, accumulate, lambda *keep: sink.stream_for(w, *keep))

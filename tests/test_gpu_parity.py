@@ -1614,6 +1614,15 @@ def test_image_layer_weight_gradient_is_exact_on_small_integers(gan, cin, cout, 
         buf = torch.empty_like(gw)
         ops._wgrad_launch_multi([(xb[:3], gb[:3]), (xb[3:], gb[3:])], buf, 4, 4, 2, 1, _lib.GC_PREC_BF16, 1.0, accumulate=False)
         assert torch.equal(buf.double().cpu(), w.grad)
+    # the fp32 image itself (rounded to bf16 inside the kernel: no bf16 copy of the image)
+    xf = x.cuda().contiguous(memory_format=torch.channels_last)
+    _lib.profile_enable(True)
+    gw2 = ops.conv_wgrad(xf, gb, 4, 4, 2, 1, _lib.GC_PREC_BF16)
+    torch.cuda.synchronize()
+    names = set(_lib.profile_collect())
+    _lib.profile_enable(False)
+    assert "gc::conv_wgrad_image_kernel" in names and not any("copy" in n for n in names), sorted(names)
+    assert torch.equal(gw2.double().cpu(), w.grad)
 
 
 @pytest.mark.parametrize("cin,cout,hw,dt", [(512, 1, 4, torch.bfloat16), (512, 1, 4, torch.float32), (128, 3, 2, torch.bfloat16),
