@@ -369,6 +369,7 @@ class WganGpTrainer:
         self.batch_real_fake = batch_real_fake
         self.two_streams = two_streams      # critic iteration: penalty chain and real + fake chain on two streams
         self.gen_ahead = two_streams        # with two_streams: the generator phase's forward pass runs ahead as well (-1.6 %)
+        self.freeze_critic_in_generator_phase = False   # True: skip the critic's (discarded) weight gradients of that phase
         self.device = torch.device(device)
         self.net_G = Generator(z_dim, hidden_dim, 3, resolution, activation_dtype=activation_dtype)
         self.net_D = Discriminator(3, hidden_dim, resolution, is_wgan=True, activation_dtype=activation_dtype)
@@ -434,6 +435,19 @@ class WganGpTrainer:
             torch.cuda.current_stream(self.device).wait_event(ev)
         return f
 
+    def _generator_phase(self, arm, fake=None):
+        """The generator phase of the cycle.  The critic's weight gradients of this pass -- added to the critic's
+        gradients as the reference adds them (BasicGANs/loss_functions.py:31-36), read by nobody -- are no link of the
+        backward chain: each is launched on a stream of its own as soon as its operands exist."""
+        weights = [p for p in self.net_D.parameters()
+                   if p.requires_grad and p.dim() == 4 and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()]
+        if self.device.type != "cuda" or not weights or not weight_gradient_sink:
+            return wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], arm, fake)
+        early = [] if (serialize_chains or not early_weight_gradients) else [_side_stream(self.device, 8)]
+        with gops.weight_gradient_sink(weights, [p.grad for p in weights], defer=True, expected=1, early_streams=early) as sink:
+            sink.touched.update(p.data_ptr() for p in weights)      # the launches add to the gradients that are there
+            return wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], arm, fake)
+
     def cycle_eager(self):
         out = []
         fakes = self._fakes_ahead(self.gen_ahead) if self.two_streams and self.device.type == "cuda" else None
@@ -448,17 +462,20 @@ class WganGpTrainer:
             self.opt_D.step()
             out += [d_x, d_g_z1, gp]
         self._zero(self.net_G, self.red_G)
-        # the critic's gradients of the generator phase are never used (cleared by the next zero_grad)
-        for p in self.net_D.parameters():
+        # The reference leaves the critic trainable in the generator phase (BasicGANs/loss_functions.py:31-36): its weight
+        # gradients of this pass are computed and then thrown away by the next optimizer_D.zero_grad() (BasicGANs/train.py:96).
+        # The measured cycle computes them as well; freeze_critic_in_generator_phase skips them (no parameter changes).
+        frozen = list(self.net_D.parameters()) if self.freeze_critic_in_generator_phase else []
+        for p in frozen:
             p.requires_grad_(False)
         arm = self.red_G.arm if self.red_G is not None else None
         if fakes is not None and self.gen_ahead:
             # the generator's backward pass runs on the stream of its forward pass, a forked one: no further fork from there
             with gops.suspended_backward_overlap():
-                g_err = wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], arm, self._fake(fakes, self.reps))
+                g_err = self._generator_phase(arm, self._fake(fakes, self.reps))
         else:
-            g_err = wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], arm)
-        for p in self.net_D.parameters():
+            g_err = self._generator_phase(arm)
+        for p in frozen:
             p.requires_grad_(True)
         if self.red_G is not None:
             self.red_G.finish()
@@ -524,9 +541,9 @@ class WganGpTrainer:
         def gen():
             step_D()
             self.red_G.zero_grad()
-            # (the critic's parameters stay trainable, as in the reference and in the single-graph form: its gradients of this
-            #  phase land in its buckets and are zeroed at the start of the next critic iteration)
-            return wgan_generator_phase(self.net_G, self.net_D, self.z[self.reps], None)
+            # (the critic's parameters stay trainable, as in the reference: its gradients of this phase land in its buckets
+            #  and are zeroed at the start of the next critic iteration)
+            return self._generator_phase(None)
         g_fb, out = record(gen)
         g_opt, _ = record(lambda: (self.red_G.average_(), self.opt_G.step(), gops.clear_cast_cache()))
         self.graphs += [(g_fb, self.red_G), (g_opt, None)]

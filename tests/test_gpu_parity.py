@@ -1052,6 +1052,59 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     assert not torch.allclose(ref[2], ref[4], rtol=1e-3)      # the losses do change from cycle to cycle
 
 
+def test_generator_phase_adds_the_critics_weight_gradients_like_the_reference(gan):
+    """The reference's generator phase leaves the critic trainable (BasicGANs/loss_functions.py:31-36): the critic's
+    .grad ends the cycle as (last critic iteration) + (generator phase) and is thrown away by the next zero_grad
+    (BasicGANs/train.py:96).  The trainer computes them too -- through the sink, on a side stream -- and the frozen
+    variant changes no parameter: (a) sink form == plain autograd accumulation, (b) frozen form: same parameters after
+    two cycles, critic gradients differ by the generator phase's share."""
+    from gan_amd.harness import basic_gans
+    from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
+    B = 8
+
+    def run(freeze=False, sink=True, cycles=2, lr=1e-4):
+        old = basic_gans.weight_gradient_sink
+        basic_gans.weight_gradient_sink = sink
+        try:
+            tr = WganGpTrainer(B, 32, 100, 64, device="cuda:0", capturable=True, batch_real_fake=True, fused_adam=True,
+                               two_streams=True, activation_dtype=torch.bfloat16, lr=lr)
+            tr.freeze_critic_in_generator_phase = freeze
+            g = torch.Generator().manual_seed(5001)
+            real, zs = synth_inputs(g, B, 100, 64, 6)
+            tr.set_inputs(real, zs, torch.rand(5, B, 1, 1, 1, generator=g))
+            for _ in range(cycles):
+                tr.cycle_eager()
+            torch.cuda.synchronize()
+            return tr
+        finally:
+            basic_gans.weight_gradient_sink = old
+
+    gan.set_split_reduction(False)      # (no atomic split reductions: runs are bitwise repeatable)
+    try:
+        a, f = run(), run(freeze=True)
+        for (n, pa), (_, pf) in zip(list(a.net_D.named_parameters()) + list(a.net_G.named_parameters()),
+                                    list(f.net_D.named_parameters()) + list(f.net_G.named_parameters())):
+            assert torch.equal(pa, pf), n
+        # learning rate 0: the parameters stay where they are, so the generator phase's share can be computed on its own
+        # afterwards, and the two forms of the critic iterations (other summation orders) cannot drift apart through Adam
+        a0, p0, f0 = run(cycles=1, lr=0.0), run(sink=False, cycles=1, lr=0.0), run(freeze=True, cycles=1, lr=0.0)
+        got = {n: (pa.grad - pf.grad) for (n, pa), (_, pf) in zip(a0.net_D.named_parameters(), f0.net_D.named_parameters())}
+        for (n, pa), (_, pp) in zip(a0.net_D.named_parameters(), p0.net_D.named_parameters()):
+            assert rel(pa.grad, pp.grad) < 2e-3, (n, rel(pa.grad, pp.grad))
+        for q in f0.net_D.parameters():
+            q.grad = None
+        basic_gans.wgan_generator_phase(f0.net_G, f0.net_D, f0.z[f0.reps])        # (no sink: autograd's own accumulation)
+        n_weights = 0
+        for n, q in f0.net_D.named_parameters():
+            if q.dim() == 4:      # (the small share is the difference of two large gradients: fp32 rounding of the sum)
+                n_weights += 1
+                assert q.grad.abs().max() > 0, n
+                assert rel(got[n], q.grad) < 2e-2, (n, rel(got[n], q.grad))
+        assert n_weights == 5
+    finally:
+        gan.set_split_reduction(True)
+
+
 @pytest.mark.parametrize("B,N,d,C", [(2, 256, 8, 64), (3, 384, 16, 128), (1, 4096, 16, 128), (2, 4096, 8, 64)])
 def test_attention_against_unfused_product(gan, B, N, d, C):
     """gan_amd.ops.attention (forward and the three operand gradients) against bmm + softmax + bmm in fp32 on the same

@@ -10,7 +10,7 @@ import gan_amd
 from gan_amd.harness.basic_gans import WganGpTrainer, synth_inputs
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="two_streams", choices=["two_streams", "three_chains", "repack", "gen_ahead", "flag"])
+ap.add_argument("--what", default="two_streams", choices=["two_streams", "three_chains", "repack", "gen_ahead", "flag", "freeze_critic"])
 ap.add_argument("--flag", default="weight_gradient_sink", help="with --what flag: the boolean switch of gan_amd.harness.basic_gans under test, or NAME=A,B for two integer values")
 ap.add_argument("--batch", type=int, default=256)
 args = ap.parse_args()
@@ -27,8 +27,9 @@ def make(on):
     # three_chains: real, fake and penalty passes on three streams against real + fake batched beside the penalty pass
     tr = WganGpTrainer(args.batch, 64, 100, 64, device="cuda:0", capturable=True, batch_real_fake=not (on and args.what == "three_chains"),
                        fused_adam=True, activation_dtype=torch.bfloat16,
-                       two_streams=(on and args.what == "two_streams") or args.what in ("three_chains", "gen_ahead", "flag"))
+                       two_streams=(on and args.what == "two_streams") or args.what in ("three_chains", "gen_ahead", "flag", "freeze_critic"))
     tr.gen_ahead = tr.two_streams and (on or args.what != "gen_ahead")
+    tr.freeze_critic_in_generator_phase = on and args.what == "freeze_critic"
     if args.what == "repack" and not on:
         tr.opt_D.repack_after_step()
         tr.opt_G.repack_after_step()
