@@ -400,7 +400,8 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   if (l.in_bf16 && l.mode == kVecLoads && l.to == 128 && l.big_tile_ok) {
     long pix = 0;
     for (int c = 0; c < p.tt.n_classes; c++) pix += (long)p.N * p.tt.cls_oh[c] * p.tt.cls_ow[c];
-    if ((pix / 256) * p.n_oc_tiles >= 1024) l.tp = 256;
+    static const long big_min = getenv("GC_BIG_TILE_MIN") ? atol(getenv("GC_BIG_TILE_MIN")) : 1024;
+    if ((pix / 256) * p.n_oc_tiles >= big_min) l.tp = 256;
     // largest problems: 256 x 256 per workgroup (two-deep ring fills the LDS) halves the bytes moved into LDS per FLOP
     if (l.tp == 256 && p.OC % 256 == 0 && (pix / 256) * (p.OC / 256) >= 512) {
       l.to = 256;

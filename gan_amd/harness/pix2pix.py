@@ -10,6 +10,7 @@ The dropout masks can be passed in so that a step is repeatable across devices.
 import torch
 
 from .. import nn as gnn
+from .. import ops as gops
 
 # Speed options, read when a network is BUILT (parameter names and state_dicts are the same either way):
 #   activation dtype: storage type of the activations between the layers (None = float32; torch.bfloat16 halves the
@@ -34,51 +35,75 @@ def _batch_norm(ch, activation=None):
 
 
 class DownSample(torch.nn.Module):
-    def __init__(self, in_ch, out_ch, inplace=False, use_bn=True):
+    """LeakyReLU(0.2) -> Conv2d(4, 2, 1) -> BatchNorm2d (Pix2Pix/models.py:4-17).
+
+    `consumer`, fused-norm networks only: the activation every reader of this block's output applies first ("leaky_relu":
+    the next down block, whose own LeakyReLU then is not run again; "relu": the first up block).  It moves into this
+    block's last kernel (the norm's apply pass, or the convolution's epilogue without a norm), and the block takes its
+    input already activated (`input_activated`).  The up block that reads the same output through the skip connection
+    applies ReLU to it, and relu(leaky_relu(v)) = relu(v) with the same derivative, so values and gradients are those
+    of the reference graph."""
+
+    def __init__(self, in_ch, out_ch, inplace=False, use_bn=True, consumer=None, input_activated=False):
         super().__init__()
-        self.downsample = gnn.Conv2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1, channel_statistics=use_bn and _FUSED_NORM)
+        consumer = consumer if _FUSED_NORM else None
+        self.input_activated = bool(input_activated and _FUSED_NORM)
+        self.downsample = gnn.Conv2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1, channel_statistics=use_bn and _FUSED_NORM,
+                                     activation=None if use_bn else consumer, negative_slope=0.2)
         self.relu = torch.nn.LeakyReLU(0.2, inplace=inplace)
-        self.batch_norm = _batch_norm(out_ch) if use_bn else torch.nn.Identity()
+        self.batch_norm = _batch_norm(out_ch, consumer) if use_bn else torch.nn.Identity()
 
     def forward(self, x):
-        return self.batch_norm(self.downsample(self.relu(x)))
+        return self.batch_norm(self.downsample(x if self.input_activated else self.relu(x)))
 
 
 class UpSample(torch.nn.Module):
-    def __init__(self, in_ch, out_ch, interpolation=False, use_bn=True):
+    """ReLU -> ConvTranspose2d(4, 2, 1) -> BatchNorm2d (Pix2Pix/models.py:20-37; `leaky_relu` is a ReLU there).
+
+    `fused`, fused-norm networks only: the input arrives with the ReLU applied (by the block before it and the joining
+    kernel of the skip connection), and the ReLU of the NEXT up block -- the only reader of this block's output, through
+    dropout (a multiplication by 0 or 2) and the concatenation, both of which commute with it -- runs in this block's norm
+    kernel."""
+
+    def __init__(self, in_ch, out_ch, interpolation=False, use_bn=True, fused=False):
         super().__init__()
         if interpolation:
             raise RuntimeError("the bilinear-upsample variant is not on the reference's path (Generator never enables it)")
+        self.fused = bool(fused and _FUSED_NORM)
         # (the last block, without BatchNorm, feeds tanh: fused into its epilogue, image in float32)
         self.up_sample = gnn.ConvTranspose2d(in_ch, out_ch, kernel_size=4, stride=2, padding=1, activation=None if use_bn else "tanh",
                                              out_dtype=None if use_bn else torch.float32, channel_statistics=use_bn and _FUSED_NORM)
-        self.batch_norm = _batch_norm(out_ch) if use_bn else torch.nn.Identity()
+        self.batch_norm = _batch_norm(out_ch, "relu" if self.fused else None) if use_bn else torch.nn.Identity()
         self.leaky_relu = torch.nn.ReLU()
 
     def forward(self, x):
-        return self.batch_norm(self.up_sample(self.leaky_relu(x)))
+        return self.batch_norm(self.up_sample(x if self.fused else self.leaky_relu(x)))
 
 
 class Generator(torch.nn.Module):
     def __init__(self, ch=64, image_dim=3, interpolation=True):
         super().__init__()
         self.interpolation = interpolation   # accepted and ignored, as in the reference
-        self.downsample_1 = gnn.Conv2d(image_dim, ch, kernel_size=4, stride=2, padding=1, out_dtype=_ACT_DTYPE)
-        self.downsample_2 = DownSample(ch, ch * 2)
-        self.downsample_3 = DownSample(ch * 2, ch * 4)
-        self.downsample_4 = DownSample(ch * 4, ch * 8)
-        self.downsample_5 = DownSample(ch * 8, ch * 8)
-        self.downsample_6 = DownSample(ch * 8, ch * 8)
-        self.downsample_7 = DownSample(ch * 8, ch * 8)
-        self.downsample_8 = DownSample(ch * 8, ch * 8, use_bn=False)
-        self.upsample_1 = UpSample(ch * 8, ch * 8)
-        self.upsample_2 = UpSample(ch * 8 * 2, ch * 8)
-        self.upsample_3 = UpSample(ch * 8 * 2, ch * 8)
-        self.upsample_4 = UpSample(ch * 8 * 2, ch * 8)
-        self.upsample_5 = UpSample(ch * 8 * 2, ch * 4)
-        self.upsample_6 = UpSample(ch * 4 * 2, ch * 2)
-        self.upsample_7 = UpSample(ch * 2 * 2, ch)
-        self.upsample_8 = UpSample(ch * 2, image_dim, use_bn=False)
+        # fused-norm networks: every activation of the U-Net runs in the kernel that produces its input (see DownSample /
+        # UpSample), and a skip connection's cat + ReLU is one launch (ops.act_concat)
+        self.fused = f = _FUSED_NORM
+        self.downsample_1 = gnn.Conv2d(image_dim, ch, kernel_size=4, stride=2, padding=1, out_dtype=_ACT_DTYPE,
+                                       activation="leaky_relu" if f else None, negative_slope=0.2)
+        self.downsample_2 = DownSample(ch, ch * 2, consumer="leaky_relu", input_activated=True)
+        self.downsample_3 = DownSample(ch * 2, ch * 4, consumer="leaky_relu", input_activated=True)
+        self.downsample_4 = DownSample(ch * 4, ch * 8, consumer="leaky_relu", input_activated=True)
+        self.downsample_5 = DownSample(ch * 8, ch * 8, consumer="leaky_relu", input_activated=True)
+        self.downsample_6 = DownSample(ch * 8, ch * 8, consumer="leaky_relu", input_activated=True)
+        self.downsample_7 = DownSample(ch * 8, ch * 8, consumer="leaky_relu", input_activated=True)
+        self.downsample_8 = DownSample(ch * 8, ch * 8, use_bn=False, consumer="relu", input_activated=True)
+        self.upsample_1 = UpSample(ch * 8, ch * 8, fused=True)
+        self.upsample_2 = UpSample(ch * 8 * 2, ch * 8, fused=True)
+        self.upsample_3 = UpSample(ch * 8 * 2, ch * 8, fused=True)
+        self.upsample_4 = UpSample(ch * 8 * 2, ch * 8, fused=True)
+        self.upsample_5 = UpSample(ch * 8 * 2, ch * 4, fused=True)
+        self.upsample_6 = UpSample(ch * 4 * 2, ch * 2, fused=True)
+        self.upsample_7 = UpSample(ch * 2 * 2, ch, fused=True)
+        self.upsample_8 = UpSample(ch * 2, image_dim, use_bn=False, fused=True)
 
     def forward(self, x, dropout_masks=None):
         """dropout_masks: optional three tensors (already scaled by 1/(1-p)) multiplied onto the outputs of
@@ -87,6 +112,12 @@ class Generator(torch.nn.Module):
             if dropout_masks is None:
                 return torch.nn.functional.dropout(t, 0.5, training=True)
             return t * dropout_masks[i].to(t.dtype)
+
+        def join(out, skip):       # the up block's input: cat, and in the fused form its ReLU as well
+            if self.fused and out.is_cuda and out.dtype == skip.dtype and out.dtype in (torch.float32, torch.bfloat16):
+                return gops.act_concat(out, skip, 0.0)
+            cat = torch.cat((out, skip), dim=1)
+            return torch.relu(cat) if self.fused else cat
 
         x1 = self.downsample_1(x)
         x2 = self.downsample_2(x1)
@@ -97,13 +128,13 @@ class Generator(torch.nn.Module):
         x7 = self.downsample_7(x6)
         x8 = self.downsample_8(x7)
         out = drop(self.upsample_1(x8), 0)
-        out = drop(self.upsample_2(torch.cat((out, x7), dim=1)), 1)
-        out = drop(self.upsample_3(torch.cat((out, x6), dim=1)), 2)
-        out = self.upsample_4(torch.cat((out, x5), dim=1))
-        out = self.upsample_5(torch.cat((out, x4), dim=1))
-        out = self.upsample_6(torch.cat((out, x3), dim=1))
-        out = self.upsample_7(torch.cat((out, x2), dim=1))
-        return self.upsample_8(torch.cat((out, x1), dim=1))      # tanh in the transposed convolution's epilogue
+        out = drop(self.upsample_2(join(out, x7)), 1)
+        out = drop(self.upsample_3(join(out, x6)), 2)
+        out = self.upsample_4(join(out, x5))
+        out = self.upsample_5(join(out, x4))
+        out = self.upsample_6(join(out, x3))
+        out = self.upsample_7(join(out, x2))
+        return self.upsample_8(join(out, x1))      # tanh in the transposed convolution's epilogue
 
 
 class ResNetBlock(torch.nn.Module):

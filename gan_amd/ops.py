@@ -1615,6 +1615,64 @@ torch.library.register_autograd("ganconv::rowdot", _rowdot_backward,
                                 setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1]))
 
 
+# ---- channel concatenation fused with the activation behind it (U-Net skip connections, Pix2Pix/models.py:128-145) ----
+@torch.library.custom_op("ganconv::act_concat", mutates_args=())
+def act_concat(a: Tensor, b: Tensor, negative_slope: float) -> Tensor:
+    """leaky_relu(torch.cat((a, b), dim=1), negative_slope) as one launch (0 = ReLU, 1 = plain concatenation); a and b
+    of one dtype (fp32 / bf16) and one N, H, W, channels multiples of 4 / 8."""
+    _check_cuda(a, b)
+    if a.dtype != b.dtype or a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+        raise RuntimeError("ganconv: act_concat expects two tensors of one dtype, batch and image size")
+    N, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    a, b = _nhwc(a), _nhwc(b)
+    y = torch.empty((N, Ca + Cb, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_act_concat_fwd(_ptr(a), _ptr(b), _ptr(y), N * H * W, Ca, Cb, _dtype_code(a), float(negative_slope), _stream()),
+               "gc_act_concat_fwd")
+    return y
+
+
+@act_concat.register_fake
+def _(a, b, negative_slope):
+    return a.new_empty((a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3]), memory_format=torch.channels_last)
+
+
+@torch.library.custom_op("ganconv::act_concat_backward", mutates_args=())
+def act_concat_backward(g: Tensor, y: Tensor, ca: int, negative_slope: float) -> tuple[Tensor, Tensor]:
+    """The two input gradients of act_concat from the output gradient g and the forward output y (first-order only)."""
+    _check_cuda(g, y)
+    N, C, H, W = y.shape
+    if g.shape != y.shape:
+        raise RuntimeError("ganconv: act_concat_backward expects a gradient of the output's shape")
+    y = _nhwc(y)
+    g = _nhwc(g.to(y.dtype))
+    ga = torch.empty((N, ca, H, W), dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
+    gb = torch.empty((N, C - ca, H, W), dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_act_concat_bwd(_ptr(g), _ptr(y), _ptr(ga), _ptr(gb), N * H * W, ca, C - ca, _dtype_code(y), float(negative_slope),
+                                            _stream()), "gc_act_concat_bwd")
+    return ga, gb
+
+
+@act_concat_backward.register_fake
+def _(g, y, ca, negative_slope):
+    N, C, H, W = y.shape
+    return (y.new_empty((N, ca, H, W), memory_format=torch.channels_last), y.new_empty((N, C - ca, H, W), memory_format=torch.channels_last))
+
+
+def _act_concat_setup(ctx, inputs, output):
+    ctx.ca, ctx.slope = inputs[0].shape[1], inputs[2]
+    ctx.save_for_backward(output)
+
+
+def _act_concat_backward(ctx, g):
+    (y,) = ctx.saved_tensors
+    ga, gb = act_concat_backward(g, y, ctx.ca, ctx.slope)
+    return ga, gb, None
+
+
+torch.library.register_autograd("ganconv::act_concat", _act_concat_backward, setup_context=_act_concat_setup)
+
+
 # ---- reflection padding (Pix2Pix/models.py:162,185,204,210) and its adjoint, each other's gradient ---------------
 def _reflect(fn_name, x, pad, H, W, shape):
     _check_cuda(x)

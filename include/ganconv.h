@@ -320,6 +320,16 @@ int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32_t H, int32
 int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream);
 int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream);
 
+/* Channel concatenation of two NHWC tensors of one gc_dtype fused with the (Leaky)ReLU behind it, and its adjoint:
+ *   gc_act_concat_fwd   y[p, 0..Ca) = act(a[p, :]), y[p, Ca..Ca+Cb) = act(b[p, :]),  act(v) = v > 0 ? v : slope * v
+ *   gc_act_concat_bwd   ga = g[p, 0..Ca) * m, gb = g[p, Ca..Ca+Cb) * m,              m = y > 0 ? 1 : slope   (y: the forward output)
+ * P = N * H * W pixels; Ca, Cb multiples of 4 (fp32) / 8 (bf16); 16-byte aligned pointers; slope = 0 is ReLU, 1 a plain
+ * concatenation / split.  Replace torch.cat + ReLU (and threshold_backward + the two slices of cat's backward) on the
+ * skip connections of the U-Net, Pix2Pix/models.py:128-145 with the up block's ReLU of models.py:30-32. */
+int gc_act_concat_fwd(const void* a, const void* b, void* y, int64_t P, int32_t Ca, int32_t Cb, int32_t dtype, float slope, void* stream);
+int gc_act_concat_bwd(const void* g, const void* y, void* ga, void* gb, int64_t P, int32_t Ca, int32_t Cb, int32_t dtype, float slope,
+                      void* stream);
+
 /* EXTENSION (no counterpart in the reference, whose StyleGAN is version 1 with AdaIN: StyleGAN/model.py:179-261): the two
  * memory-bound halves of a StyleGAN2-style modulated convolution written without per-sample weights,
  *   y[n, o] = d[n, o] * conv(x[n, i] * s[n, i], w)[o],  d[n, o] = rsqrt(sum_i s[n, i]^2 * sum_k w[o, i, k]^2 + eps),

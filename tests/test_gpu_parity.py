@@ -1052,6 +1052,40 @@ def test_hip_graph_replay_matches_eager_cycles(gan, with_reducer, overlap, fused
     assert not torch.allclose(ref[2], ref[4], rtol=1e-3)      # the losses do change from cycle to cycle
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("slope", [0.0, 0.2, 1.0])
+@pytest.mark.parametrize("shape", [(2, 8, 24, 5, 7), (1, 512, 512, 1, 1), (3, 64, 128, 16, 16), (0, 8, 8, 4, 4), (2, 128, 64, 33, 9)])
+def test_act_concat_is_cat_plus_leaky_relu_bit_for_bit(gan, shape, slope, dt):
+    """ops.act_concat and its gradients against torch.cat + leaky_relu on the same storage type (Pix2Pix/models.py:128-145
+    with the ReLU of models.py:30-32): an elementwise selection and one rounding, so the results are equal bit for bit
+    (as numbers: a negative value times slope 0 is -0 here)."""
+    N, Ca, Cb, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    cl = torch.channels_last
+    a = torch.randn(N, Ca, H, W, generator=g).cuda().to(dt).contiguous(memory_format=cl).requires_grad_(True)
+    b = torch.randn(N, Cb, H, W, generator=g).cuda().to(dt).contiguous(memory_format=cl).requires_grad_(True)
+    go = torch.randn(N, Ca + Cb, H, W, generator=g).cuda().to(dt).contiguous(memory_format=cl)
+    y = gan.ops.act_concat(a, b, slope)
+    ga, gb = torch.autograd.grad(y, (a, b), go)
+    ar, br = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(torch.cat((ar, br), dim=1), slope)
+    gar, gbr = torch.autograd.grad(yr, (ar, br), go)
+    assert y.shape == yr.shape and y.dtype == dt and y.is_contiguous(memory_format=cl)
+    assert torch.equal(y, yr)
+    assert torch.equal(ga, gar) and torch.equal(gb, gbr)
+    assert ga.shape == a.shape and gb.shape == b.shape
+
+
+def test_act_concat_rejects_what_it_cannot_run(gan):
+    a = torch.zeros(1, 8, 4, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        gan.ops.act_concat(a, torch.zeros(1, 8, 4, 5, device="cuda"), 0.0)          # other image size
+    with pytest.raises(RuntimeError):
+        gan.ops.act_concat(a, torch.zeros(1, 6, 4, 4, device="cuda"), 0.0)          # channels not a multiple of 4
+    with pytest.raises(RuntimeError):
+        gan.ops.act_concat(a, a.to(torch.bfloat16), 0.0)                            # two dtypes
+
+
 def test_generator_phase_adds_the_critics_weight_gradients_like_the_reference(gan):
     """The reference's generator phase leaves the critic trainable (BasicGANs/loss_functions.py:31-36): the critic's
     .grad ends the cycle as (last critic iteration) + (generator phase) and is thrown away by the next zero_grad
