@@ -73,9 +73,13 @@ class Conv2d(gnn.Conv2d):
         self.n_iterations, self.norm = n_iterations, norm
         self.register_buffer("U_vector", torch.rand(1, output_channels))
 
-    def forward(self, x, activation=None, out_dtype=None):
+    def forward(self, x, activation=None, out_dtype=None, upsample=False):
+        """upsample: the input is replicated x2 first (BigGAN/model.py:117-119), folded into the 3x3 weight."""
+        out_dtype = out_dtype if out_dtype is not None else _opt["dtype"]
+        if upsample:
+            return GF.upsample2x_conv3x3(x, self.weight / _sigma(self), self.bias, activation=activation, out_dtype=out_dtype)
         return GF.conv2d(x, self.weight / _sigma(self), self.bias, self.stride, self.padding, self.dilation, self.groups,
-                         activation=activation, out_dtype=out_dtype if out_dtype is not None else _opt["dtype"])
+                         activation=activation, out_dtype=out_dtype)
 
 
 class Linear(torch.nn.Linear):
@@ -138,7 +142,7 @@ class SelfAttentionBlock(torch.nn.Module):
 
 
 class GeneratorBlock(torch.nn.Module):
-    """norm-relu-upsample-conv3x3-norm-relu-conv3x3 plus a 1x1 shortcut on the up-scaled input."""
+    """norm-relu-upsample-conv3x3-norm-relu-conv3x3 plus a 1x1 shortcut on the up-scaled input (BigGAN/model.py:100-133)."""
 
     def __init__(self, cin, cout, y_dim=148):
         super().__init__()
@@ -149,9 +153,10 @@ class GeneratorBlock(torch.nn.Module):
         self.residual_conv = Conv2d(cin, cout, 1)
 
     def forward(self, x, y):
-        h = self.conv_1(GF.upsample_nearest2x(self.batch_norm_1(x, y)))
+        h = self.conv_1(self.batch_norm_1(x, y), upsample=True)
         h = self.conv_2(self.batch_norm_2(h, y))
-        return h + self.residual_conv(GF.upsample_nearest2x(x))
+        # (a 1x1 convolution commutes with the replication: it runs on the small image)
+        return h + GF.upsample_nearest2x(self.residual_conv(x))
 
 
 class DiscriminatorBlock(torch.nn.Module):

@@ -80,7 +80,10 @@ class _EqConvCore(gnn.Conv2d):
     def effective_weight(self):          # what the reference's forward pre-hook would store in `.weight`
         return self.weight_orig * self.scale
 
-    def forward(self, x, out_dtype=None):
+    def forward(self, x, out_dtype=None, upsample=False):
+        if upsample:      # nearest x2 in front of the 3x3 convolution (StyleGAN/model.py:236-238), folded into the weight
+            return GF.upsample2x_conv3x3(x, self.weight_orig, self.bias, activation=self.activation, negative_slope=self.negative_slope,
+                                         out_dtype=out_dtype, weight_scale=self.scale)
         return GF.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, _wkey=self._wkey_for(self.weight_orig),
                          activation=self.activation, negative_slope=self.negative_slope, out_dtype=out_dtype, weight_scale=self.scale)
 
@@ -95,8 +98,8 @@ class EqualizedConv2d(torch.nn.Module):
             self.conv2d.activation, self.conv2d.negative_slope = "leaky_relu", LRELU
         self.keep_fp32 = keep_fp32
 
-    def forward(self, x, out_dtype=None):
-        return self.conv2d(x, torch.float32 if self.keep_fp32 else (out_dtype or _store["dtype"]))
+    def forward(self, x, out_dtype=None, upsample=False):
+        return self.conv2d(x, torch.float32 if self.keep_fp32 else (out_dtype or _store["dtype"]), upsample)
 
 
 class _EqLinearCore(torch.nn.Linear):
@@ -239,7 +242,11 @@ class SynthesisBlock(torch.nn.Module):
             h = self.convolution_1(style_vector.shape[0])
         else:
             h = x
-            for stage in _children(self.convolution_1):
+            stages = _children(self.convolution_1)
+            if self.kind != "transposed":          # (replication, 3x3 convolution, blur): the first two as one launch
+                h = stages[1](h, upsample=True)
+                stages = stages[2:]
+            for stage in stages:
                 h = stage(h)
         if noise is None:
             noise = torch.randn(h.shape[0], 1, h.shape[2], h.shape[3], device=h.device)
