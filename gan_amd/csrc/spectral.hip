@@ -1,0 +1,161 @@
+// Spectral norm of a weight matrix by power iteration (BigGAN/model.py:20-35, p = 2):
+//     v = normalize(u W),   u' = normalize(v W^T),   sigma = u' W v^T
+// for W [rows][cols] in row-major fp32 (a convolution weight flattened to [out, rest]) and the stored left vector u [rows],
+// which is advanced in place.  With s = W v^T the last two are u' = s / max(|s|, eps) and sigma = |s|^2 / max(|s|, eps).
+// HBM-bound: W is read twice per iteration, with 16-byte loads where the row length allows; every sum runs in a fixed
+// order (partial sums per row range, added in order), so the result does not depend on timing.
+//   sn_cols_kernel       part[split][col] = sum over the split's rows of u[row] * W[row][col]
+//   sn_cols_finish       t = sum of the parts, scal[0] = 1 / max(|t|, eps)                       (one workgroup)
+//   sn_rows_kernel       s[row] = scal[0] * <W[row], t>                                          (one wave per row)
+//   sn_rows_finish       u = s / max(|s|, eps), sigma = |s|^2 / max(|s|, eps)                    (one workgroup)
+#include "common.h"
+
+namespace gc {
+namespace {
+
+constexpr float kNormEps = 1e-12f;      // torch.nn.functional.normalize's default
+constexpr int kMaxSplits = 64;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // red: kThreads / 64 floats of LDS; all threads get the sum
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) s += red[w];
+  return s;
+}
+
+// grid (column blocks, splits); a thread owns VEC consecutive columns
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sn_cols_kernel(const float* w, const float* u, float* part, int rows, long cols, int rows_per_split) {
+  const long c0 = ((long)blockIdx.x * kThreads + threadIdx.x) * VEC;
+  if (c0 >= cols) return;
+  const int r0 = blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; i++) acc[i] = 0.f;
+  for (int r = r0; r < r1; r++) {
+    const float ur = u[r];
+    const float* src = w + (size_t)r * cols + c0;
+    if (VEC == 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] += ur * v[i];
+    } else {
+      acc[0] += ur * src[0];
+    }
+  }
+  float* dst = part + (size_t)blockIdx.y * cols + c0;
+#pragma unroll
+  for (int i = 0; i < VEC; i++) dst[i] = acc[i];
+}
+
+__global__ __launch_bounds__(kThreads) void sn_cols_finish(const float* part, float* t, float* scal, long cols, int splits) {
+  __shared__ float red[kThreads / 64];
+  float sq = 0.f;
+  for (long c = threadIdx.x; c < cols; c += kThreads) {
+    float s = 0.f;
+    for (int k = 0; k < splits; k++) s += part[(size_t)k * cols + c];
+    t[c] = s;
+    sq += s * s;
+  }
+  sq = block_sum(sq, red);
+  if (threadIdx.x == 0) scal[0] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+}
+
+// one wave per row
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sn_rows_kernel(const float* w, const float* t, const float* scal, float* s, int rows, long cols) {
+  const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* src = w + (size_t)row * cols;
+  float acc = 0.f;
+  if (VEC == 4) {
+    for (long c = lane * 4; c < cols; c += 64 * 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + c), b = *reinterpret_cast<const f32x4*>(t + c);
+      acc += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+    }
+  } else {
+    for (long c = lane; c < cols; c += 64) acc += src[c] * t[c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) s[row] = acc * scal[0];
+}
+
+__global__ __launch_bounds__(kThreads) void sn_rows_finish(const float* s, float* u, float* sigma, int rows) {
+  __shared__ float red[kThreads / 64];
+  float sq = 0.f;
+  for (int r = threadIdx.x; r < rows; r += kThreads) sq += s[r] * s[r];
+  sq = block_sum(sq, red);
+  const float inv = 1.f / fmaxf(sqrtf(sq), kNormEps);
+  for (int r = threadIdx.x; r < rows; r += kThreads) u[r] = s[r] * inv;
+  if (threadIdx.x == 0) sigma[0] = sq * inv;
+}
+
+int splits_for(int rows, long cols, int vec) {
+  const long col_blocks = (cols + (long)kThreads * vec - 1) / ((long)kThreads * vec);
+  long want = (1024 + col_blocks - 1) / col_blocks;          // about four workgroups per CU
+  if (want > rows / 8) want = rows / 8;                      // at least eight rows per split
+  if (want > kMaxSplits) want = kMaxSplits;
+  return want < 1 ? 1 : (int)want;
+}
+
+}  // namespace
+}  // namespace gc
+
+using namespace gc;
+
+extern "C" {
+
+size_t gc_spectral_norm_workspace_bytes(int32_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  // parts [splits][cols], t [cols], s [rows], one scalar; each piece 16-byte aligned
+  const size_t c4 = ((size_t)cols + 3) / 4 * 4, r4 = ((size_t)rows + 3) / 4 * 4;
+  return ((size_t)kMaxSplits * c4 + c4 + r4 + 4) * sizeof(float);
+}
+
+int gc_spectral_norm_power_iteration(const float* w, int32_t rows, int64_t cols, float* u, float* sigma, int32_t n_iterations,
+                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (w == nullptr || u == nullptr || sigma == nullptr || rows <= 0 || cols <= 0 || n_iterations < 1) {
+    set_error("gc_spectral_norm_power_iteration: null pointer, empty matrix or no iteration");
+    return GC_BAD_ARGUMENT;
+  }
+  if (workspace == nullptr || workspace_bytes < gc_spectral_norm_workspace_bytes(rows, cols) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) {
+    set_error("gc_spectral_norm_power_iteration: workspace missing, too small (gc_spectral_norm_workspace_bytes) or not 16-byte aligned");
+    return GC_BAD_ARGUMENT;
+  }
+  const bool vec = cols % 4 == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0;
+  const size_t c4 = ((size_t)cols + 3) / 4 * 4, r4 = ((size_t)rows + 3) / 4 * 4;
+  float* part = static_cast<float*>(workspace);
+  float* t = part + (size_t)kMaxSplits * c4;
+  float* s = t + c4;
+  float* scal = s + r4;
+  const int v = vec ? 4 : 1;
+  const int splits = splits_for(rows, cols, v);
+  const int rows_per_split = (rows + splits - 1) / splits;
+  const dim3 grid_c((unsigned)((cols + (long)kThreads * v - 1) / ((long)kThreads * v)), (unsigned)splits);
+  const unsigned grid_r = (unsigned)((rows + kThreads / 64 - 1) / (kThreads / 64));
+  for (int it = 0; it < n_iterations; it++) {
+    {
+      ProfScope ps("gc::sn_cols_kernel", 0.0, stream);
+      if (vec) hipLaunchKernelGGL(sn_cols_kernel<4>, grid_c, dim3(kThreads), 0, stream, w, u, part, rows, (long)cols, rows_per_split);
+      else hipLaunchKernelGGL(sn_cols_kernel<1>, grid_c, dim3(kThreads), 0, stream, w, u, part, rows, (long)cols, rows_per_split);
+    }
+    hipLaunchKernelGGL(sn_cols_finish, dim3(1), dim3(kThreads), 0, stream, part, t, scal, (long)cols, splits);
+    {
+      ProfScope ps("gc::sn_rows_kernel", 0.0, stream);
+      if (vec) hipLaunchKernelGGL(sn_rows_kernel<4>, dim3(grid_r), dim3(kThreads), 0, stream, w, t, scal, s, rows, (long)cols);
+      else hipLaunchKernelGGL(sn_rows_kernel<1>, dim3(grid_r), dim3(kThreads), 0, stream, w, t, scal, s, rows, (long)cols);
+    }
+    hipLaunchKernelGGL(sn_rows_finish, dim3(1), dim3(kThreads), 0, stream, s, u, sigma, rows);
+  }
+  return check_hip(hipGetLastError(), "spectral norm launch");
+}
+
+}  // extern "C"

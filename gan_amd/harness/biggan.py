@@ -11,8 +11,9 @@ class embedding with the [B, 1] score (:233).
 
 What runs where: every convolution (3x3, 1x1, the attention projections) on the gan_amd convolution kernels; conditional
 BatchNorm + ReLU on the fused normalisation kernels; 2x2 average pooling and nearest x2 up-scaling on the resampling
-kernels; the ReLU between a discriminator block's two convolutions in the first one's epilogue; the power iteration, the
-spectrally normalised Linear layers, the embeddings and (by default) the attention product on torch ops.  A
+kernels; the ReLU between a discriminator block's two convolutions in the first one's epilogue; the power iteration of the
+spectral norm and the orthogonal regularisation on library kernels (ops.spectral_sigma_, ops.orthogonal_regularization_);
+the spectrally normalised Linear layers, the embeddings and (by default) the attention product on torch ops.  A
 discriminator block's 1x1 shortcut runs behind the pooling instead of in front of it (both are linear: same result, a
 quarter of the pixels).
 
@@ -53,6 +54,8 @@ def set_fused_norm(on):
 def _sigma(layer):
     """Largest singular value of layer.weight (as a [out, rest] matrix) by power iteration from the stored left vector
     U_vector [1, out], which is advanced in place.  No gradient flows through it."""
+    if layer.weight.is_cuda and layer.norm == 2 and layer.weight.dtype == torch.float32:
+        return ops.spectral_sigma_(layer.weight, layer.U_vector, layer.n_iterations)       # four launches per iteration
     with torch.no_grad():
         w = layer.weight.flatten(1)
         for _ in range(layer.n_iterations):
@@ -242,12 +245,15 @@ def orthogonal_init(model):
 def orthogonal_regularization(model, beta=1e-4):
     """BigGAN/train.py:115-127: grad += beta * 2 (W W^T with its diagonal removed) W for every weight with more than two
     dimensions, W flattened to [out, rest]."""
-    for p in model.parameters():
-        if p.dim() > 2 and p.grad is not None:
-            w = p.flatten(1)
-            gram = w @ w.t()
-            gram.fill_diagonal_(0.0)
-            p.grad.add_((gram @ w).view_as(p), alpha=2.0 * beta)
+    params = [p for p in model.parameters() if p.dim() > 2 and p.grad is not None]
+    if params and params[0].is_cuda:
+        ops.orthogonal_regularization_(params, beta)       # both products on the convolution kernels
+        return
+    for p in params:
+        w = p.flatten(1)
+        gram = w @ w.t()
+        gram.fill_diagonal_(0.0)
+        p.grad.add_((gram @ w).view_as(p), alpha=2.0 * beta)
 
 
 def discriminator_phase(net_G, net_D, real, real_label, z, fake_label, orth_reg=True, on_last_backward=None):

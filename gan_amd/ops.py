@@ -1831,6 +1831,52 @@ def _(real, fake, eps):
     return torch.empty_like(real, dtype=torch.float32)
 
 
+@torch.no_grad()
+def spectral_sigma_(weight, u, n_iterations=1):
+    """SpectralNorm._power_iterations (BigGAN/model.py:27-35, p = 2) on the library's kernels: advances the left vector
+    `u` ([1, out] or [out], fp32) in place and returns sigma as a 0-dim tensor.  `weight`: any fp32 parameter with `out`
+    as its first dimension (read as [out, rest]).  No gradient flows through it, as in the reference."""
+    _check_cuda(weight)
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    rows = w.shape[0]
+    cols = w.numel() // rows
+    if u.dtype != torch.float32 or u.numel() != rows or not u.is_contiguous():
+        raise RuntimeError(f"ganconv: the left vector must be contiguous fp32 with {rows} elements, got {tuple(u.shape)} {u.dtype}")
+    L = _lib.lib()
+    ws = torch.empty(L.gc_spectral_norm_workspace_bytes(rows, cols) // 4, dtype=torch.float32, device=w.device)
+    sigma = torch.empty((), dtype=torch.float32, device=w.device)
+    _lib.check(L.gc_spectral_norm_power_iteration(ctypes.c_void_p(w.data_ptr()), rows, cols, ctypes.c_void_p(u.data_ptr()),
+                                                  ctypes.c_void_p(sigma.data_ptr()), int(n_iterations), ctypes.c_void_p(ws.data_ptr()),
+                                                  ws.numel() * 4, _stream()), "gc_spectral_norm_power_iteration")
+    return sigma
+
+
+@torch.no_grad()
+def orthogonal_regularization_(parameters, beta=1e-4, precision="fp32x3"):
+    """BigGAN/train.py:115-127: grad += 2 beta (W W^T with its diagonal removed) W for every parameter with more than two
+    dimensions that has a gradient, W = the parameter flattened to [out, rest].  Both products run on the convolution
+    kernels: W in memory IS a one-sample NHWC image of `out` pixels x `rest` channels, so W W^T is a 1x1 convolution of that
+    image with W as the filter bank, and (W W^T) W is the data gradient of the same 1x1 convolution for the Gram matrix as the
+    output gradient -- no transposed copy of W.  `precision`: "fp32x3" (split fp32 operands, fp32-like accuracy; default, the
+    reference computes this in fp32) or "bf16"."""
+    prec = _PRECISION[precision]
+    f32 = _code_of(torch.float32)
+    for p in parameters:
+        if p.dim() <= 2 or p.grad is None:
+            continue
+        rows = p.shape[0]
+        w2 = p.detach().reshape(rows, -1).float()
+        K = w2.shape[1]
+        image = w2.reshape(1, rows, 1, K).permute(0, 3, 1, 2)            # [1, K, rows, 1] over W's own memory
+        bank = w2.reshape(rows, K, 1, 1)
+        gram = conv_fprop(image, bank, None, 1, 0, prec, 0, 0, 0.0, f32)     # [1, rows, rows, 1]: (0, j, i, 0) = <w_i, w_j>
+        gram.permute(0, 2, 3, 1).reshape(rows, rows).fill_diagonal_(0.0)
+        r = conv_dgrad(gram, bank, None, rows, 1, 1, 0, prec, 0, 0, 0.0, f32)     # [1, K, rows, 1]: (0, k, i, 0) = sum_j gram[i, j] W[j, k]
+        p.grad.add_(r.permute(0, 2, 3, 1).reshape(p.shape).to(p.grad.dtype), alpha=2.0 * beta)
+
+
 @torch.library.custom_op("ganconv::gradient_penalty", mutates_args=())
 def gradient_penalty(gradient: Tensor, c_lambda: float) -> tuple[Tensor, Tensor, Tensor]:
     """(c_lambda * mean_n (||gradient_n||_2 - 1)^2 as a 0-dim tensor, the per-sample norms, the per-sample factor of

@@ -374,6 +374,15 @@ int gc_gradient_penalty_bwd(const void* gradient, int32_t dtype, int32_t N, int6
                             void* out, void* stream);
 int gc_wgan_critic_loss(const float* scores, int32_t B, float drift, float* out, float* grad, void* stream);
 
+/* Spectral norm of a weight by power iteration, as SpectralNorm._power_iterations computes it (BigGAN/model.py:27-35,
+ * p = 2): per iteration v = normalize(u W), u' = normalize(v W^T), sigma = u' W v^T, for W [rows][cols] row-major fp32 (a
+ * convolution or Linear weight flattened to [out, rest]) and the stored left vector u [rows] (U_vector), which is
+ * advanced in place; sigma [1] receives the last iteration's value.  normalize() divides by max(norm, 1e-12) as
+ * torch.nn.functional.normalize does.  Fixed summation order.  workspace: gc_spectral_norm_workspace_bytes, 16-byte aligned. */
+size_t gc_spectral_norm_workspace_bytes(int32_t rows, int64_t cols);
+int gc_spectral_norm_power_iteration(const float* w, int32_t rows, int64_t cols, float* u, float* sigma, int32_t n_iterations,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Self-attention over image positions without the [N, N] weight matrix in memory: out = softmax(k q^T) v per sample,
  * softmax over the last index, unit scale.  Replaces the bmm + Softmax + bmm of SelfAttentionBlock.forward
  * (BigGAN/model.py:97-103; the reference calls the [B, N, C / 8] operand of the first bmm "key" and the other
