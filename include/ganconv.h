@@ -374,6 +374,25 @@ int gc_gradient_penalty_bwd(const void* gradient, int32_t dtype, int32_t N, int6
                             void* out, void* stream);
 int gc_wgan_critic_loss(const float* scores, int32_t B, float drift, float* out, float* grad, void* stream);
 
+/* Input side of the step: a batch of decoded 8-bit images (interleaved channels, rows `src_stride` bytes apart, in
+ * device memory) to the float batch the networks take.  Per sample, in the order of the reference's datasets
+ * (BasicGANs/utils.py:46-55; Pix2Pix/dataset.py:225-318; StyleGAN/train.py:30-38): cv2.resize to resize_w x resize_h
+ * (interp 1: INTER_LINEAR with OpenCV's 8-bit fixed-point arithmetic, 0: INTER_NEAREST, the label masks), the window
+ * [crop_y, crop_y + out_h) x [crop_x, crop_x + out_w) of the resized image (random jitter), cv2.flip(., 1) of that window
+ * when `flip`, value / divisor (255 for images, 1 for label masks), (value - mean[c]) / std[c] (host arrays of `channels`
+ * floats, or null: 0 / 1), stored at out + n * s[0] + c * s[1] + y * s[2] + x * s[3] (elements; any layout).  `jobs`: n
+ * records in DEVICE memory.  Channels stay in the file's order (cv2: BGR), as in the reference.  out_dtype: GC_F32 / GC_BF16. */
+typedef struct {
+  const void* src;                     /* first byte of the image */
+  int32_t src_h, src_w, src_stride;    /* rows, columns, bytes per row */
+  int32_t resize_h, resize_w;          /* size after cv2.resize */
+  int32_t crop_y, crop_x;              /* window of the resized image that becomes the output */
+  int32_t flip;                        /* 1: mirror the window left-right */
+} gc_image_job;
+int gc_image_batch_prepare(const gc_image_job* jobs, int32_t n, int32_t channels, int32_t out_h, int32_t out_w, int32_t interp,
+                           float divisor, const float* mean, const float* std_, void* out, int32_t out_dtype,
+                           const int64_t out_strides[4], void* stream);
+
 /* Spectral norm of a weight by power iteration, as SpectralNorm._power_iterations computes it (BigGAN/model.py:27-35,
  * p = 2): per iteration v = normalize(u W), u' = normalize(v W^T), sigma = u' W v^T, for W [rows][cols] row-major fp32 (a
  * convolution or Linear weight flattened to [out, rest]) and the stored left vector u [rows] (U_vector), which is

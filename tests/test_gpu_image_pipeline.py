@@ -1,0 +1,77 @@
+"""gc_image_batch_prepare (gan_amd.data.ImageBatcher) against the CPU restatement of the reference's per-sample pipeline
+(oracle/ref_image_pipeline.py): 8-bit resize values and the float steps must agree bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gan():
+    import gan_amd
+    return gan_amd
+
+
+def _images(rng, n, channels, sizes):
+    return [rng.randint(0, 256, (h, w, channels)).astype(np.uint8) for (h, w) in (sizes * n)[:n]]
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_dcgan_pipeline(gan, channels_last):
+    """BasicGANs/utils.py:46-55 + train.py:56-57: resize to 64 x 64, / 255, Normalize(0.5, 0.5)."""
+    from oracle import ref_image_pipeline as R
+    rng = np.random.RandomState(61)
+    images = _images(rng, 7, 3, [(178, 218), (64, 64), (31, 47), (300, 200), (65, 63), (128, 128), (1, 1)])
+    b = gan.data.ImageBatcher((64, 64), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), channels_last=channels_last)
+    out = b(images)
+    assert out.shape == (7, 3, 64, 64) and out.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    for i, im in enumerate(images):
+        want = R.prepare(im, (64, 64), (0, 0), (64, 64), False, mean=(0.5,) * 3, std=(0.5,) * 3)
+        assert np.array_equal(out[i].cpu().numpy(), want), i
+
+
+def test_pix2pix_pipeline_with_jitter_flip_and_label_masks(gan):
+    """Pix2Pix/dataset.py:262-318: resize to int(256 * 1.1171875) = 286, random 256 x 256 window, flip; the label mask takes
+    the same window with nearest resize and raw values."""
+    from oracle import ref_image_pipeline as R
+    rng = np.random.RandomState(62)
+    images = _images(rng, 4, 3, [(256, 256), (512, 384), (200, 333), (286, 286)])
+    masks = [rng.randint(0, 30, im.shape).astype(np.uint8) for im in images]
+    b = gan.data.ImageBatcher((256, 256), mean=(0.5,) * 3, std=(0.5,) * 3, jitter=1.1171875, flip=True)
+    m = gan.data.ImageBatcher((256, 256), jitter=1.1171875, flip=True, linear=False, divisor=1.0)
+    plans = b.plan([im.shape for im in images], np.random.RandomState(5))
+    assert all(p[0] == 286 and p[1] == 286 and 0 <= p[2] < 30 and 0 <= p[3] < 30 for p in plans) and {p[4] for p in plans} <= {0, 1}
+    plans[0] = plans[0][:4] + (1,)
+    plans[1] = plans[1][:4] + (0,)
+    out, mout = b(images, plans), m(masks, plans)
+    for i, (im, mk, (rh, rw, y, x, flip)) in enumerate(zip(images, masks, plans)):
+        want = R.prepare(im, (rh, rw), (y, x), (256, 256), bool(flip), mean=(0.5,) * 3, std=(0.5,) * 3)
+        assert np.array_equal(out[i].cpu().numpy(), want), i
+        want_mask = R.prepare(mk, (rh, rw), (y, x), (256, 256), bool(flip), linear=False, divisor=1.0)
+        assert np.array_equal(mout[i].cpu().numpy(), want_mask), i
+
+
+def test_progressive_sizes_and_bf16_storage(gan):
+    """StyleGAN/train.py:33, 45-50: the same files at 4, 8, ... pixels; one-channel images; bf16 storage rounds once."""
+    from oracle import ref_image_pipeline as R
+    rng = np.random.RandomState(63)
+    images = _images(rng, 3, 1, [(28, 28), (97, 40), (128, 128)])
+    for size in (4, 8, 32, 128):
+        out = gan.data.ImageBatcher((size, size), mean=(0.5,), std=(0.5,))(images)
+        half = gan.data.ImageBatcher((size, size), mean=(0.5,), std=(0.5,), dtype=torch.bfloat16)(images)
+        for i, im in enumerate(images):
+            want = torch.from_numpy(R.prepare(im, (size, size), (0, 0), (size, size), False, mean=(0.5,), std=(0.5,)))
+            assert torch.equal(out[i].cpu(), want)
+            assert torch.equal(half[i].cpu(), want.to(torch.bfloat16))
+
+
+def test_batcher_rejects_what_it_cannot_do(gan):
+    b = gan.data.ImageBatcher((8, 8))
+    with pytest.raises(RuntimeError):
+        b([np.zeros((4, 4, 5), np.uint8)])
+    with pytest.raises(RuntimeError):
+        b([np.zeros((4, 4, 3), np.float32)])
+    with pytest.raises(RuntimeError):
+        b([np.zeros((4, 4, 3), np.uint8)], plans=[(8, 8, 1, 0, 0)])        # the window leaves the resized image
+    assert b([]).shape == (0, 3, 8, 8)
