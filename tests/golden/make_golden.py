@@ -417,9 +417,9 @@ def _sample(g, n=4096):
     return g if g.size <= 20000 else g.ravel()[::max(1, g.size // n)][:n].copy()
 
 
-def make_stylegan_trace(ref, out):
+def make_stylegan_trace(ref, out, pg=5, name="stylegan_trace"):
     """StyleGAN-v1 at progressive-growing step 5 (128x128, the first resolution with the fused up/down-sampling
-    blocks), batch 2: one critic phase with style mixing and gradient penalty, one generator phase, and a
+    blocks) or 6 (256x256, `stylegan256_trace`: the resolution the throughput figures are quoted at), batch 2: one critic phase with style mixing and gradient penalty, one generator phase, and a
     forward-only fade-in (alpha = 0.5) pass, on the reference's StyleGAN/model.py + BasicGANs/loss_functions.py.
     Weights are re-created from the seed by the tests (checksums here); every random draw made inside forward /
     the loss (noise images, crossover, epsilon) is recorded."""
@@ -427,7 +427,8 @@ def make_stylegan_trace(ref, out):
     models = load_by_path("ref_sg_models", os.path.join(ref, "StyleGAN/model.py"))
     losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
     seed_all()
-    B, pg = 2, 5
+    B, res = 2, 4 * 2 ** pg
+    lo, hi = res // 2 - 32, res // 2 + 32          # the recorded image window
     net_G = models.StyleBasedGenerator(fused=True)
     net_D = models.Discriminator(fused=True, use_activations=True)
     rec = {"param_count": {"G": sum(p.numel() for p in net_G.parameters()), "D": sum(p.numel() for p in net_D.parameters())},
@@ -435,7 +436,7 @@ def make_stylegan_trace(ref, out):
                              "D": checksum(torch.cat([p.flatten() for p in net_D.parameters()]))},
            "B": B, "pg_step": pg}
     gen = torch.Generator().manual_seed(SEED + 3)
-    real = torch.rand(B, 3, 128, 128, generator=gen) * 2 - 1
+    real = torch.rand(B, 3, res, res, generator=gen) * 2 - 1
     zs = torch.randn(4, B, 512, generator=gen)
     rec["input_checksum"] = {"real": checksum(real), "zs": checksum(zs)}
     blob = {}
@@ -484,15 +485,15 @@ def make_stylegan_trace(ref, out):
             img1 = net_G(zs[0], progressive_growing_phase=pg, alpha=1)
         for i, t in enumerate(drawn["randn"]):
             blob[f"fade.noise{i}"] = t.numpy()
-        blob["fade.image_crop"] = img[:, :, 32:96, 32:96].numpy()
+        blob["fade.image_crop"] = img[:, :, lo:hi, lo:hi].numpy()
         blob["fade.score"] = score.numpy()
-        blob["fade.image_alpha1_crop"] = img1[:, :, 32:96, 32:96].numpy()
+        blob["fade.image_alpha1_crop"] = img1[:, :, lo:hi, lo:hi].numpy()
     finally:
         torch.randn, torch.rand = o_randn, o_rand
         models.random.randint = o_randint
-    np.savez_compressed(os.path.join(out, "stylegan_trace.npz"), **blob)
-    json.dump(rec, open(os.path.join(out, "stylegan_trace.json"), "w"), indent=1)
-    print("stylegan_trace.npz:", len(blob), "arrays;", blob["critic.scalars"], blob["gen.scalars"], rec["param_count"], blob["critic.crossover"], blob["gen.crossover"])
+    np.savez_compressed(os.path.join(out, name + ".npz"), **blob)
+    json.dump(rec, open(os.path.join(out, name + ".json"), "w"), indent=1)
+    print(name + ".npz:", len(blob), "arrays;", blob["critic.scalars"], blob["gen.scalars"], rec["param_count"], blob["critic.crossover"], blob["gen.crossover"])
 
 
 def make_biggan_trace(ref, out):
@@ -646,7 +647,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "wide_ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "pix2pixhd_trace", "stylegan_trace", "biggan_trace"]
+    todo = a.only.split(",") if a.only else ["ops", "wide_ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "pix2pixhd_trace", "stylegan_trace", "stylegan256_trace", "biggan_trace"]
     if "ops" in todo: make_ops(a.out)
     if "wide_ops" in todo: make_wide_ops(a.out)
     if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
@@ -656,4 +657,5 @@ if __name__ == "__main__":
     if "pix2pix_trace" in todo: make_pix2pix_trace(a.ref, a.out)
     if "pix2pixhd_trace" in todo: make_pix2pixhd_trace(a.ref, a.out)
     if "stylegan_trace" in todo: make_stylegan_trace(a.ref, a.out)
+    if "stylegan256_trace" in todo: make_stylegan_trace(a.ref, a.out, pg=6, name="stylegan256_trace")
     if "biggan_trace" in todo: make_biggan_trace(a.ref, a.out)

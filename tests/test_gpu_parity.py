@@ -941,9 +941,11 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
 #  rounding of the summands leaves 0.2-0.3 of the small remainder, in either storage type)
 @pytest.mark.parametrize("prec,tol,coarse,bf16_storage", [("fp32x3", 5e-4, 5e-2, False), ("bf16", 5e-2, 4e-1, False), ("bf16", 5e-2, 4e-1, True)],
                          ids=["fp32x3", "bf16", "bf16_storage"])
-def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse, bf16_storage):
-    """StyleGAN-v1 at 128x128 (pg step 5, fused blocks, style mixing, minibatch stddev, 513-channel conv): critic phase
-    with gradient penalty, generator phase and a fade-in forward pass against the reference trace."""
+@pytest.mark.parametrize("fixture", ["stylegan_trace", "stylegan256_trace"], ids=["128x128_step5", "256x256_step6"])
+def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse, bf16_storage, fixture):
+    """StyleGAN-v1 at 128x128 (pg step 5) and at 256x256 (pg step 6, the resolution of the throughput figures): fused
+    blocks, style mixing, minibatch stddev, 513-channel conv; critic phase with gradient penalty, generator phase and a
+    fade-in forward pass against the reference traces."""
     from gan_amd.harness import stylegan as S
     from test_oracle_golden import check_grads, stylegan_setup
     gan.set_precision(prec)
@@ -951,7 +953,10 @@ def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coa
     S.set_activation_dtype(torch.bfloat16 if bf16_storage else None)
     try:
         z, rec, G, D, real, zs, noises = stylegan_setup(golden_dir, lambda: S.StyleBasedGenerator(fused=True),
-                                                        lambda: S.Discriminator(fused=True, use_activations=True))
+                                                        lambda: S.Discriminator(fused=True, use_activations=True), fixture)
+        lo, hi = 2 * 2 ** rec["pg_step"] - 32, 2 * 2 ** rec["pg_step"] + 32      # the recorded image window
+        if prec == "bf16" and rec["pg_step"] >= 6:
+            coarse *= 1.25      # four times the summands per cancelling sum (see above): 0.40 seen on one noise scaling factor
         G.cuda(); D.cuda()
         real, zs = real.cuda(), zs.cuda()
         noises = {k: [t.cuda() for t in v] for k, v in noises.items()}
@@ -959,7 +964,7 @@ def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coa
         with torch.no_grad():   # forward only first: smooth in the rounding error
             img = G(zs[0], progressive_growing_phase=pg, alpha=0.5, noises=noises["fade"])
             score = D(img, progressive_growing_phase=pg, alpha=0.5)
-        assert rel(img[:, :, 32:96, 32:96], z["fade.image_crop"]) < tol
+        assert rel(img[:, :, lo:hi, lo:hi], z["fade.image_crop"]) < tol
         assert rel(score, z["fade.score"]) < 20 * tol
         d_x, d_g, gp, _ = S.critic_phase(G, D, real, [zs[0], zs[1]], cu(z["critic.eps"]), pg, 1, 10.0, noises["critic"],
                                          int(z["critic.crossover"][0]))

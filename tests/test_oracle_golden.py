@@ -229,13 +229,14 @@ def test_full_size_pix2pix_parameter_counts():
         assert D(torch.zeros(1, 3, 256, 256), torch.zeros(1, 3, 256, 256)).shape == (1, 1, 30, 30)
 
 
-def stylegan_setup(golden_dir, make_G, make_D):
-    z = np.load(os.path.join(golden_dir, "stylegan_trace.npz"))
-    rec = json.load(open(os.path.join(golden_dir, "stylegan_trace.json")))
+def stylegan_setup(golden_dir, make_G, make_D, name="stylegan_trace"):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    rec = json.load(open(os.path.join(golden_dir, name + ".json")))
     torch.manual_seed(5000)
     G = make_G(); D = make_D()
     gen = torch.Generator().manual_seed(5003)
-    real = torch.rand(rec["B"], 3, 128, 128, generator=gen) * 2 - 1
+    res = 4 * 2 ** rec["pg_step"]
+    real = torch.rand(rec["B"], 3, res, res, generator=gen) * 2 - 1
     zs = torch.randn(4, rec["B"], 512, generator=gen)
     assert _checksum(real) == rec["input_checksum"]["real"] and _checksum(zs) == rec["input_checksum"]["zs"]
     noises = {ph: [torch.from_numpy(z[f"{ph}.noise{i}"]) for i in range(rec["pg_step"] + 1)] for ph in ("critic", "gen", "fade")}
@@ -268,10 +269,12 @@ def check_grads(named_params, z, prefix, tol, report=None):
     return n
 
 
-def test_restated_stylegan_matches_reference(golden_dir):
+@pytest.mark.parametrize("fixture", ["stylegan_trace", "stylegan256_trace"], ids=["128x128_step5", "256x256_step6"])
+def test_restated_stylegan_matches_reference(golden_dir, fixture):
     from oracle import ref_stylegan as S
     z, rec, G, D, real, zs, noises = stylegan_setup(golden_dir, lambda: S.StyleBasedGenerator(fused=True),
-                                                    lambda: S.Discriminator(fused=True, use_activations=True))
+                                                    lambda: S.Discriminator(fused=True, use_activations=True), fixture)
+    lo, hi = 2 * 2 ** rec["pg_step"] - 32, 2 * 2 ** rec["pg_step"] + 32          # the recorded image window
     assert sum(p.numel() for p in G.parameters()) == rec["param_count"]["G"] == 26219115
     assert sum(p.numel() for p in D.parameters()) == rec["param_count"]["D"] == 26054017
     assert _checksum(torch.cat([p.flatten() for p in G.parameters()])) == rec["init_checksum"]["G"]
@@ -287,7 +290,7 @@ def test_restated_stylegan_matches_reference(golden_dir):
     with torch.no_grad():
         img = G(zs[0], progressive_growing_phase=pg, alpha=0.5, noises=noises["fade"])
         score = D(img, progressive_growing_phase=pg, alpha=0.5)
-    assert rel_err(img[:, :, 32:96, 32:96].numpy(), z["fade.image_crop"]) < 1e-5
+    assert rel_err(img[:, :, lo:hi, lo:hi].numpy(), z["fade.image_crop"]) < 1e-5
     assert rel_err(score.numpy(), z["fade.score"]) < 1e-4
 
 
