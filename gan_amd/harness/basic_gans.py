@@ -234,18 +234,23 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
         with gops.weight_gradient_sink(params, bufs, defer=True, flush_streams=lanes, expected=len(rf_chains) + 2,
                                        early_streams=early) as sink:
             run_chains()
-        g_main = []
+        g_main, later = [], []      # later[k]: (sums, addends) of the parameters with more than k + 1 contributions
         for i, (p, b) in enumerate(zip(params, bufs)):
             rest = [r[0][i] for r in results if r[0][i] is not None]
             if p.data_ptr() in sink.touched:
                 g = b
             elif rest:
-                g = rest.pop(0).clone()
+                g = rest.pop(0)          # (autograd.grad's own result tensor: nobody else holds it)
             else:
                 raise RuntimeError("a critic parameter received no gradient")
-            for r in rest:
-                g.add_(r)
+            for k, r in enumerate(rest):
+                while len(later) <= k:
+                    later.append(([], []))
+                later[k][0].append(g)
+                later[k][1].append(r)
             g_main.append(g)
+        for sums, addends in later:      # the normalisation layers' gradients of all chains: one launch per chain, not per tensor
+            torch._foreach_add_(sums, addends)
     else:
         run_chains()
         g_main = list(results[0][0])
