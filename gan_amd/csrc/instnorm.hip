@@ -13,6 +13,8 @@
 // coalesced along the NHWC channel axis) x 16 lanes across pixels.  Statistics are recomputed from x in every
 // kernel (mean first, then centred sums: no E[x^2]-E[x]^2 cancellation); the per-workgroup slab (H*W x 64
 // channels) is re-read from L2.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -187,6 +189,123 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
   }
 }
 
+// Small images (H*W <= 64: the critics' 8 x 8 and 4 x 4 maps): one WAVE owns a sample and a run of 64 channels -- 16 lanes
+// across channel quads x 4 lanes across pixels, every lane keeping its pixels (at most 16) in registers -- so the sums over
+// the pixels are two lane exchanges and the kernel has no LDS traffic and no barrier.  The workgroup form above spends a
+// slab of 2-8 KB on five to seven workgroup-wide reductions (three barriers each): 0.8-1.1 TB/s on [512, 512, 4, 4].
+// A workgroup is four independent waves.
+__device__ __forceinline__ f32x4 pixel_lanes_sum(f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    v[e] += __shfl_xor(v[e], 16, 64);
+    v[e] += __shfl_xor(v[e], 32, 64);
+  }
+  return v;
+}
+
+template <int MODE, typename T, int KC>      // KC: pixels per lane (4: up to 16 pixels, 16: up to 64)
+__global__ __launch_bounds__(kThreads) void instnorm_wave_kernel(const InstNormParams p) {
+  typedef RawQuad<T> RQ;
+  typename RQ::type xr[KC], gr[MODE >= 1 ? KC : 1], ur[MODE == 2 ? KC : 1];
+  const int lane = threadIdx.x & 63, tq = lane & 15, tl = lane >> 4;
+  const int chunks = (p.C / 4 + 15) / 16;
+  const long slab = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (slab >= (long)p.N * chunks) return;          // (whole waves leave: the exchanges below stay inside a wave)
+  const int n = (int)(slab / chunks), chunk = (int)(slab % chunks);
+  const int c = (chunk * 16 + tq) * 4;
+  const bool cok = c < p.C;
+  const size_t base = (size_t)n * p.HW * p.C + (cok ? c : 0);
+  const float inv_n = 1.f / (float)p.HW;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KC; i++) {
+    const int pix = tl + i * 4;
+    if (cok && pix < p.HW) {
+      xr[i] = RQ::load(p.x, base + (size_t)pix * p.C);
+      if (MODE >= 1) gr[i] = RQ::load(p.gz, base + (size_t)pix * p.C);
+      if (MODE == 2) ur[i] = RQ::load(p.u, base + (size_t)pix * p.C);
+    }
+  }
+  auto for_pixels = [&](auto&& f) {
+#pragma unroll
+    for (int i = 0; i < KC; i++) {
+      const int pix = tl + i * 4;
+      if (cok && pix < p.HW) f(pix, RQ::widen(xr[i]), MODE >= 1 ? RQ::widen(gr[MODE >= 1 ? i : 0]) : f32x4{0.f, 0.f, 0.f, 0.f},
+                               MODE == 2 ? RQ::widen(ur[MODE == 2 ? i : 0]) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  };
+  auto mask = [&](f32x4 d) -> f32x4 {
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; e++) m[e] = (p.act == GC_ACT_LRELU && !(d[e] > 0.f)) ? p.slope : 1.f;
+    return m;
+  };
+
+  f32x4 s = zero;
+  for_pixels([&](int, f32x4 xv, f32x4, f32x4) { s += xv; });
+  const f32x4 mu = pixel_lanes_sum(s) * inv_n;
+
+  f32x4 s2 = zero, sg = zero, sgd = zero, su = zero, sud = zero, sug = zero;
+  for_pixels([&](int, f32x4 xv, f32x4 gv, f32x4 uu) {
+    const f32x4 d = xv - mu;
+    s2 += d * d;
+    if (MODE >= 1) {
+      const f32x4 gy = gv * mask(d);
+      sg += gy;
+      sgd += gy * d;
+      if (MODE == 2) {
+        su += uu;
+        sud += uu * d;
+        sug += uu * gy;
+      }
+    }
+  });
+  s2 = pixel_lanes_sum(s2);
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; e++) r[e] = rsqrtf(s2[e] * inv_n + p.eps);
+  if (MODE >= 1) { sg = pixel_lanes_sum(sg); sgd = pixel_lanes_sum(sgd); }
+  if (MODE == 2) { su = pixel_lanes_sum(su); sud = pixel_lanes_sum(sud); sug = pixel_lanes_sum(sug); }
+
+  if (MODE == 0) {
+    for_pixels([&](int pix, f32x4 xv, f32x4, f32x4) {
+      const f32x4 d = xv - mu;
+      const f32x4 z = d * r * mask(d);
+      store4<T>(p.out0, base + (size_t)pix * p.C, z);
+      if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(z);
+    });
+  } else if (MODE == 1) {
+    const f32x4 gbar = sg * inv_n, cbar = sgd * r * inv_n;
+    for_pixels([&](int pix, f32x4 xv, f32x4 gv, f32x4) {
+      const f32x4 d = xv - mu;
+      const f32x4 gy = gv * mask(d);
+      const f32x4 gx = r * (gy - gbar - d * r * cbar);
+      store4<T>(p.out0, base + (size_t)pix * p.C, gx);
+      if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(gx);
+    });
+  } else {
+    const float nn = (float)p.HW;
+    const f32x4 gbar = sg * inv_n, ubar = su * inv_n;
+    const f32x4 c_ = sgd * r, b_ = sud * r;
+    const f32x4 a_ = sug - nn * ubar * gbar;
+    const f32x4 k0 = a_ - b_ * c_ * inv_n;
+    const f32x4 scale = -(r * r) * inv_n;
+    for_pixels([&](int pix, f32x4 xv, f32x4 gv, f32x4 uu) {
+      const f32x4 d = xv - mu;
+      const f32x4 m = mask(d);
+      const f32x4 xh = d * r;
+      const f32x4 gy = gv * m;
+      const f32x4 pu = uu - ubar - xh * (b_ * inv_n);
+      const f32x4 pg = gy - gbar - xh * (c_ * inv_n);
+      const f32x4 o0 = scale * (k0 * xh + c_ * pu + b_ * pg), o1 = m * r * pu;
+      store4<T>(p.out0, base + (size_t)pix * p.C, o0);
+      store4<T>(p.out1, base + (size_t)pix * p.C, o1);
+      if (p.out0_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out0_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o0);
+      if (p.out1_bf16 != nullptr) *reinterpret_cast<u32x2*>(p.out1_bf16 + base + (size_t)pix * p.C) = cvt_bf16x4(o1);
+    });
+  }
+}
+
 static int launch_instnorm(int mode, int dtype, const void* x, const void* gz, const void* u, void* out0, void* out1, void* out0_bf16,
                            void* out1_bf16, int N, int HW, int C, float eps, float slope, int act, hipStream_t stream) {
   if (dtype != GC_F32 && dtype != GC_BF16) { set_error("instnorm: unknown dtype"); return GC_BAD_ARGUMENT; }
@@ -203,13 +322,31 @@ static int launch_instnorm(int mode, int dtype, const void* x, const void* gz, c
     set_error("instnorm: misaligned bf16 output"); return GC_BAD_ARGUMENT;
   }
   InstNormParams p{x, gz, u, out0, out1, (uint16_t*)out0_bf16, (uint16_t*)out1_bf16, N, HW, C, 0, eps, slope, act};
+  static const char* names[3] = {"gc::instnorm_kernel<0>", "gc::instnorm_kernel<1>", "gc::instnorm_kernel<2>"};
+  // small images: a wave per (sample, 64 channels), its pixels in registers (bf16 tensors; fp32 ones up to 16 pixels, or in
+  // the forward pass, where one tensor is held)
+  static const bool wave_off = getenv("GC_NO_WAVE_NORM") != nullptr;
+  if (!wave_off && HW <= 4 * kCachePix && (dtype == GC_BF16 || mode == 0 || HW <= 16)) {
+    const long slabs = (long)N * ((C / 4 + 15) / 16);
+    const dim3 wgrid((unsigned)((slabs + kThreads / 64 - 1) / (kThreads / 64))), wblock(kThreads);
+    ProfScope ps(names[mode], 0.0, stream);
+#define GC_WAVE_NORM(M_)                                                                                             \
+    if (mode == M_) {                                                                                                  \
+      if (dtype == GC_F32 && HW <= 16) hipLaunchKernelGGL((instnorm_wave_kernel<M_, float, 4>), wgrid, wblock, 0, stream, p);        \
+      else if (dtype == GC_F32) hipLaunchKernelGGL((instnorm_wave_kernel<0, float, 16>), wgrid, wblock, 0, stream, p);               \
+      else if (HW <= 16) hipLaunchKernelGGL((instnorm_wave_kernel<M_, uint16_t, 4>), wgrid, wblock, 0, stream, p);                   \
+      else hipLaunchKernelGGL((instnorm_wave_kernel<M_, uint16_t, 16>), wgrid, wblock, 0, stream, p);                                \
+    }
+    GC_WAVE_NORM(0) GC_WAVE_NORM(1) GC_WAVE_NORM(2)
+#undef GC_WAVE_NORM
+    return check_hip(hipGetLastError(), "instnorm launch");
+  }
   while ((1 << p.qb_log2) < C / 4 && p.qb_log2 < 4) p.qb_log2++;
   // few samples with large images: narrower channel runs per workgroup (down to 16 channels) to fill the CUs
   while (p.qb_log2 > 2 && (long)N * ((C / 4 + (1 << p.qb_log2) - 1) >> p.qb_log2) < 512 && HW >= 1024) p.qb_log2--;
   const int QB = 1 << p.qb_log2;
   const int chunks = (C / 4 + QB - 1) / QB;
   const dim3 grid((unsigned)N * chunks), block(kThreads);
-  static const char* names[3] = {"gc::instnorm_kernel<0>", "gc::instnorm_kernel<1>", "gc::instnorm_kernel<2>"};
   ProfScope ps(names[mode], 0.0, stream);
   // register-resident slabs: at most kCachePix pixels per thread; fp32 tensors only in the forward pass (three fp32
   // tensors of 16 quads would need 192 registers)
