@@ -189,37 +189,40 @@ __global__ __launch_bounds__(kThreads) void instnorm_kernel(const InstNormParams
   }
 }
 
-// Small images (H*W <= 64: the critics' 8 x 8 and 4 x 4 maps): one WAVE owns a sample and a run of 64 channels -- 16 lanes
-// across channel quads x 4 lanes across pixels, every lane keeping its pixels (at most 16) in registers -- so the sums over
-// the pixels are two lane exchanges and the kernel has no LDS traffic and no barrier.  The workgroup form above spends a
-// slab of 2-8 KB on five to seven workgroup-wide reductions (three barriers each): 0.8-1.1 TB/s on [512, 512, 4, 4].
-// A workgroup is four independent waves.
+// Images of up to 256 pixels (the critics' 16 x 16, 8 x 8 and 4 x 4 maps): one WAVE owns a sample and a run of channels --
+// QL lanes across channel quads x PL lanes across pixels (16 x 4 up to 64 pixels, 4 x 16 up to 256), every lane keeping
+// its pixels (at most 16) in registers -- so the sums over the pixels are lane exchanges and the kernel has no LDS traffic
+// and no barrier.  The workgroup form above spends a slab of 2-8 KB on five to seven workgroup-wide reductions (three
+// barriers each): 0.8-1.1 TB/s on [512, 512, 4, 4].  A workgroup is four independent waves on neighbouring channel runs
+// (with 4 quads per wave they share every 128-byte line they touch).
+template <int PL>
 __device__ __forceinline__ f32x4 pixel_lanes_sum(f32x4 v) {
 #pragma unroll
   for (int e = 0; e < 4; e++) {
-    v[e] += __shfl_xor(v[e], 16, 64);
-    v[e] += __shfl_xor(v[e], 32, 64);
+#pragma unroll
+    for (int o = 64 / PL; o < 64; o <<= 1) v[e] += __shfl_xor(v[e], o, 64);
   }
   return v;
 }
 
-template <int MODE, typename T, int KC>      // KC: pixels per lane (4: up to 16 pixels, 16: up to 64)
+template <int MODE, typename T, int KC, int PL>      // KC: pixels per lane, PL: lanes across pixels (KC * PL pixels at most)
 __global__ __launch_bounds__(kThreads) void instnorm_wave_kernel(const InstNormParams p) {
   typedef RawQuad<T> RQ;
+  constexpr int QL = 64 / PL;
   typename RQ::type xr[KC], gr[MODE >= 1 ? KC : 1], ur[MODE == 2 ? KC : 1];
-  const int lane = threadIdx.x & 63, tq = lane & 15, tl = lane >> 4;
-  const int chunks = (p.C / 4 + 15) / 16;
+  const int lane = threadIdx.x & 63, tq = lane & (QL - 1), tl = lane / QL;
+  const int chunks = (p.C / 4 + QL - 1) / QL;
   const long slab = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (slab >= (long)p.N * chunks) return;          // (whole waves leave: the exchanges below stay inside a wave)
   const int n = (int)(slab / chunks), chunk = (int)(slab % chunks);
-  const int c = (chunk * 16 + tq) * 4;
+  const int c = (chunk * QL + tq) * 4;
   const bool cok = c < p.C;
   const size_t base = (size_t)n * p.HW * p.C + (cok ? c : 0);
   const float inv_n = 1.f / (float)p.HW;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < KC; i++) {
-    const int pix = tl + i * 4;
+    const int pix = tl + i * PL;
     if (cok && pix < p.HW) {
       xr[i] = RQ::load(p.x, base + (size_t)pix * p.C);
       if (MODE >= 1) gr[i] = RQ::load(p.gz, base + (size_t)pix * p.C);
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void instnorm_wave_kernel(const InstNormP
   auto for_pixels = [&](auto&& f) {
 #pragma unroll
     for (int i = 0; i < KC; i++) {
-      const int pix = tl + i * 4;
+      const int pix = tl + i * PL;
       if (cok && pix < p.HW) f(pix, RQ::widen(xr[i]), MODE >= 1 ? RQ::widen(gr[MODE >= 1 ? i : 0]) : f32x4{0.f, 0.f, 0.f, 0.f},
                                MODE == 2 ? RQ::widen(ur[MODE == 2 ? i : 0]) : f32x4{0.f, 0.f, 0.f, 0.f});
     }
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void instnorm_wave_kernel(const InstNormP
 
   f32x4 s = zero;
   for_pixels([&](int, f32x4 xv, f32x4, f32x4) { s += xv; });
-  const f32x4 mu = pixel_lanes_sum(s) * inv_n;
+  const f32x4 mu = pixel_lanes_sum<PL>(s) * inv_n;
 
   f32x4 s2 = zero, sg = zero, sgd = zero, su = zero, sud = zero, sug = zero;
   for_pixels([&](int, f32x4 xv, f32x4 gv, f32x4 uu) {
@@ -260,12 +263,12 @@ __global__ __launch_bounds__(kThreads) void instnorm_wave_kernel(const InstNormP
       }
     }
   });
-  s2 = pixel_lanes_sum(s2);
+  s2 = pixel_lanes_sum<PL>(s2);
   f32x4 r;
 #pragma unroll
   for (int e = 0; e < 4; e++) r[e] = rsqrtf(s2[e] * inv_n + p.eps);
-  if (MODE >= 1) { sg = pixel_lanes_sum(sg); sgd = pixel_lanes_sum(sgd); }
-  if (MODE == 2) { su = pixel_lanes_sum(su); sud = pixel_lanes_sum(sud); sug = pixel_lanes_sum(sug); }
+  if (MODE >= 1) { sg = pixel_lanes_sum<PL>(sg); sgd = pixel_lanes_sum<PL>(sgd); }
+  if (MODE == 2) { su = pixel_lanes_sum<PL>(su); sud = pixel_lanes_sum<PL>(sud); sug = pixel_lanes_sum<PL>(sug); }
 
   if (MODE == 0) {
     for_pixels([&](int pix, f32x4 xv, f32x4, f32x4) {
@@ -323,21 +326,28 @@ static int launch_instnorm(int mode, int dtype, const void* x, const void* gz, c
   }
   InstNormParams p{x, gz, u, out0, out1, (uint16_t*)out0_bf16, (uint16_t*)out1_bf16, N, HW, C, 0, eps, slope, act};
   static const char* names[3] = {"gc::instnorm_kernel<0>", "gc::instnorm_kernel<1>", "gc::instnorm_kernel<2>"};
-  // small images: a wave per (sample, 64 channels), its pixels in registers (bf16 tensors; fp32 ones up to 16 pixels, or in
-  // the forward pass, where one tensor is held)
+  // up to 256 pixels: a wave per (sample, 64 or 16 channels), its pixels in registers (bf16 tensors; fp32 ones up to 16
+  // pixels, or in the forward pass, where one tensor is held)
   static const bool wave_off = getenv("GC_NO_WAVE_NORM") != nullptr;
-  if (!wave_off && HW <= 4 * kCachePix && (dtype == GC_BF16 || mode == 0 || HW <= 16)) {
-    const long slabs = (long)N * ((C / 4 + 15) / 16);
+  const bool few = HW <= 16, mid = HW <= 4 * kCachePix, many = HW <= 16 * kCachePix;
+  if (!wave_off && many && (dtype == GC_BF16 || mode == 0 || few)) {
+    const int ql = mid ? 16 : 4;                  // channel quads per wave
+    const long slabs = (long)N * ((C / 4 + ql - 1) / ql);
     const dim3 wgrid((unsigned)((slabs + kThreads / 64 - 1) / (kThreads / 64))), wblock(kThreads);
     ProfScope ps(names[mode], 0.0, stream);
+#define GC_WAVE_LAUNCH(M_, T_, KC_, PL_) hipLaunchKernelGGL((instnorm_wave_kernel<M_, T_, KC_, PL_>), wgrid, wblock, 0, stream, p)
 #define GC_WAVE_NORM(M_)                                                                                             \
     if (mode == M_) {                                                                                                  \
-      if (dtype == GC_F32 && HW <= 16) hipLaunchKernelGGL((instnorm_wave_kernel<M_, float, 4>), wgrid, wblock, 0, stream, p);        \
-      else if (dtype == GC_F32) hipLaunchKernelGGL((instnorm_wave_kernel<0, float, 16>), wgrid, wblock, 0, stream, p);               \
-      else if (HW <= 16) hipLaunchKernelGGL((instnorm_wave_kernel<M_, uint16_t, 4>), wgrid, wblock, 0, stream, p);                   \
-      else hipLaunchKernelGGL((instnorm_wave_kernel<M_, uint16_t, 16>), wgrid, wblock, 0, stream, p);                                \
+      if (dtype == GC_F32) {                                                                                           \
+        if (few) GC_WAVE_LAUNCH(M_, float, 4, 4);                                                                      \
+        else if (mid) GC_WAVE_LAUNCH(0, float, 16, 4);                                                                 \
+        else GC_WAVE_LAUNCH(0, float, 16, 16);                                                                         \
+      } else if (few) GC_WAVE_LAUNCH(M_, uint16_t, 4, 4);                                                              \
+      else if (mid) GC_WAVE_LAUNCH(M_, uint16_t, 16, 4);                                                               \
+      else GC_WAVE_LAUNCH(M_, uint16_t, 16, 16);                                                                       \
     }
     GC_WAVE_NORM(0) GC_WAVE_NORM(1) GC_WAVE_NORM(2)
+#undef GC_WAVE_LAUNCH
 #undef GC_WAVE_NORM
     return check_hip(hipGetLastError(), "instnorm launch");
   }
