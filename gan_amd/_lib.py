@@ -24,7 +24,7 @@ EXPORTS = (
     "gc_cond_batchnorm_workspace_bytes", "gc_cond_batchnorm_act_fwd", "gc_cond_batchnorm_act_bwd", "gc_noise_lrelu_adain_workspace_bytes", "gc_noise_lrelu_adain_fwd", "gc_noise_lrelu_adain_bwd",
     "gc_wgrad_multi_workspace_bytes", "gc_conv2d_wgrad_multi",
     "gc_channel_scale", "gc_rowdot_workspace_bytes", "gc_rowdot", "gc_act_concat_fwd", "gc_act_concat_bwd",
-    "gc_wgan_mix", "gc_gradient_penalty_workspace_bytes", "gc_gradient_penalty_fwd", "gc_gradient_penalty_bwd", "gc_wgan_critic_loss", "gc_image_batch_prepare", "gc_spectral_norm_workspace_bytes", "gc_spectral_norm_power_iteration",
+    "gc_wgan_mix", "gc_gradient_penalty_workspace_bytes", "gc_gradient_penalty_fwd", "gc_gradient_penalty_bwd", "gc_wgan_critic_loss", "gc_image_batch_prepare", "gc_spectral_norm_workspace_bytes", "gc_spectral_norm_power_iteration", "gc_spectral_norm_multi_plan", "gc_spectral_norm_multi_run",
 )
 
 
@@ -108,6 +108,8 @@ def lib():
     L.gc_spectral_norm_workspace_bytes.argtypes = [i32, i64]
     L.gc_spectral_norm_workspace_bytes.restype = ctypes.c_size_t
     L.gc_spectral_norm_power_iteration.argtypes = [vp, i32, i64, vp, vp, i32, vp, ctypes.c_size_t, vp]
+    L.gc_spectral_norm_multi_plan.argtypes = [vp, i32, vp, vp, vp]
+    L.gc_spectral_norm_multi_run.argtypes = [vp, i32, vp, i32, vp, vp]
     L.gc_gradient_penalty_workspace_bytes.argtypes = [i32, i64]
     L.gc_gradient_penalty_workspace_bytes.restype = sz
     L.gc_gradient_penalty_fwd.argtypes = [vp, i32, i32, i64, f32, vp, vp, vp, vp, sz, vp]

@@ -54,6 +54,9 @@ def set_fused_norm(on):
 def _sigma(layer):
     """Largest singular value of layer.weight (as a [out, rest] matrix) by power iteration from the stored left vector
     U_vector [1, out], which is advanced in place.  No gradient flows through it."""
+    ahead = layer.__dict__.pop("_sigma_ahead", None)      # computed for the whole network in front of this forward pass
+    if ahead is not None:
+        return ahead
     if layer.weight.is_cuda and layer.norm == 2 and layer.weight.dtype == torch.float32:
         return ops.spectral_sigma_(layer.weight, layer.U_vector, layer.n_iterations)       # four launches per iteration
     with torch.no_grad():
@@ -64,6 +67,27 @@ def _sigma(layer):
             s = (u @ w @ v.t()).reshape(())
             layer.U_vector.copy_(u)        # in place: the buffer keeps its storage, which a recorded step relies on
     return s
+
+
+def _sigmas_ahead(net):
+    """One power iteration per spectrally normalised layer of `net`, all layers in one set of launches; each layer's next
+    forward call takes its sigma from here instead of iterating itself (same values: the weights do not move inside a
+    forward pass).  Layers that cannot take part (CPU, another norm) keep iterating in their own forward call."""
+    layers = net.__dict__.get("_sn_layers")
+    if layers is None:
+        layers = [m for m in net.modules() if isinstance(m, (Conv2d, Linear)) and m.norm == 2 and m.n_iterations == 1]
+        net.__dict__["_sn_layers"] = layers
+        net.__dict__["_sn_set"] = None
+    if not layers or not layers[0].weight.is_cuda or any(m.weight.dtype != torch.float32 for m in layers):
+        return
+    st = net.__dict__["_sn_set"]
+    if st is None:
+        st = net.__dict__["_sn_set"] = ops.SpectralNormSet([m.weight for m in layers], [m.U_vector for m in layers])
+    else:
+        st.weights, st.us = [m.weight for m in layers], [m.U_vector for m in layers]       # (re-created tensors show in the key)
+    sig = st.refresh()
+    for i, m in enumerate(layers):
+        m.__dict__["_sigma_ahead"] = sig[i]
 
 
 class Conv2d(gnn.Conv2d):
@@ -190,6 +214,7 @@ class Generator(torch.nn.Module):
         self.to_RGB_layer = Conv2d(ch, 3, 1)
 
     def forward(self, latent_vector, y):
+        _sigmas_ahead(self)
         chunks = latent_vector.split(20, dim=1)            # the first feeds the 4x4 seed, one more per residual block
         klass = self.linear_y(y)
         h = self.linear_z(chunks[0]).reshape(latent_vector.shape[0], -1, 4, 4)
@@ -220,6 +245,7 @@ class Discriminator(torch.nn.Module):
         self.projection_layer = Linear(16 * ch, 1)
 
     def forward(self, x, y):
+        _sigmas_ahead(self)
         h = x
         for block in self.main_sequence:
             h = block(h)

@@ -1853,15 +1853,74 @@ def spectral_sigma_(weight, u, n_iterations=1):
     return sigma
 
 
+_SN_JOB = None
+_SN_PLAN = None
+
+
+def _sn_dtypes():
+    global _SN_JOB, _SN_PLAN
+    if _SN_JOB is None:
+        import numpy as np
+        _SN_JOB = np.dtype([("w", "<u8"), ("u", "<u8"), ("sigma", "<u8"), ("rows", "<i4"), ("pad", "<i4"), ("cols", "<i8")], align=True)
+        _SN_PLAN = np.dtype([("w", "<u8"), ("u", "<u8"), ("sigma", "<u8"), ("cols", "<i8"), ("ws_part", "<i8"), ("ws_t", "<i8"),
+                             ("ws_s", "<i8"), ("ws_scal", "<i8"), ("rows", "<i4"), ("vec", "<i4"), ("splits", "<i4"),
+                             ("rows_per_split", "<i4"), ("col_blocks", "<i4"), ("col_block0", "<i4"), ("row_block0", "<i4"),
+                             ("pad", "<i4")], align=True)
+        assert _SN_JOB.itemsize == 40 and _SN_PLAN.itemsize == 96       # gc_spectral_job, gc_spectral_plan
+    return _SN_JOB, _SN_PLAN
+
+
+class SpectralNormSet:
+    """The power iterations of ALL spectrally normalised weights of a network as one set of four launches per iteration
+    (gc_spectral_norm_multi_run) instead of four per weight.  The reference advances each layer's U_vector inside that
+    layer's forward call (BigGAN/model.py:22-25); the weights do not change inside a forward pass, so one refresh() in front
+    of it gives every layer the same sigma and the same advanced vector.  weights: fp32 CUDA parameters (read as
+    [out, rest]); us: their left vectors, contiguous fp32 with `out` elements each, advanced in place."""
+
+    def __init__(self, weights, us, n_iterations=1):
+        self.weights, self.us, self.n_iterations = list(weights), list(us), int(n_iterations)
+        self._key = None
+
+    @torch.no_grad()
+    def refresh(self):
+        """Advances every left vector and returns the sigmas as one [n] tensor (sigma of weights[i] at index i)."""
+        import numpy as np
+        key = tuple(w.data_ptr() for w in self.weights) + tuple(u.data_ptr() for u in self.us)
+        L = _lib.lib()
+        if key != self._key:          # first call, or a parameter / buffer was re-created: plan and upload again
+            job_t, plan_t = _sn_dtypes()
+            n = len(self.weights)
+            dev = self.weights[0].device
+            self.sigma = torch.empty(n, dtype=torch.float32, device=dev)
+            jobs = np.zeros(n, job_t)
+            for i, (w, u) in enumerate(zip(self.weights, self.us)):
+                _check_cuda(w, u)
+                if w.dtype != torch.float32 or not w.is_contiguous() or u.dtype != torch.float32 or not u.is_contiguous() or u.numel() != w.shape[0]:
+                    raise RuntimeError("ganconv: SpectralNormSet takes contiguous fp32 weights and left vectors of `out` elements")
+                jobs[i] = (w.data_ptr(), u.data_ptr(), self.sigma.data_ptr() + 4 * i, w.shape[0], 0, w.numel() // w.shape[0])
+            plan = np.zeros(n, plan_t)
+            ws_bytes = ctypes.c_size_t(0)
+            self._grids = (ctypes.c_int32 * 2)()
+            _lib.check(L.gc_spectral_norm_multi_plan(jobs.ctypes.data_as(ctypes.c_void_p), n, plan.ctypes.data_as(ctypes.c_void_p),
+                                                     ctypes.byref(ws_bytes), self._grids), "gc_spectral_norm_multi_plan")
+            self._plan = torch.from_numpy(plan.view(np.uint8)).to(dev)
+            self._ws = torch.empty(max(ws_bytes.value // 4, 4), dtype=torch.float32, device=dev)
+            self._key = key
+        _lib.check(L.gc_spectral_norm_multi_run(ctypes.c_void_p(self._plan.data_ptr()), len(self.weights), self._grids, self.n_iterations,
+                                                ctypes.c_void_p(self._ws.data_ptr()), _stream()), "gc_spectral_norm_multi_run")
+        return self.sigma
+
+
 @torch.no_grad()
-def orthogonal_regularization_(parameters, beta=1e-4, precision="fp32x3"):
+def orthogonal_regularization_(parameters, beta=1e-4, precision=None):
     """BigGAN/train.py:115-127: grad += 2 beta (W W^T with its diagonal removed) W for every parameter with more than two
     dimensions that has a gradient, W = the parameter flattened to [out, rest].  Both products run on the convolution
     kernels: W in memory IS a one-sample NHWC image of `out` pixels x `rest` channels, so W W^T is a 1x1 convolution of that
     image with W as the filter bank, and (W W^T) W is the data gradient of the same 1x1 convolution for the Gram matrix as the
-    output gradient -- no transposed copy of W.  `precision`: "fp32x3" (split fp32 operands, fp32-like accuracy; default, the
-    reference computes this in fp32) or "bf16"."""
-    prec = _PRECISION[precision]
+    output gradient -- no transposed copy of W.  `precision`: None (the mode the convolutions run in, set_precision), "fp32x3"
+    (split fp32 operands, fp32-like accuracy: the reference computes this in fp32) or "bf16" (operands rounded to bf16: the
+    added term, 2 beta times a product of weights, is then accurate to about 1e-2 of itself)."""
+    prec = get_precision() if precision is None else _PRECISION[precision]
     f32 = _code_of(torch.float32)
     for p in parameters:
         if p.dim() <= 2 or p.grad is None:

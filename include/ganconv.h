@@ -401,6 +401,29 @@ int gc_image_batch_prepare(const gc_image_job* jobs, int32_t n, int32_t channels
 size_t gc_spectral_norm_workspace_bytes(int32_t rows, int64_t cols);
 int gc_spectral_norm_power_iteration(const float* w, int32_t rows, int64_t cols, float* u, float* sigma, int32_t n_iterations,
                                      void* workspace, size_t workspace_bytes, void* stream);
+/* The same for every spectrally normalised weight of a network in one set of four launches per iteration (the
+ * reference runs the iteration inside each layer's forward call, BigGAN/model.py:22-25; the weights do not change
+ * inside a forward pass, so doing all of them in front of it gives the same values).  gc_spectral_norm_multi_plan (host
+ * only) turns n jobs into n plan records, the workspace size and the two grid sizes; the caller copies the records to
+ * device memory once and calls gc_spectral_norm_multi_run with that copy before every forward pass. */
+typedef struct {
+  const void* w;                 /* [rows][cols] fp32 */
+  void* u;                       /* [rows] fp32, advanced in place */
+  void* sigma;                   /* [1] fp32 */
+  int32_t rows, pad;
+  int64_t cols;
+} gc_spectral_job;
+typedef struct {
+  const void* w;
+  void* u;
+  void* sigma;
+  int64_t cols;
+  int64_t ws_part, ws_t, ws_s, ws_scal;      /* offsets into the workspace, in floats */
+  int32_t rows, vec, splits, rows_per_split, col_blocks, col_block0, row_block0, pad;
+} gc_spectral_plan;
+int gc_spectral_norm_multi_plan(const gc_spectral_job* jobs, int32_t n, gc_spectral_plan* plan, size_t* workspace_bytes, int32_t grids[2]);
+int gc_spectral_norm_multi_run(const gc_spectral_plan* plan_device, int32_t n, const int32_t grids[2], int32_t n_iterations, void* workspace,
+                               void* stream);
 
 /* Self-attention over image positions without the [N, N] weight matrix in memory: out = softmax(k q^T) v per sample,
  * softmax over the last index, unit scale.  Replaces the bmm + Softmax + bmm of SelfAttentionBlock.forward

@@ -70,9 +70,35 @@ def test_orthogonal_regularisation_gradient(gan, shape):
     p.grad = grad0.clone().cuda()
     skipped = torch.nn.Parameter(torch.randn(16, 16, generator=g).cuda())        # two dimensions: left alone
     skipped.grad = torch.ones(16, 16, device="cuda")
-    gan.ops.orthogonal_regularization_([p, skipped], beta)
+    gan.ops.orthogonal_regularization_([p, skipped], beta, precision="fp32x3")
     assert rel(p.grad - grad0.cuda(), want - grad0.double()) < 5e-5          # the added term itself
     assert torch.equal(skipped.grad, torch.ones(16, 16, device="cuda"))
     p.grad = grad0.clone().cuda()
-    gan.ops.orthogonal_regularization_([p], beta, precision="bf16")
+    gan.ops.orthogonal_regularization_([p], beta)                            # the convolutions' mode: bf16 operands
     assert rel(p.grad - grad0.cuda(), want - grad0.double()) < 2e-2
+
+
+def test_spectral_norms_of_a_whole_network_in_one_set_of_launches(gan):
+    """ops.SpectralNormSet against the per-weight call: same sigmas, same advanced vectors, over two refreshes; and through the
+    BigGAN harness, whose networks refresh every layer in front of a forward pass."""
+    g = torch.Generator().manual_seed(54)
+    shapes = [(64, 32, 3, 3), (128, 3, 3, 3), (96, 20), (2048, 20), (256, 256, 1, 1), (8, 8, 1, 1), (1, 37), (512, 512, 3, 3)]
+    ws = [torch.randn(*s, generator=g).cuda() for s in shapes]
+    u_one = [torch.rand(1, s[0], generator=g).cuda() for s in shapes]
+    u_set = [u.clone() for u in u_one]
+    st = gan.ops.SpectralNormSet(ws, u_set)
+    for _ in range(2):
+        sig = st.refresh().clone()
+        for i, (w, u) in enumerate(zip(ws, u_one)):
+            want = gan.ops.spectral_sigma_(w, u, 1)
+            assert torch.equal(sig[i], want) and torch.equal(u_set[i], u), i
+    from gan_amd.harness import biggan as B
+    torch.manual_seed(55)
+    D = B.Discriminator(n_classes=4, ch=8).cuda()
+    layers = [m for m in D.modules() if isinstance(m, (B.Conv2d, B.Linear))]
+    u0 = [m.U_vector.detach().cpu().clone() for m in layers]
+    D(torch.randn(2, 3, 128, 128, device="cuda"), torch.zeros(2, dtype=torch.long, device="cuda"))
+    for m, u in zip(layers, u0):
+        _, want_u = _power_iterations(m.weight.detach().cpu(), u, 1)
+        assert rel(m.U_vector, want_u) < 2e-5
+        assert "_sigma_ahead" not in m.__dict__            # every layer took its sigma

@@ -23,6 +23,7 @@ CPU_B = 4
 ONLY = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]     # --only=biggan etc.
 NO_CPU = "--no-cpu" in sys.argv
 GRAPH = "--graph" in sys.argv    # also time the step recorded into one HIP graph
+TOP = ([int(a.split("=")[1]) for a in sys.argv if a.startswith("--top=")] or [10])[0]      # kernels listed per family
 FAST = "--fast" in sys.argv      # bf16 activation storage and the other speed options of the harnesses
 
 
@@ -67,7 +68,7 @@ def kernel_table(step, title):
     _lib.profile_enable(False)
     tot = sum(v["total_ms"] for v in prof.values())
     print(f"-- {title}: library kernels {tot:.2f} ms per step")
-    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:10]:
+    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:TOP]:
         tf = v["flops"] / (v["total_ms"] * 1e-3) / 1e12 if v["flops"] > 0 and v["total_ms"] > 0 else 0.0
         print(f"   {k:78s} n={v['launches']:4d} {v['total_ms']:8.3f} ms {tf:7.1f} TFLOP/s")
 
