@@ -1883,7 +1883,7 @@ class SpectralNormSet:
 
     @torch.no_grad()
     def refresh(self):
-        """Advances every left vector and returns the sigmas as one [n] tensor (sigma of weights[i] at index i)."""
+        """Advances every left vector and returns the sigmas as one new [n] tensor (sigma of weights[i] at index i)."""
         import numpy as np
         key = tuple(w.data_ptr() for w in self.weights) + tuple(u.data_ptr() for u in self.us)
         L = _lib.lib()
@@ -1908,7 +1908,8 @@ class SpectralNormSet:
             self._key = key
         _lib.check(L.gc_spectral_norm_multi_run(ctypes.c_void_p(self._plan.data_ptr()), len(self.weights), self._grids, self.n_iterations,
                                                 ctypes.c_void_p(self._ws.data_ptr()), _stream()), "gc_spectral_norm_multi_run")
-        return self.sigma
+        # (a fresh tensor per call: a graph that divides by an earlier call's values keeps them for its backward pass)
+        return self.sigma.clone()
 
 
 @torch.no_grad()
