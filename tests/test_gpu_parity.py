@@ -1171,7 +1171,7 @@ def test_attention_against_unfused_product(gan, B, N, d, C):
 @pytest.mark.parametrize("shape", [(3, 32, 8, 8), (2, 64, 40, 24), (4, 8, 4, 4), (1, 512, 16, 16), (2, 64, 64, 64), (1, 24, 70, 61), (3, 128, 32, 48)])
 def test_noise_lrelu_adain_against_torch(gan, shape, dt):
     """ys * InstanceNorm2d(leaky_relu(x + sf * noise)) + yb (reference StyleGAN/model.py:249-261) and the gradients of x,
-    the noise scale and the two styles against the torch composition in fp32."""
+    the noise scale and the two styles against the torch composition on the CPU in float64."""
     g = torch.Generator().manual_seed(17)
     N, C, H, W = shape
     x = (torch.randn(*shape, generator=g) * 1.3).cuda().to(dt).requires_grad_(True)
@@ -1182,10 +1182,10 @@ def test_noise_lrelu_adain_against_torch(gan, shape, dt):
     out, mu, r = gan.ops.noise_lrelu_adain(x, noise, sf, ys, yb, 1e-5, 0.2)
     go = torch.randn(*shape, generator=g).cuda().to(dt)
     gx, gsf, gys, gyb = torch.autograd.grad(out, (x, sf, ys, yb), go)
-    xr, sfr, ysr, ybr = (t.detach().float().requires_grad_(True) for t in (x, sf, ys, yb))
-    tr = torch.nn.functional.leaky_relu(xr + sfr * noise, 0.2)
+    xr, sfr, ysr, ybr = (t.detach().cpu().double().requires_grad_(True) for t in (x, sf, ys, yb))      # CPU, float64
+    tr = torch.nn.functional.leaky_relu(xr + sfr * noise.cpu().double(), 0.2)
     outr = ysr[:, :, None, None] * torch.nn.functional.instance_norm(tr, eps=1e-5) + ybr[:, :, None, None]
-    gxr, gsfr, gysr, gybr = torch.autograd.grad(outr, (xr, sfr, ysr, ybr), go.float())
+    gxr, gsfr, gysr, gybr = torch.autograd.grad(outr, (xr, sfr, ysr, ybr), go.cpu().double())
     tol, gtol = (2e-5, 2e-4) if dt == torch.float32 else (6e-3, 1.5e-2)
     assert out.dtype == dt and rel(out.float(), outr) < tol
     assert rel(mu, tr.mean(dim=(2, 3))) < 1e-5
@@ -1197,7 +1197,7 @@ def test_noise_lrelu_adain_against_torch(gan, shape, dt):
 @pytest.mark.parametrize("shape,act", [((4, 32, 8, 8), 1), ((3, 64, 40, 24), 1), ((2, 8, 32, 32), 0), ((5, 128, 4, 4), 1)])
 def test_conditional_batchnorm_against_torch(gan, shape, act, dt):
     """gamma[n, c] * BatchNorm2d(affine=False)(x) + beta[n, c], then ReLU (reference BigGAN/model.py:61-77,129): output,
-    the batch statistics and the gradients of x, gamma and beta against the torch composition in fp32."""
+    the batch statistics and the gradients of x, gamma and beta against the torch composition on the CPU in float64."""
     g = torch.Generator().manual_seed(13)
     N, C, H, W = shape
     x = (torch.randn(*shape, generator=g) * 1.5 + 0.3).cuda().to(dt).requires_grad_(True)
@@ -1206,13 +1206,11 @@ def test_conditional_batchnorm_against_torch(gan, shape, act, dt):
     y, mean, rstd, var = gan.ops.batchnorm_act(x, gamma, beta, None, None, True, 1e-5, act, 0.0)
     gy = torch.randn(*shape, generator=g).cuda().to(dt)
     gx, gg, gb = torch.autograd.grad(y, (x, gamma, beta), gy)
-    xr, gr, br = x.detach().float().requires_grad_(True), gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    xr, gr, br = (t.detach().cpu().double().requires_grad_(True) for t in (x, gamma, beta))      # CPU, float64
     yr = gr[:, :, None, None] * torch.nn.functional.batch_norm(xr, None, None, training=True, eps=1e-5) + br[:, :, None, None]
     if act:
         yr = torch.relu(yr)
-    if dt == torch.bfloat16:     # the gradient mask follows the stored (rounded) output's sign in both implementations
-        yr = yr + (y.float() - yr).detach() * 0
-    gxr, ggr, gbr = torch.autograd.grad(yr, (xr, gr, br), gy.float())
+    gxr, ggr, gbr = torch.autograd.grad(yr, (xr, gr, br), gy.cpu().double())
     tol = 2e-5 if dt == torch.float32 else 8e-3
     assert y.dtype == dt and rel(y.float(), yr) < tol
     assert rel(mean, xr.mean(dim=(0, 2, 3))) < 1e-5 and rel(var, xr.var(dim=(0, 2, 3), unbiased=True)) < 1e-4
@@ -1223,19 +1221,19 @@ def test_conditional_batchnorm_against_torch(gan, shape, act, dt):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 16, 8, 12), (2, 64, 34, 6), (1, 8, 2, 2)])
 def test_pool_and_replicate_against_torch(gan, shape, dt):
-    """AvgPool2d(2) and nearest 2x upsampling kernels, forward and gradient, against the torch operators."""
+    """AvgPool2d(2) and nearest 2x upsampling kernels, forward and gradient, against the torch operators on the CPU."""
     g = torch.Generator().manual_seed(3)
     x = torch.randn(*shape, generator=g).cuda().to(dt).requires_grad_(True)
     tol = 1e-6 if dt == torch.float32 else 4e-3
     for fn, ref in ((gan.functional.avg_pool2x2, lambda t: torch.nn.functional.avg_pool2d(t, 2)),
                     (gan.functional.upsample_nearest2x, lambda t: torch.nn.functional.interpolate(t, scale_factor=2, mode="nearest"))):
         y = fn(x)
-        xr = x.detach().float().requires_grad_(True)
+        xr = x.detach().cpu().double().requires_grad_(True)       # CPU, float64
         yr = ref(xr)
         assert y.shape == yr.shape and y.dtype == dt
         gy = torch.randn(*y.shape, generator=g).cuda().to(dt)
         gx, = torch.autograd.grad(y, x, gy)
-        gxr, = torch.autograd.grad(yr, xr, gy.float())
+        gxr, = torch.autograd.grad(yr, xr, gy.cpu().double())
         assert rel(y.float(), yr) < tol and rel(gx.float(), gxr) < tol
 
 
@@ -1326,7 +1324,8 @@ def test_randomized_geometries_exact_on_small_integers(gan, prec):
 @pytest.mark.parametrize("cin,cout,hw,k,s,p", [(256, 256, 128, 3, 1, 1), (128, 512, 96, 4, 2, 1)])
 def test_largest_tiles_against_torch(gan, cin, cout, hw, k, s, p):
     """Problems big enough for the 256-channel x 256-pixel tiles (and their data gradients), too big for the C oracle:
-    compared with torch's fp32 convolution of the same bf16-rounded operands on the GPU."""
+    compared with torch's fp32 convolution of the same bf16-rounded operands on the CPU (another implementation on
+    another device)."""
     g = torch.Generator().manual_seed(21)
     B = 8
     x = torch.randn(B, cin, hw, hw, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
@@ -1334,9 +1333,9 @@ def test_largest_tiles_against_torch(gan, cin, cout, hw, k, s, p):
     y = gan.functional.conv2d(x, w, None, stride=s, padding=p)
     gy = torch.randn(*y.shape, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     gx, gw = torch.autograd.grad(y, (x, w), gy)
-    xr, wr = x.detach().float().requires_grad_(True), w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    xr, wr = x.detach().cpu().float().requires_grad_(True), w.detach().cpu().to(torch.bfloat16).float().requires_grad_(True)
     yr = torch.nn.functional.conv2d(xr, wr, None, stride=s, padding=p)
-    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.float())
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.cpu().float())
     assert rel(y.float(), yr) < 4e-3 and rel(gx.float(), gxr) < 4e-3 and rel(gw, gwr) < 2e-3
 
 
