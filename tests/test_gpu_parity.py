@@ -1146,8 +1146,8 @@ def test_generator_phase_adds_the_critics_weight_gradients_like_the_reference(ga
 
 @pytest.mark.parametrize("B,N,d,C", [(2, 256, 8, 64), (3, 384, 16, 128), (1, 4096, 16, 128), (2, 4096, 8, 64)])
 def test_attention_against_unfused_product(gan, B, N, d, C):
-    """gan_amd.ops.attention (forward and the three operand gradients) against bmm + softmax + bmm in fp32 on the same
-    bf16-rounded operands (reference BigGAN/model.py:97-103).  Tolerance: the kernel rounds the probabilities and dS to
+    """gan_amd.ops.attention (forward and the three operand gradients) against bmm + softmax + bmm on the CPU in float64 on
+    the same bf16-rounded operands (reference BigGAN/model.py:97-103).  Tolerance: the kernel rounds the probabilities and dS to
     bf16 before the second products (relative 2^-9 per element, fp32 accumulation) and stores bf16 results."""
     g = torch.Generator().manual_seed(7)
     k = (torch.randn(B, N, d, generator=g) * 0.7).cuda().to(torch.bfloat16).requires_grad_(True)
@@ -1156,10 +1156,10 @@ def test_attention_against_unfused_product(gan, B, N, d, C):
     go = torch.randn(B, N, C, generator=g).cuda().to(torch.bfloat16)
     out, lse = gan.ops.attention(k, q, v)
     dk, dq, dv = torch.autograd.grad(out, (k, q, v), go)
-    kr, qr, vr = (t.detach().float().requires_grad_(True) for t in (k, q, v))
+    kr, qr, vr = (t.detach().cpu().double().requires_grad_(True) for t in (k, q, v))       # CPU, float64
     sr = torch.bmm(kr, qr.transpose(1, 2))
     outr = torch.bmm(torch.softmax(sr, dim=-1), vr)
-    dkr, dqr, dvr = torch.autograd.grad(outr, (kr, qr, vr), go.float())
+    dkr, dqr, dvr = torch.autograd.grad(outr, (kr, qr, vr), go.cpu().double())
     assert rel(lse, torch.logsumexp(sr, dim=-1)) < 1e-5
     assert rel(out.float(), outr) < 6e-3
     assert rel(dv.float(), dvr) < 6e-3
