@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(const BnParams p) 
 // One workgroup per 16 channels: thread (channel, lane) merges slabs lane, lane+16, ... then lane 0 merges the 16 lanes
 // (a fixed order, so the result does not depend on scheduling).
 constexpr int kFinCh = 16, kFinLanes = kThreads / kFinCh;
+constexpr int kDirectRows = 512;      // statistics rows of a convolution up to which the finalizing kernel reads them directly
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p) {
   __shared__ float sh_a[kThreads], sh_b[kThreads], sh_n[kThreads];
@@ -155,14 +156,20 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
   const int c = blockIdx.x * kFinCh + tc;
   const bool cok = c < p.C;
   float n = 0.f, a = 0.f, b = 0.f;   // forward: count, mean, M2;  backward: -, sum g, sum g*xh
-  if (MODE == 2) {                   // (sum, sum of squares) per slice of the rows the convolution in front wrote: plain sums in double
-    __shared__ double sh_s[kThreads], sh_q[kThreads];
+  if (MODE == 2 || MODE == 3) {      // (sum, sum of squares) per slice of the rows the convolution in front wrote: plain sums in double
+    __shared__ double sh_s[kThreads], sh_q[kThreads];      // MODE 3: straight from the fp32 rows themselves (few rows: no slice pass)
     double ds = 0.0, dq = 0.0;
     if (cok)
       for (int s = lane; s < p.slabs; s += kFinLanes) {
-        const double* v = reinterpret_cast<const double*>(p.part) + ((size_t)s * p.C + c) * 2;
-        ds += v[0];
-        dq += v[1];
+        if (MODE == 3) {
+          const float2 v = *reinterpret_cast<const float2*>(p.part + ((size_t)s * p.C + c) * 2);
+          ds += (double)v.x;
+          dq += (double)v.y;
+        } else {
+          const double* v = reinterpret_cast<const double*>(p.part) + ((size_t)s * p.C + c) * 2;
+          ds += v[0];
+          dq += v[1];
+        }
       }
     sh_s[t] = ds; sh_q[t] = dq;
     __syncthreads();
@@ -203,12 +210,12 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
         b += v.y;
       }
     }
-  if (MODE != 2) {
+  if (MODE < 2) {
   sh_a[t] = a; sh_b[t] = b; sh_n[t] = n;
   __syncthreads();
   if (lane != 0 || !cok) return;
   }
-  for (int l = 1; MODE != 2 && l < kFinLanes; l++) {
+  for (int l = 1; MODE < 2 && l < kFinLanes; l++) {
     const float va = sh_a[l * kFinCh + tc], vb = sh_b[l * kFinCh + tc], nb = sh_n[l * kFinCh + tc];
     if (MODE == 0) {
       if (nb > 0.f) {
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
       b += vb;
     }
   }
-  if (MODE == 0 || MODE == 2) {
+  if (MODE == 0 || MODE >= 2) {
     const float mean = a, var = b / (float)p.P;
     const float r = rsqrtf(var + p.eps);
     p.save_mean[c] = mean;
@@ -640,12 +647,19 @@ static int bn_forward(const void* x, void* y, void* y_bf16, const float* gamma, 
     }
     BnParams q = p;
     q.slabs = slices;
-    {
-      ProfScope ps("gc::bn_rows_partial_kernel", 0.0, s);
-      hipLaunchKernelGGL(bn_rows_partial_kernel, dim3((C + kFinCh - 1) / kFinCh, slices), block, 0, s, stat_rows, reinterpret_cast<double*>(p.part),
-                         n_rows, per, C);
+    if (n_rows <= kDirectRows) {       // few rows: the finalizing workgroups add them themselves (one launch less)
+      q.slabs = n_rows;
+      q.part = const_cast<float*>(stat_rows);
+      ProfScope ps("gc::bn_finalize_kernel<3>", 0.0, s);
+      hipLaunchKernelGGL(bn_finalize_kernel<3>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, q);
+    } else {
+      {
+        ProfScope ps("gc::bn_rows_partial_kernel", 0.0, s);
+        hipLaunchKernelGGL(bn_rows_partial_kernel, dim3((C + kFinCh - 1) / kFinCh, slices), block, 0, s, stat_rows, reinterpret_cast<double*>(p.part),
+                           n_rows, per, C);
+      }
+      { ProfScope ps("gc::bn_finalize_kernel<2>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<2>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, q); }
     }
-    { ProfScope ps("gc::bn_finalize_kernel<2>", 0.0, s); hipLaunchKernelGGL(bn_finalize_kernel<2>, dim3((C + kFinCh - 1) / kFinCh), block, 0, s, q); }
     ProfScope ps("gc::bn_apply_kernel<0>", 0.0, s);
     if (dtype == GC_F32) hipLaunchKernelGGL((bn_apply_kernel<0, float>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((bn_apply_kernel<0, uint16_t>), grid, block, 0, s, p);
