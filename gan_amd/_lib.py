@@ -155,7 +155,9 @@ def profile_enable(on):
     check(lib().gc_profile_enable(1 if on else 0), "gc_profile_enable")
 
 
-def profile_collect(max_entries=32):
+def profile_collect(max_entries=512):
+    """Timed launches since profile_enable(True), summed per kernel name (names beyond max_entries are dropped by the
+    library; a training step of the larger harnesses launches about 50 different kernels)."""
     names = ((ctypes.c_char * 96) * max_entries)()
     launches = (ctypes.c_int64 * max_entries)()
     total_ms = (ctypes.c_double * max_entries)()
