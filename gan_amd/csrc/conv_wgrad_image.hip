@@ -46,9 +46,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
   const int units_per_sample = p.Ho / kTH;
   const int ychunks = p.Cout / 8;                    // 16-byte chunks of a gy pixel
 
-  // ---- what this thread loads per rectangle: 4 chunks of gy, up to 3 patch pixels
+  // ---- what this thread loads per rectangle: 4 chunks of gy, up to 3 patch pixels.  The image values wait in registers as
+  // loaded and are rounded to bf16 on their way into LDS, after the multiplications of the rectangle before: a conversion
+  // next to its load would put a wait for that load in front of the next load, three memory latencies in a row per rectangle.
   u32x4 yreg[4];
-  u32x2 xreg[3];
+  TX xraw[3][4];
   int ppr[3], ppc[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -70,16 +72,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int ih = ih0 + ppr[i], iw = ppc[i] - 1;
-      uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) xraw[i][c] = (TX)0;
       if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
         const TX* src = img + (uint32_t)((ih * p.W + iw) * p.Cin);
-        auto bits = [](TX v) -> uint32_t { return sizeof(TX) == 2 ? (uint32_t)v : (uint32_t)float_to_bf16_bits((float)v); };
-        c0 = bits(src[0]);
-        if (p.Cin > 1) c1 = bits(src[1]);
-        if (p.Cin > 2) c2 = bits(src[2]);
-        if (p.Cin > 3) c3 = bits(src[3]);
+        xraw[i][0] = src[0];
+        if (p.Cin > 1) xraw[i][1] = src[1];
+        if (p.Cin > 2) xraw[i][2] = src[2];
+        if (p.Cin > 3) xraw[i][3] = src[3];
       }
-      xreg[i] = u32x2{c0 | (c1 << 16), c2 | (c3 << 16)};
     }
   };
   auto store_unit = [&](int buf) {
@@ -90,9 +91,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
       const int idx = t + i * kThreads, row = idx >> 3, ch = idx & 7;
       *reinterpret_cast<u32x4*>(yb + row * 128 + (((ch >> 1) ^ gy_swz(row)) << 5) + (ch & 1) * 16) = yreg[i];
     }
+    auto bits = [](TX v) -> uint32_t { return sizeof(TX) == 2 ? (uint32_t)v : (uint32_t)float_to_bf16_bits((float)v); };
 #pragma unroll
     for (int i = 0; i < 3; i++)
-      if (t + i * kThreads < kPH * kPW) *reinterpret_cast<u32x2*>(pb + (t + i * kThreads) * 8) = xreg[i];
+      if (t + i * kThreads < kPH * kPW)
+        *reinterpret_cast<u32x2*>(pb + (t + i * kThreads) * 8) =
+            u32x2{bits(xraw[i][0]) | (bits(xraw[i][1]) << 16), bits(xraw[i][2]) | (bits(xraw[i][3]) << 16)};
   };
 
   f32x4 acc[4][4];
