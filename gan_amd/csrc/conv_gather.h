@@ -81,6 +81,10 @@ int launch_scatter(const GatherParams& p, const GatherLaunch& l, bool out_f32, h
 bool plan_dot(const GatherParams& p, const GatherLaunch& l);
 int launch_dot(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 bool plan_image(const GatherParams& p, const GatherLaunch& l);
+// One input value per sample (the data gradient of a critic's score layer): an outer product, see conv_outer.hip; applies
+// the gradient mask itself.
+bool plan_outer(const GatherParams& p, const GatherLaunch& l);
+int launch_outer(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // Patch-resident kernel (stride-1 gathers with >= 4 taps per class on large images, see conv_patch.hip); plan_patch
 // rewrites the tile bookkeeping in p when it accepts.

@@ -331,6 +331,11 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
     return GC_UNSUPPORTED_GEOMETRY;
   }
   if (plan_dot(p, l)) return launch_dot(p, l, out_dt == GC_F32, stream);
+  if (plan_outer(p, l)) {
+    const int rc = launch_outer(p, l, out_dt == GC_F32, stream);    // applies grad_mask itself
+    p.mask = nullptr;
+    return rc;
+  }
   if (plan_image(p, l)) return launch_image(p, l, out_dt == GC_F32, stream);
   if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   l.big_tile_ok = true;

@@ -1,0 +1,75 @@
+"""Gathers whose input is one value per sample: the data gradient of the critics' score layer, Conv2d(512 -> 1, kernel 4)
+on 4 x 4 maps (BasicGANs/models.py:77), and a transposed convolution of a [N, 1, 1, 1] input.  They run as an outer
+product (gc::conv_outer_kernel); every output element is one product, so small-integer operands must come out exact,
+and random operands equal to the bf16-rounded product."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gan():
+    import gan_amd
+    return gan_amd
+
+
+def _names(gan, fn):
+    gan._lib.profile_enable(True)
+    out = fn()
+    torch.cuda.synchronize()
+    names = set(gan._lib.profile_collect())
+    gan._lib.profile_enable(False)
+    return out, names
+
+
+@pytest.mark.parametrize("cin,hw,N,dt", [(512, 4, 37, torch.bfloat16), (512, 4, 256, torch.float32), (64, 2, 5, torch.bfloat16),
+                                         (128, 3, 16, torch.bfloat16)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_score_layer_data_gradient(gan, cin, hw, N, dt, masked):
+    """x -> LeakyReLU epilogue of the layer before (masked: its derivative runs inside the gradient kernel) -> score."""
+    g = torch.Generator().manual_seed(61)
+    pre = torch.randint(-2, 3, (N, cin, hw, hw), generator=g).float()
+    w = torch.randint(-1, 2, (1, cin, hw, hw), generator=g).float()
+    gy = torch.randint(-3, 4, (N, 1, 1, 1), generator=g).float()
+    slope = 0.25
+    pr = pre.double().requires_grad_(True)
+    xr = torch.nn.functional.leaky_relu(pr, slope) if masked else pr
+    torch.nn.functional.conv2d(xr, w.double()).backward(gy.double())
+    want = pr.grad
+    xg = pre.cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    xg = (torch.nn.functional.leaky_relu(xg, slope) if masked else xg).requires_grad_(True)
+    kw = dict(input_activation_slope=slope) if masked else {}
+    y = gan.functional.conv2d(xg, w.cuda(), None, out_dtype=torch.float32, **kw)
+    (gx,), names = _names(gan, lambda: torch.autograd.grad(y, (xg,), gy.cuda()))
+    assert "gc::conv_outer_kernel" in names, sorted(names)
+    assert gx.dtype == dt and torch.equal(gx.double().cpu(), want)
+
+
+def test_score_layer_data_gradient_random_operands(gan):
+    """Random operands: each element is the product of the two values rounded to bf16, rounded to the output's type."""
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(64, 512, 4, 4, generator=g)
+    w = torch.randn(1, 512, 4, 4, generator=g)
+    gy = torch.randn(64, 1, 1, 1, generator=g)
+    want = gy.bfloat16().double() * w.bfloat16().double()
+    xg = x.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = gan.functional.conv2d(xg, w.cuda(), None, out_dtype=torch.float32)
+    (gx,), names = _names(gan, lambda: torch.autograd.grad(y, (xg,), gy.cuda()))
+    assert "gc::conv_outer_kernel" in names, sorted(names)
+    assert torch.equal(gx.cpu(), want.float().bfloat16())
+
+
+@pytest.mark.parametrize("stride,pad,k", [(1, 0, 4), (2, 1, 4), (2, 0, 3)])
+def test_transposed_convolution_of_one_value_per_sample(gan, stride, pad, k):
+    """ConvTranspose2d(1 -> 64) of a [N, 1, 1, 1] input with bias and activation: pixels no tap reaches hold act(bias)."""
+    g = torch.Generator().manual_seed(63)
+    N, cout = 21, 64
+    x = torch.randint(-3, 4, (N, 1, 1, 1), generator=g).float()
+    w = torch.randint(-2, 3, (1, cout, k, k), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride, pad), 0.5)
+    y, names = _names(gan, lambda: gan.functional.conv_transpose2d(x.cuda(), w.cuda(), b.cuda(), stride, pad, activation="leaky_relu",
+                                                                   negative_slope=0.5, out_dtype=torch.float32))
+    assert "gc::conv_outer_kernel" in names, sorted(names)
+    assert y.shape == want.shape and torch.equal(y.double().cpu(), want)
