@@ -30,7 +30,14 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
   const int u0 = (int)blockIdx.x * units_per_wg, u1 = min(units, u0 + units_per_wg);
   if (u0 >= u1) return;
 
-  // weights: A fragments of up to four 16-channel blocks, two reduction steps (filter rows 0-1, 2-3)
+  // weights: A fragments of up to four 16-channel blocks, two reduction steps (filter rows 0-1, 2-3).  The rows of a
+  // pair of blocks are interleaved -- row 4 g' + e of block ob is channel 32 (ob / 2) + 8 g' + 4 (ob % 2) + e -- so that a lane's
+  // results of the two blocks are 8 consecutive channels of its pixel: one 16-byte store, 64 contiguous bytes per
+  // pixel and instruction (a last block without a partner keeps its own order: 4 channels, 8 bytes per lane).
+  const int nb = p.OC / 16;
+  auto channel_of = [&](int ob, int row) {
+    return (ob | 1) < nb ? 32 * (ob >> 1) + 8 * (row >> 2) + 4 * (ob & 1) + (row & 3) : 16 * ob + row;
+  };
   bf16x8 wa[4][2];
 #pragma unroll
   for (int ob = 0; ob < 4; ob++)
@@ -38,14 +45,14 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
     for (int ks = 0; ks < 2; ks++) {
       const u32x4 z = {0u, 0u, 0u, 0u};
       u32x4 v = z;
-      if (ob * 16 < p.OC) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)(ob * 16 + c16) * p.row_pitch + ks * 32 + g * 8);
+      if (ob < nb) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)channel_of(ob, c16) * p.row_pitch + ks * 32 + g * 8);
       wa[ob][ks] = __builtin_bit_cast(bf16x8, v);
     }
   f32x4 bias_v[4];
 #pragma unroll
   for (int ob = 0; ob < 4; ob++) {
     bias_v[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && ob * 16 < p.OC) bias_v[ob] = *reinterpret_cast<const f32x4*>(p.bias + ob * 16 + 4 * g);
+    if (p.bias != nullptr && ob < nb) bias_v[ob] = *reinterpret_cast<const f32x4*>(p.bias + channel_of(ob, 4 * g));
   }
   const float sl = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);
 
@@ -108,21 +115,36 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
           if (ob * 16 < p.OC) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
       }
       const uint32_t pix = (uint32_t)((oh0 + oh_l) * p.OW + ow0 + ow_l);
-      const size_t o0 = ((size_t)n * p.OH * p.OW + pix) * p.out_cstride + p.out_coff + 4 * g;
+      const size_t o0 = ((size_t)n * p.OH * p.OW + pix) * p.out_cstride + p.out_coff;
+      f32x4 v[4];
 #pragma unroll
       for (int ob = 0; ob < 4; ob++) {
-        if (ob * 16 >= p.OC) continue;
-        f32x4 v = acc[ob] + bias_v[ob];
+        v[ob] = acc[ob] + bias_v[ob];
         if (LEAN) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], v[e] * sl);
+          for (int e = 0; e < 4; e++) v[ob][e] = fmaxf(v[ob][e], v[ob][e] * sl);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act, p.slope);
+          for (int e = 0; e < 4; e++) v[ob][e] = apply_act(v[ob][e], p.act, p.slope);
         }
-        const size_t o = o0 + ob * 16;
-        if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-        else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v);
+      }
+#pragma unroll
+      for (int ob = 0; ob < 4; ob += 2) {
+        if (ob >= nb) continue;
+        if (ob + 1 < nb) {          // a pair of blocks: 8 consecutive channels
+          const size_t o = o0 + 32 * (ob >> 1) + 8 * g;
+          if (sizeof(TOut) == 4) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v[ob];
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o + 4) = v[ob + 1];
+          } else {
+            const u32x2 lo = cvt_bf16x4(v[ob]), hi = cvt_bf16x4(v[ob + 1]);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + o) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
+        } else {
+          const size_t o = o0 + 16 * ob + 4 * g;
+          if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v[ob];
+          else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v[ob]);
+        }
       }
     }
     if (more) store_unit(buf ^ 1);
@@ -140,6 +162,8 @@ bool plan_image(const GatherParams& p, const GatherLaunch& l) {
   for (int e = 0; e < 16; e++)
     if (p.tt.dh[e] != e / 4 - 1 || p.tt.dw[e] != e % 4 - 1 || p.tt.wtap[e] != e) return false;
   if (p.OC % 16 != 0 || p.OC > 64 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
+  // 16-byte stores of 8 channels
+  if ((reinterpret_cast<uintptr_t>(p.out) & 15u) != 0 || p.out_cstride % 8 != 0 || p.out_coff % 8 != 0) return false;
   if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
   if ((reinterpret_cast<uintptr_t>(p.bias) & 15u) != 0) return false;
   if ((long)p.IH * p.IW * p.IC >= (1l << 31)) return false;      // 32-bit offsets inside a sample
