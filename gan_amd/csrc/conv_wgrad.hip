@@ -296,13 +296,32 @@ __global__ __launch_bounds__(SW * 64) void wgrad_reduce_dense_kernel(const Wgrad
   f32x4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (ok)
-    for (int sp = wave; sp < p.splits; sp += SW) {
+  if (ok) {
+    // two slabs per step: eight loads in flight per lane (a slab at a time leaves one memory latency per slab in a row);
+    // the order of the additions is that of the slab index either way
+    int sp = wave;
+    for (; sp + SW < p.splits; sp += 2 * SW) {
+      const float* src = p.part + (size_t)sp * T * pairs + pair0 + quad * 4;
+      const float* src2 = src + (size_t)SW * T * pairs;
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        a[j] = b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tl + 4 * j < T) {
+          a[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(tl + 4 * j) * pairs);
+          b[j] = *reinterpret_cast<const f32x4*>(src2 + (size_t)(tl + 4 * j) * pairs);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) { acc[j] += a[j]; acc[j] += b[j]; }
+    }
+    for (; sp < p.splits; sp += SW) {
       const float* src = p.part + (size_t)sp * T * pairs + pair0 + quad * 4;
 #pragma unroll
       for (int j = 0; j < 4; j++)
         if (tl + 4 * j < T) acc[j] += *reinterpret_cast<const f32x4*>(src + (size_t)(tl + 4 * j) * pairs);
     }
+  }
   if (SW > 1) {
     if (wave > 0) {
 #pragma unroll
