@@ -22,7 +22,8 @@ constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 // A workgroup walks a run of consecutive rectangles (units: sample-major, then rows of rectangles, then columns): the
 // weights and the bias are fetched once, and the image loads of rectangle i + 1 are in flight while rectangle i is
 // multiplied and stored (two patch buffers, the raw floats wait in registers).
-template <typename TOut, bool LEAN>
+// NB: 16-channel blocks the kernel is built for (4: up to 64 output channels; 8: up to 128, at twice the registers)
+template <typename TOut, bool LEAN, int NB>
 __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p, int units, int units_per_wg) {
   __shared__ __attribute__((aligned(16))) uint16_t patch[2][kPH * kPW * 4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c16 = lane & 15;
@@ -38,9 +39,9 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
   auto channel_of = [&](int ob, int row) {
     return (ob | 1) < nb ? 32 * (ob >> 1) + 8 * (row >> 2) + 4 * (ob & 1) + (row & 3) : 16 * ob + row;
   };
-  bf16x8 wa[4][2];
+  bf16x8 wa[NB][2];
 #pragma unroll
-  for (int ob = 0; ob < 4; ob++)
+  for (int ob = 0; ob < NB; ob++)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const u32x4 z = {0u, 0u, 0u, 0u};
@@ -48,9 +49,9 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
       if (ob < nb) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)channel_of(ob, c16) * p.row_pitch + ks * 32 + g * 8);
       wa[ob][ks] = __builtin_bit_cast(bf16x8, v);
     }
-  f32x4 bias_v[4];
+  f32x4 bias_v[NB];
 #pragma unroll
-  for (int ob = 0; ob < 4; ob++) {
+  for (int ob = 0; ob < NB; ob++) {
     bias_v[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr && ob < nb) bias_v[ob] = *reinterpret_cast<const f32x4*>(p.bias + channel_of(ob, 4 * g));
   }
@@ -103,22 +104,22 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 #pragma unroll
     for (int grp = 0; grp < 2 * RW; grp++) {
       const int oh_l = RW * wave + (grp >> 1), ow_l = (grp & 1) * 16 + c16;
-      f32x4 acc[4];
+      f32x4 acc[NB];
 #pragma unroll
-      for (int ob = 0; ob < 4; ob++) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ob = 0; ob < NB; ob++) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
         const int pr = 2 * oh_l + 2 * ks + (g >> 1), pc = 2 * ow_l + 2 * (g & 1);
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(patch[buf] + (pr * kPW + pc) * 4);
 #pragma unroll
-        for (int ob = 0; ob < 4; ob++)
-          if (ob * 16 < p.OC) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
+        for (int ob = 0; ob < NB; ob++)
+          if (ob < nb) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
       }
       const uint32_t pix = (uint32_t)((oh0 + oh_l) * p.OW + ow0 + ow_l);
       const size_t o0 = ((size_t)n * p.OH * p.OW + pix) * p.out_cstride + p.out_coff;
-      f32x4 v[4];
+      f32x4 v[NB];
 #pragma unroll
-      for (int ob = 0; ob < 4; ob++) {
+      for (int ob = 0; ob < NB; ob++) {
         v[ob] = acc[ob] + bias_v[ob];
         if (LEAN) {
 #pragma unroll
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
         }
       }
 #pragma unroll
-      for (int ob = 0; ob < 4; ob += 2) {
+      for (int ob = 0; ob < NB; ob += 2) {
         if (ob >= nb) continue;
         if (ob + 1 < nb) {          // a pair of blocks: 8 consecutive channels
           const size_t o = o0 + 32 * (ob >> 1) + 8 * g;
@@ -154,14 +155,14 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 
 }  // namespace
 
-// Applies to: fp32 input of at most 4 dense channels, the 4x4 / stride 2 / padding 1 forward pass, up to 64 output
-// channels in multiples of 16, output extents that tile by 4 x 32, plain epilogue (bias, activation).
+// Applies to: fp32 input of at most 4 dense channels, the 4x4 / stride 2 / padding 1 forward pass, up to 128 output
+// channels in multiples of 16 (more than 64: the data gradient of a generator's image-producing transposed convolution), output extents that tile by 4 x 32, plain epilogue (bias, activation).
 bool plan_image(const GatherParams& p, const GatherLaunch& l) {
   if (l.in_bf16 || l.x3 || l.mode != kThinInput || p.ICp != 4 || p.IC > 4 || p.in_cstride != p.IC || p.in_coff != 0) return false;
   if (p.T != 16 || p.tt.n_classes != 1 || p.a != 2 || p.row_pitch != 64 || p.IH != 2 * p.OH || p.IW != 2 * p.OW) return false;
   for (int e = 0; e < 16; e++)
     if (p.tt.dh[e] != e / 4 - 1 || p.tt.dw[e] != e % 4 - 1 || p.tt.wtap[e] != e) return false;
-  if (p.OC % 16 != 0 || p.OC > 64 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
+  if (p.OC % 16 != 0 || p.OC > 128 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
   // 16-byte stores of 8 channels
   if ((reinterpret_cast<uintptr_t>(p.out) & 15u) != 0 || p.out_cstride % 8 != 0 || p.out_coff % 8 != 0) return false;
   if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
@@ -182,13 +183,15 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
   ProfScope ps("gc::conv_image_kernel", l.flops, stream);
   const bool lean = p.act == GC_ACT_NONE || p.act == GC_ACT_RELU || (p.act == GC_ACT_LRELU && p.slope >= 0.f && p.slope <= 1.f);
   const dim3 grid(blocks);
-  if (out_f32) {
-    if (lean) hipLaunchKernelGGL((conv_image_kernel<float, true>), grid, dim3(kThreads), 0, stream, p, units, per);
-    else hipLaunchKernelGGL((conv_image_kernel<float, false>), grid, dim3(kThreads), 0, stream, p, units, per);
+#define GC_IMAGE_LAUNCH(T_, L_, NB_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, NB_>), grid, dim3(kThreads), 0, stream, p, units, per)
+  if (p.OC <= 64) {
+    if (out_f32) { if (lean) GC_IMAGE_LAUNCH(float, true, 4); else GC_IMAGE_LAUNCH(float, false, 4); }
+    else { if (lean) GC_IMAGE_LAUNCH(uint16_t, true, 4); else GC_IMAGE_LAUNCH(uint16_t, false, 4); }
   } else {
-    if (lean) hipLaunchKernelGGL((conv_image_kernel<uint16_t, true>), grid, dim3(kThreads), 0, stream, p, units, per);
-    else hipLaunchKernelGGL((conv_image_kernel<uint16_t, false>), grid, dim3(kThreads), 0, stream, p, units, per);
+    if (out_f32) { if (lean) GC_IMAGE_LAUNCH(float, true, 8); else GC_IMAGE_LAUNCH(float, false, 8); }
+    else { if (lean) GC_IMAGE_LAUNCH(uint16_t, true, 8); else GC_IMAGE_LAUNCH(uint16_t, false, 8); }
   }
+#undef GC_IMAGE_LAUNCH
   return check_hip(hipGetLastError(), "conv_image launch");
 }
 
