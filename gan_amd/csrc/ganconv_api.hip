@@ -337,6 +337,7 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
     return rc;
   }
   if (plan_image(p, l)) return launch_image(p, l, out_dt == GC_F32, stream);
+  if (plan_point(p, l)) return launch_point(p, l, out_dt == GC_F32, stream);
   if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   l.big_tile_ok = true;
   plan_gather(p, l);
