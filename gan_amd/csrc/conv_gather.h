@@ -50,7 +50,7 @@ struct GatherParams {
   int64_t in_bytes, w_bytes;  // extents of the input tensor and the packed weights (LDS-DMA path: buffer ranges)
   int32_t a_bias;        // LDS-DMA path: bytes by which the activation buffer starts before `in` (most negative tap offset)
   // few-output-channel kernel (conv_scatter): patch geometry
-  int32_t sc_dh_min, sc_dw_min, sc_ph, sc_pw, sc_tiles_h, sc_tiles_w;
+  int32_t sc_dh_min, sc_dw_min, sc_ph, sc_pw, sc_tiles_h, sc_tiles_w, sc_th;
   FastDiv sc_div_oc;
   TapTable tt;
 };

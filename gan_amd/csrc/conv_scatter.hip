@@ -16,7 +16,8 @@ namespace gc {
 
 namespace {
 
-constexpr int kTH = 8, kTW = 16;     // class-local output rectangle of a workgroup
+constexpr int kTW = 16;               // class-local output rectangle of a workgroup: TH (8, or 4 where the halo of a 4 x 4
+                                     // filter makes the patch of 8 rows too large) x 16
 constexpr int kMaxPatch = 192;       // patch pixels (rows of the staged input tile)
 constexpr int kMaxRows = 64;         // (tap, oc) pairs
 constexpr int kPStride = 196;        // floats per row of P: 4 * 196 = 16 (mod 64) keeps the fragment stores conflict-free
@@ -25,8 +26,9 @@ __device__ __forceinline__ int sswz(int row) { return (row >> 1) & 7; }
 
 }  // namespace
 
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, int TH>
 __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherParams p) {
+  constexpr int kTH = TH;
   constexpr int EPC = 16 / (int)sizeof(TIn);          // elements per 16-byte source chunk
   constexpr int CPR = kBK / EPC;                      // source chunks per 64-channel row
   constexpr int RPP = kThreads / CPR;                 // rows loaded per pass
@@ -182,10 +184,12 @@ bool plan_scatter(GatherParams& p, const GatherLaunch& l) {
   }
   for (int c = 0; c < p.tt.n_classes; c++)   // phase 2 derives the class from the pixel's parity
     if (p.tt.cls_ph[c] != c / p.b || p.tt.cls_pw[c] != c % p.b) return false;
-  const int ph = (kTH - 1) * p.a + (dh1 - dh0) + 1, pw = (kTW - 1) * p.a + (dw1 - dw0) + 1;
+  const int pw = (kTW - 1) * p.a + (dw1 - dw0) + 1;
+  int th = 8, ph = (th - 1) * p.a + (dh1 - dh0) + 1;
+  if (ph * pw > kMaxPatch) { th = 4; ph = (th - 1) * p.a + (dh1 - dh0) + 1; }
   if (ph * pw > kMaxPatch) return false;
-  p.sc_dh_min = dh0; p.sc_dw_min = dw0; p.sc_ph = ph; p.sc_pw = pw;
-  p.sc_tiles_h = ((p.OH + p.b - 1) / p.b + kTH - 1) / kTH;
+  p.sc_dh_min = dh0; p.sc_dw_min = dw0; p.sc_ph = ph; p.sc_pw = pw; p.sc_th = th;
+  p.sc_tiles_h = ((p.OH + p.b - 1) / p.b + th - 1) / th;
   p.sc_tiles_w = ((p.OW + p.b - 1) / p.b + kTW - 1) / kTW;
   p.sc_div_oc = make_fastdiv((uint32_t)p.OC);
   return true;
@@ -196,7 +200,7 @@ static int launch_scatter_one(const GatherParams& p, double flops, hipStream_t s
   const int rows16 = (p.T * p.OC + 15) / 16 * 16;
   int smem = rows16 * kPStride * 4;
   if (smem < (kMaxPatch + kMaxRows) * 128) smem = (kMaxPatch + kMaxRows) * 128;
-  auto kern = conv_scatter_kernel<TIn, TOut>;
+  auto kern = p.sc_th == 8 ? conv_scatter_kernel<TIn, TOut, 8> : conv_scatter_kernel<TIn, TOut, 4>;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_scatter_kernel<%s, %s>", sizeof(TIn) == 4 ? "float" : "unsigned short",
            sizeof(TOut) == 4 ? "float" : "unsigned short");

@@ -73,3 +73,18 @@ def test_transposed_convolution_of_one_value_per_sample(gan, stride, pad, k):
                                                                    negative_slope=0.5, out_dtype=torch.float32))
     assert "gc::conv_outer_kernel" in names, sorted(names)
     assert y.shape == want.shape and torch.equal(y.double().cpu(), want)
+
+
+@pytest.mark.parametrize("cin,cout,hw,N", [(512, 1, 31, 8), (256, 2, 24, 3), (64, 3, 33, 2)])
+def test_patch_score_map_on_the_few_channel_kernel(gan, cin, cout, hw, N):
+    """The last layer of the PatchGAN discriminator, Conv2d(512 -> 1, kernel 4, stride 1, padding 1) on 31 x 31 maps
+    (Pix2Pix/models.py:221-243): the halo of a 4 x 4 filter needs the few-output-channel kernel's 4-row rectangles."""
+    g = torch.Generator().manual_seed(64)
+    x = torch.randint(-2, 3, (N, cin, hw, hw), generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin, 4, 4), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    want = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    xg = x.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y, names = _names(gan, lambda: gan.functional.conv2d(xg, w.cuda(), b.cuda(), 1, 1, out_dtype=torch.float32))
+    assert any("conv_scatter_kernel" in n for n in names), sorted(names)
+    assert torch.equal(y.double().cpu(), want)
