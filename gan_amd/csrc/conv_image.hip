@@ -23,9 +23,11 @@ constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 // weights and the bias are fetched once, and the image loads of rectangle i + 1 are in flight while rectangle i is
 // multiplied and stored (two patch buffers, the raw floats wait in registers).
 // NB: 16-channel blocks the kernel is built for (4: up to 64 output channels; 8: up to 128, at twice the registers)
-template <typename TOut, bool LEAN, int NB>
+// ICP: channels of a patch pixel (4, or 8 for 5 to 8 input channels -- the PatchGAN's image pair: a filter row per MFMA)
+template <typename TOut, bool LEAN, int NB, int ICP>
 __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p, int units, int units_per_wg) {
-  __shared__ __attribute__((aligned(16))) uint16_t patch[2][kPH * kPW * 4];
+  constexpr int NKS = ICP / 2;        // reduction steps of 32: 16 taps x ICP channels
+  __shared__ __attribute__((aligned(16))) uint16_t patch[2][kPH * kPW * ICP];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c16 = lane & 15;
   const int tiles_w = p.OW / kTW, tiles = tiles_w * (p.OH / kTH);
   const int u0 = (int)blockIdx.x * units_per_wg, u1 = min(units, u0 + units_per_wg);
@@ -39,11 +41,11 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
   auto channel_of = [&](int ob, int row) {
     return (ob | 1) < nb ? 32 * (ob >> 1) + 8 * (row >> 2) + 4 * (ob & 1) + (row & 3) : 16 * ob + row;
   };
-  bf16x8 wa[NB][2];
+  bf16x8 wa[NB][NKS];
 #pragma unroll
   for (int ob = 0; ob < NB; ob++)
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
+    for (int ks = 0; ks < NKS; ks++) {
       const u32x4 z = {0u, 0u, 0u, 0u};
       u32x4 v = z;
       if (ob < nb) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)channel_of(ob, c16) * p.row_pitch + ks * 32 + g * 8);
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
     ppr[i] = e / kPW;
     ppc[i] = e - ppr[i] * kPW;
   }
-  f32x4 raw[NP];
+  f32x4 raw[NP][ICP / 4];
   auto load_unit = [&](int u) {
     const int n = u / tiles, r = u - n * tiles, th = r / tiles_w, tw = r - th * tiles_w;
     const int ih0 = 2 * kTH * th - 1, iw0 = 2 * kTW * tw - 1;       // input coordinates of patch element (0, 0)
@@ -74,21 +76,25 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int ih = ih0 + ppr[i], iw = iw0 + ppc[i];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < ICP / 4; h++) raw[i][h] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
         const float* src = img + (uint32_t)((ih * p.IW + iw) * p.IC);
-        v[0] = src[0];
-        if (p.IC > 1) v[1] = src[1];
-        if (p.IC > 2) v[2] = src[2];
-        if (p.IC > 3) v[3] = src[3];
+        raw[i][0][0] = src[0];
+#pragma unroll
+        for (int c = 1; c < ICP; c++)
+          if (p.IC > c) raw[i][c >> 2][c & 3] = src[c];
       }
-      raw[i] = v;
     }
   };
   auto store_unit = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NP; i++)
-      if (t + i * kThreads < kPH * kPW) *reinterpret_cast<u32x2*>(patch[buf] + (t + i * kThreads) * 4) = cvt_bf16x4(raw[i]);
+      if (t + i * kThreads < kPH * kPW) {
+#pragma unroll
+        for (int h = 0; h < ICP / 4; h++)
+          *reinterpret_cast<u32x2*>(patch[buf] + (t + i * kThreads) * ICP + 4 * h) = cvt_bf16x4(raw[i][h]);
+      }
   };
 
   load_unit(u0);
@@ -108,9 +114,10 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 #pragma unroll
       for (int ob = 0; ob < NB; ob++) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        const int pr = 2 * oh_l + 2 * ks + (g >> 1), pc = 2 * ow_l + 2 * (g & 1);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(patch[buf] + (pr * kPW + pc) * 4);
+      for (int ks = 0; ks < NKS; ks++) {
+        // the 8 reduction elements of lane group g: two pixels of 4 channels (two filter rows per step), or one pixel of 8
+        const int pr = ICP == 4 ? 2 * oh_l + 2 * ks + (g >> 1) : 2 * oh_l + ks, pc = ICP == 4 ? 2 * ow_l + 2 * (g & 1) : 2 * ow_l + g;
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(patch[buf] + (pr * kPW + pc) * ICP);
 #pragma unroll
         for (int ob = 0; ob < NB; ob++)
           if (ob < nb) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
@@ -155,17 +162,21 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 
 }  // namespace
 
-// Applies to: fp32 input of at most 4 dense channels, the 4x4 / stride 2 / padding 1 forward pass, up to 128 output
+// Applies to: fp32 input of at most 4 dense channels (up to 8 with at most 64 output channels), the 4x4 / stride 2 / padding 1 forward pass, up to 128 output
 // channels in multiples of 16 (more than 64: the data gradient of a generator's image-producing transposed convolution), output extents that tile by 4 x 32, plain epilogue (bias, activation).
 bool plan_image(const GatherParams& p, const GatherLaunch& l) {
-  if (l.in_bf16 || l.x3 || l.mode != kThinInput || p.ICp != 4 || p.IC > 4 || p.in_cstride != p.IC || p.in_coff != 0) return false;
-  if (p.T != 16 || p.tt.n_classes != 1 || p.a != 2 || p.row_pitch != 64 || p.IH != 2 * p.OH || p.IW != 2 * p.OW) return false;
+  if (l.in_bf16 || l.x3 || l.mode != kThinInput || (p.ICp != 4 && p.ICp != 8) || p.IC > p.ICp || p.in_cstride != p.IC || p.in_coff != 0) return false;
+  if (p.ICp == 8 && p.OC > 64) return false;
+  if (p.T != 16 || p.tt.n_classes != 1 || p.a != 2 || p.row_pitch != 16 * p.ICp || p.IH != 2 * p.OH || p.IW != 2 * p.OW) return false;
   for (int e = 0; e < 16; e++)
     if (p.tt.dh[e] != e / 4 - 1 || p.tt.dw[e] != e % 4 - 1 || p.tt.wtap[e] != e) return false;
   if (p.OC % 16 != 0 || p.OC > 128 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
   // 16-byte stores of 8 channels
   if ((reinterpret_cast<uintptr_t>(p.out) & 15u) != 0 || p.out_cstride % 8 != 0 || p.out_coff % 8 != 0) return false;
   if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
+  // (rows of channel statistics on offer are left unwritten -- the norm layer then sweeps the output itself -- except with 5 to
+  // 8 input channels, where the general kernel, which writes them, keeps the layer)
+  if (p.ICp == 8 && p.stat_rows != nullptr) return false;
   if ((reinterpret_cast<uintptr_t>(p.bias) & 15u) != 0) return false;
   if ((long)p.IH * p.IW * p.IC >= (1l << 31)) return false;      // 32-bit offsets inside a sample
   return (long)p.N * (p.OH / kTH) * (p.OW / kTW) < (1l << 31);
@@ -183,8 +194,12 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
   ProfScope ps("gc::conv_image_kernel", l.flops, stream);
   const bool lean = p.act == GC_ACT_NONE || p.act == GC_ACT_RELU || (p.act == GC_ACT_LRELU && p.slope >= 0.f && p.slope <= 1.f);
   const dim3 grid(blocks);
-#define GC_IMAGE_LAUNCH(T_, L_, NB_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, NB_>), grid, dim3(kThreads), 0, stream, p, units, per)
-  if (p.OC <= 64) {
+#define GC_IMAGE_LAUNCH8(T_, L_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, 4, 8>), grid, dim3(kThreads), 0, stream, p, units, per)
+#define GC_IMAGE_LAUNCH(T_, L_, NB_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, NB_, 4>), grid, dim3(kThreads), 0, stream, p, units, per)
+  if (p.ICp == 8) {
+    if (out_f32) { if (lean) GC_IMAGE_LAUNCH8(float, true); else GC_IMAGE_LAUNCH8(float, false); }
+    else { if (lean) GC_IMAGE_LAUNCH8(uint16_t, true); else GC_IMAGE_LAUNCH8(uint16_t, false); }
+  } else if (p.OC <= 64) {
     if (out_f32) { if (lean) GC_IMAGE_LAUNCH(float, true, 4); else GC_IMAGE_LAUNCH(float, false, 4); }
     else { if (lean) GC_IMAGE_LAUNCH(uint16_t, true, 4); else GC_IMAGE_LAUNCH(uint16_t, false, 4); }
   } else {
@@ -192,6 +207,7 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
     else { if (lean) GC_IMAGE_LAUNCH(uint16_t, true, 8); else GC_IMAGE_LAUNCH(uint16_t, false, 8); }
   }
 #undef GC_IMAGE_LAUNCH
+#undef GC_IMAGE_LAUNCH8
   return check_hip(hipGetLastError(), "conv_image launch");
 }
 

@@ -1,4 +1,4 @@
-"""Forward pass of the critics' first layer, Conv2d(<= 4 channels -> 16 .. 128, kernel 4, stride 2, padding 1) on fp32 images
+"""Forward pass of the critics' first layer, Conv2d(<= 4 channels -> 16 .. 128 or 5 .. 8 channels -> 16 .. 64 (the PatchGAN's image pair, Pix2Pix/models.py:221-243), kernel 4, stride 2, padding 1) on fp32 images
 (BasicGANs/models.py:52-56,77), on its own kernel (gc::conv_image_kernel): every output-channel count the kernel takes (its
 channel blocks are interleaved in pairs, a last block without a partner is not), both output types, fused and plain
 activations.  Small-integer operands: every product and sum is exact, so the result must equal torch's on the CPU."""
@@ -14,7 +14,7 @@ def gan():
     return gan_amd
 
 
-@pytest.mark.parametrize("cin,cout", [(3, 64), (3, 48), (1, 32), (4, 16), (2, 64), (3, 128), (3, 96), (4, 112)])
+@pytest.mark.parametrize("cin,cout", [(3, 64), (3, 48), (1, 32), (4, 16), (2, 64), (3, 128), (3, 96), (4, 112), (6, 64), (5, 32), (8, 48)])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("activation", [None, "leaky_relu", "tanh"])
 def test_image_layer_forward_is_exact_on_small_integers(gan, cin, cout, out_dtype, activation):
