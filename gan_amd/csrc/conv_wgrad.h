@@ -26,6 +26,10 @@ struct WgradParams {
   // Several (x, gy) pairs of one layer reduced into one gradient (the passes of a training phase that all add to the
   // same weight gradient): n_seg > 1, segment g owns the splits seg_split0[g] .. seg_split0[g + 1] - 1 and K = seg_K[g].
   int32_t n_seg;
+  // Row-streaming 3x3 kernel (conv_wgrad_rows.hip): rows = 1; the reduction is dealt out in column strips of 32 pixels
+  // (strips_w per image row, total_strips over all samples of all segments, strips_per_split per workgroup) and
+  // seg_split0[g] is the first STRIP of segment g.
+  int32_t rows, strips_w, total_strips, strips_per_split;
   int32_t seg_K[kMaxWgradSegments];
   int32_t seg_split0[kMaxWgradSegments];
   const void* seg_x[kMaxWgradSegments];
@@ -79,6 +83,8 @@ int launch_wgrad_dma(const WgradParams& p, const WgradLaunch& l, hipStream_t str
 bool wgrad_image_geometry(const WgradParams& p);
 bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l);
 int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
+bool plan_wgrad_rows(WgradParams& p, const WgradLaunch& l, int n_seg, const int32_t* Ns);
+int launch_wgrad_rows(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream);
 int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream);
 

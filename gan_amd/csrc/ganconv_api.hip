@@ -661,6 +661,7 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
   if (validate(d) != GC_OK) return 0;
   WgradParams p; WgradLaunch l;
   wgrad_setup(d, p, l, true);
+  plan_wgrad_rows(p, l, 1, &d->N);
   size_t need = wgrad_need(d, p);
   if (l.dma) {
     wgrad_setup(d, p, l, false);
@@ -695,7 +696,8 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
   if (gw == nullptr || gw_strides == nullptr) { set_error("%s: null pointer", who); return GC_BAD_ARGUMENT; }
   WgradParams p; WgradLaunch l;
   wgrad_setup(d, p, l, al);
-  if (n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
+  const bool rows = plan_wgrad_rows(p, l, n_seg, Ns);
+  if (!rows && n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
   const size_t need = wgrad_need(d, p);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("%s: workspace of %zu bytes given, %zu needed", who, workspace_bytes, need);
@@ -703,11 +705,12 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
   }
   if (!aligned16(workspace)) { set_error("%s: workspace must be 16-byte aligned", who); return GC_BAD_ARGUMENT; }
   p.x = xs[0]; p.gy = gys[0]; p.part = (float*)workspace;
-  for (int g = 0; g < n_seg && n_seg > 1; g++) {
+  for (int g = 0; g < n_seg && (n_seg > 1 || rows); g++) {
     p.seg_x[g] = xs[g]; p.seg_gy[g] = gys[g];
     p.seg_x_bytes[g] = (int64_t)Ns[g] * d->H * d->W * p.x_cstride * 2;
-    p.seg_y_bytes[g] = (int64_t)p.seg_K[g] * p.y_cstride * 2;
+    p.seg_y_bytes[g] = (int64_t)Ns[g] * d->Ho * d->Wo * p.y_cstride * 2;
   }
+  if (rows) p.n_seg = n_seg;
   if (d->x_dtype != d->y_dtype && !(p.x_f32 && p.image)) {
     set_error("%s: x and gy must have one dtype (an fp32 image with a bf16 gradient is taken in the image layer's geometry only)", who);
     return GC_UNSUPPORTED_GEOMETRY;
@@ -720,7 +723,14 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
   l.aligned = p.thin ? y_vec : x_vec;
   p.y_elem = (!p.thin && x_vec && !y_vec) ? 1 : 0;
   l.flops = conv_flops(d);
-  if ((rc = l.dma ? launch_wgrad_dma(p, l, (hipStream_t)stream) : launch_wgrad(p, l, (hipStream_t)stream)) != GC_OK) return rc;
+  // an fp32 x beside a bf16 gy is converted by the image-layer kernel only: every other kernel would read it as bf16
+  if (p.x_f32 && !wgrad_image_applies(p, l)) {
+    set_error("%s: an fp32 x with a bf16 gy needs the image layer's geometry with 16-byte aligned, unsliced operands", who);
+    return GC_UNSUPPORTED_GEOMETRY;
+  }
+  if (rows) rc = launch_wgrad_rows(p, l, (hipStream_t)stream);
+  else rc = l.dma ? launch_wgrad_dma(p, l, (hipStream_t)stream) : launch_wgrad(p, l, (hipStream_t)stream);
+  if (rc != GC_OK) return rc;
   WgradReduceParams r;
   r.part = p.part; r.gw = gw;
   r.s_co = gw_strides[0]; r.s_ci = gw_strides[1]; r.s_r = gw_strides[2]; r.s_s = gw_strides[3];
@@ -767,7 +777,7 @@ size_t gc_wgrad_multi_workspace_bytes(const gc_conv_desc* d, int32_t n_seg, cons
   for (int dma = 0; dma < 2; dma++) {      // the call knows the alignment, the query covers both plans
     WgradParams p; WgradLaunch l;
     wgrad_setup(&t, p, l, dma != 0);
-    if (n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
+    if (!plan_wgrad_rows(p, l, n_seg, Ns) && n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
     const size_t b = wgrad_need(&t, p);
     if (b > need) need = b;
   }

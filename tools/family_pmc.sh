@@ -1,0 +1,31 @@
+#!/bin/bash
+# Kernel statistics and counter passes of ONE model family's training step (run on the GPU box from the repository root):
+#   tools/family_pmc.sh <tag> <family of tools/family_bench.py: stylegan | biggan | pix2pix | ...>
+# Writes gpurun_out/<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of eager steps), traffic.{json,txt}
+# (FETCH_SIZE / WRITE_SIZE passes, per kernel and launch) and sq.txt (matrix-core, wait and LDS counters per kernel).
+# Every counter pass is a run of its own; counters never share a run with a trace.
+set -e -o pipefail
+tag=$1; fam=$2
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+cmd="python3 tools/family_bench.py --only=$fam --no-cpu --full --fast --top=40"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $cmd > $out/family_table.txt 2>&1
+cp $(find $out/trace -name '*kernel_stats.csv') $out/kernel_stats.csv
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $cmd > /dev/null 2>&1
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $cmd > /dev/null 2>&1
+python3 tools/pmc_traffic.py $(find $out/fetch -name '*counter_collection.csv') $(find $out/write -name '*counter_collection.csv') $out/traffic.json > $out/traffic.txt
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
+P2="TCC_HIT_sum TCC_MISS_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+timeout -s KILL 240 rocprofv3 --pmc $P1 --output-format csv -d $out/sq1 -o p -- $cmd > /dev/null 2>&1
+timeout -s KILL 240 rocprofv3 --pmc $P2 --output-format csv -d $out/sq2 -o p -- $cmd > /dev/null 2>&1
+python3 tools/pmc_summary.py $out/sq1 $out/sq2 > $out/sq.txt
+rm -rf $out/trace $out/fetch $out/write $out/sq1 $out/sq2
+python3 - <<PY
+import csv
+rows = list(csv.DictReader(open("$out/kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel ms over the run", tot / 1e6)
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:30]:
+    print(f'{100 * float(r["TotalDurationNs"]) / tot:6.2f}%  n={int(r["Calls"]):6d}  avg={float(r["AverageNs"]) / 1e3:9.1f}us  {r["Name"][:120]}')
+PY

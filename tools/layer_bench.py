@@ -19,6 +19,10 @@ SETS = {
                (64, 32, 128, 3, 1, 1), (64, 32, 128, 1, 1, 0), (128, 32, 128, 1, 1, 0), (512, 32, 128, 1, 1, 0)],
     "big": [(256, 32, 512, 4, 2, 1), (512, 64, 512, 3, 1, 1), (128, 128, 128, 3, 1, 1), (512, 16, 512, 4, 2, 1),
             (512, 32, 512, 3, 1, 1), (256, 64, 256, 3, 1, 1), (1024, 16, 1024, 3, 1, 1)],
+    # the StyleGAN-256 layers that carry its FLOPs (run with --batch 32 --dtype bf16)
+    "sg": [(64, 256, 128, 3, 1, 1), (128, 128, 256, 3, 1, 1), (256, 64, 512, 3, 1, 1), (512, 64, 512, 3, 1, 1), (512, 32, 512, 3, 1, 1),
+           (512, 64, 256, 3, 1, 1), (256, 64, 256, 3, 1, 1), (128, 128, 128, 3, 1, 1), (64, 256, 64, 3, 1, 1), (128, 256, 128, 4, 2, 1),
+           (256, 128, 256, 4, 2, 1)],
 }
 B = a.batch
 
@@ -32,6 +36,7 @@ def timeit(fn, n=20):
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
     tot = sum(v["total_ms"] for k, v in prof.items() if "pack_weight" not in k)
+    timeit.last = {k.replace("gc::", "").replace("unsigned short", "u16"): v["total_ms"] / n * 1e3 for k, v in prof.items() if "pack_weight" not in k}
     return tot / n * 1e3
 
 def timeit_wall(fn, n=20):
@@ -54,5 +59,8 @@ for (Cin, H, Cout, k, s, p) in SETS[a.set]:
     wp = torch.nn.Parameter(w)
     t_f = timeit(lambda: ops.conv_fprop(x, wp, None, s, p, prec, key))
     t_d = timeit(lambda: ops.conv_dgrad(gy, wp, None, H, H, s, p, prec, key))
+    kf, kd = dict(timeit.last), None
     t_w = timeit(lambda: ops.conv_wgrad(x, gy, k, k, s, p, prec))
-    print(f"C{Cin:4d}->{Cout:4d} {H:3d}x{H:<3d} k{k}s{s}p{p} {flop/1e9:8.2f} GFLOP | fprop {t_f:8.1f} us {flop/t_f/1e6:7.1f} TF | dgrad {t_d:8.1f} us {flop/t_d/1e6:7.1f} TF | wgrad {t_w:8.1f} us {flop/t_w/1e6:7.1f} TF")
+    kw = dict(timeit.last)
+    print(f"C{Cin:4d}->{Cout:4d} {H:3d}x{H:<3d} k{k}s{s}p{p} {flop/1e9:8.2f} GFLOP | fprop {t_f:8.1f} us {flop/t_f/1e6:7.1f} TF | dgrad {t_d:8.1f} us {flop/t_d/1e6:7.1f} TF | wgrad {t_w:8.1f} us {flop/t_w/1e6:7.1f} TF | " +
+          " + ".join(f"{k} {v:.0f}" for k, v in kw.items()))
