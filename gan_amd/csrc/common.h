@@ -102,6 +102,12 @@ int zero_fill(void* ptr, size_t bytes, hipStream_t stream);   // bytes a multipl
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that needs more than 64 KiB, once per (kernel, device) with
+// the calling thread's current device; callable from any host thread.
+int ensure_dynamic_smem(const void* kernel, int bytes);
+// Compute units of the current device (cached per device).
+int device_cu_count();
+
 struct ProfScope {  // records a pair of events around a launch when profiling is on
   ProfScope(const char* name, double flops, hipStream_t s);
   ~ProfScope();

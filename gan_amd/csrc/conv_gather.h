@@ -93,7 +93,7 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
 // Patch-resident kernel (stride-1 gathers with >= 4 taps per class on large images, see conv_patch.hip); plan_patch
 // rewrites the tile bookkeeping in p when it accepts.
 bool plan_patch(GatherParams& p, const GatherLaunch& l);
-int launch_patch(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
+int launch_patch(GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);   // clears p.mask when it applied it
 // Persistent wave-specialised LDS-DMA kernel for mid-size layers (conv_gather_ws.hip): full channel tiles of 64 / 128,
 // 128-pixel tiles, 16-byte aligned output rows, none / ReLU / LeakyReLU epilogues.
 bool plan_ws(const GatherParams& p, const GatherLaunch& l);

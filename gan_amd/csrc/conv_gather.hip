@@ -445,13 +445,7 @@ static int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int PL = X3 ? 2 : 1;
   constexpr int smem = 2 * PL * (TO + TP) * 128 + kMaxTaps * 4;
   auto kern = conv_gather_kernel<TIn, TO, TP, X3, MODE>;
-  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&]() {
-    if (smem > 64 * 1024)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  });
-  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
+  if (smem > 64 * 1024 && ensure_dynamic_smem(reinterpret_cast<const void*>(kern), smem) != GC_OK) return GC_HIP_ERROR;
   if (p.ksplit > 1) {
     const size_t bytes = (size_t)p.N * p.OH * p.OW * p.OC * sizeof(float);
     if (zero_fill(p.out, bytes, stream) != GC_OK) return GC_HIP_ERROR;

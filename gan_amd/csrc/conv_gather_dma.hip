@@ -388,13 +388,7 @@ template <typename TOut, int TO, int TP, int STAGES, int NW, bool WS = false>
 static int launch_dma_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * (TO + TP) * 128 + kMaxTaps * 4;
   auto kern = conv_gather_dma_kernel<TOut, TO, TP, STAGES, NW, WS>;
-  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&]() {
-    if (smem > 64 * 1024)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  });
-  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
+  if (smem > 64 * 1024 && ensure_dynamic_smem(reinterpret_cast<const void*>(kern), smem) != GC_OK) return GC_HIP_ERROR;
   const unsigned nblocks = (unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_gather_dma_kernel<%s, %d, %d, %d, %d%s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, TP, STAGES,

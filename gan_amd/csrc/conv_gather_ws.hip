@@ -497,19 +497,14 @@ template <typename TOut, int TO, int STAGES, bool MASK = false, bool SPLIT = fal
 int launch_one(const WsParams& p, int grid, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * (TO + kTP) * 128 + kMaxTaps * 4;
   auto kern = conv_gather_ws_kernel<TOut, TO, STAGES, MASK, SPLIT>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&]() {
-    if (smem > 64 * 1024)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  });
-  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
+  if (smem > 64 * 1024 && ensure_dynamic_smem(reinterpret_cast<const void*>(kern), smem) != GC_OK) return GC_HIP_ERROR;
   char name[128];
   // (the demangled kernel name as a profiler prints it, plus which of its two launches a split reduction is)
   snprintf(name, sizeof(name), "gc::conv_gather_ws_kernel<%s, %d, %d, %s, %s>%s", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, STAGES,
            MASK ? "true" : "false", SPLIT ? "true" : "false", !SPLIT ? "" : (p.nsum > 0 ? " (adding the parts)" : " (split reduction)"));
+#ifdef GC_DIAG    // diagnostic build only (make DIAG=1): this block allocates and synchronises, which the shipped library never does
   static const bool stamps = getenv("GC_DIAG_STAMPS") != nullptr;
-  if (stamps) {   // diagnostic: synchronous launches with cycle stamps per workgroup, summary on stderr
+  if (stamps) {   // synchronous launches with cycle stamps per workgroup, summary on stderr
     static unsigned long long* dbuf = nullptr;
     static unsigned long long hbuf[2 * 2048 * 4];
     if (dbuf == nullptr) (void)hipMalloc(&dbuf, sizeof(hbuf));
@@ -533,6 +528,7 @@ int launch_one(const WsParams& p, int grid, double flops, hipStream_t stream) {
       return GC_OK;
     }
   }
+#endif
   ProfScope ps(name, flops, stream);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kNW * 64), smem, stream, p);
   return check_hip(hipGetLastError(), "conv_gather_ws launch");
@@ -594,7 +590,7 @@ int launch_ws(const GatherParams& g, const GatherLaunch& l, bool out_f32, hipStr
   int per_cu = (160 * 1024) / lds;
   if (per_cu > 2) per_cu = 2;
   if (per_cu < 1) per_cu = 1;
-  const int slots = force_slots ? force_slots : 256 * per_cu;
+  const int slots = force_slots ? force_slots : device_cu_count() * per_cu;
   const int rounds = (p.n_tiles + slots - 1) / slots;
   const int grid = (p.n_tiles + rounds - 1) / rounds;
   // Few tiles with long reductions (512-channel layers on 8 x 8 images and smaller: a handful of workgroups walking 128

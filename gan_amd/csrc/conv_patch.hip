@@ -3,24 +3,27 @@
 //
 // The tiled LDS-DMA kernel (conv_gather_dma.hip) re-loads a tile's pixels once per tap: a 3x3 layer moves every input
 // element into LDS nine times, and on large layers that traffic (L2 -> LDS at about 40 GB/s per CU chip-wide), not the
-// matrix cores, sets the pace.  Here a workgroup owns a 16 x 32 rectangle of one sample's (class-local) output and
-// 128 output channels.  Per 32-channel chunk it loads the rectangle's input PATCH once ((16 + dh range) x (32 + dw
+// matrix cores, sets the pace.  Here a workgroup owns an 8 x 32 rectangle of one sample's (class-local) output and TO
+// (128 or 64) output channels.  Per 32-channel chunk it loads the rectangle's input PATCH once ((8 + dh range) x (32 + dw
 // range) pixels, zeros outside the image) and forms the B operand of every tap from it at a shifted LDS address; only
-// the weights ([128 oc][32 ch] per tap, 8 KiB) stream per step.  For 3x3 that is 39 + 9 * 8 = 111 KiB per chunk
-// instead of 9 * (32 + 8) = 360 KiB on a 128 x 512 tile: 3.2x fewer bytes into LDS per FLOP.
+// the weights ([TO oc][32 ch] per tap, 8 / 4 KiB) stream, one tap per step.
 //
-// Pipeline: a step is one chunk x TS taps (TS = 3 for nine taps, 2 for four: 96 / 64 MFMAs per wave between two
-// barriers); weights go through a 3-slot ring (two steps in flight), the patch is double-buffered and the next
-// chunk's patch is issued at the first step of the current one.  All loads are LDS-DMA
-// with buffer addressing (per-lane offsets fixed, chunk / tap moves only the scalar offset, masked lanes take an
-// out-of-range offset and receive zeros).  LDS rows are 64 bytes (32 channels); the 16-byte chunk position is XORed
-// with (row >> 1) & 3 on the source side: with the lane groups a ds_read_b128 is served in, the fragments of 16
-// consecutive rows starting anywhere are then conflict-free (modelled in tools/lds_conflicts.py).
-// 8 waves; wave w computes all 128 channels for rows 2w, 2w + 1 of the rectangle (64 pixels): 32 MFMAs per tap
-// against 8 + 4 fragment reads.
+// Two workgroups of four waves share a CU (76 KiB of LDS, at most 256 registers).  They are independent, so one's fixed
+// parts -- argument reads, the first patch, the output stores, the barrier of every step -- run beside the other's
+// MFMAs; an earlier form with one workgroup of eight waves on a 16 x 32 rectangle per CU spent 1.5-4x the MFMA time per
+// rectangle on layers with few chunks (64 -> 128 at 256 x 256: 506 TFLOP/s).
+//
+// Pipeline: weights go through a 4-slot ring (three steps in flight), the patch is double-buffered and the next
+// chunk's patch is issued at the first step of the current one.  All loads are LDS-DMA with buffer addressing (per-lane
+// offsets fixed, chunk / tap moves only the scalar offset, masked lanes take an out-of-range offset and receive zeros);
+// past the last step the cursor keeps issuing out-of-range loads into free slots so that the counted waits stay uniform.
+// LDS rows are 64 bytes (32 channels); the 16-byte chunk position is XORed with (row >> 1) & 3 on the source side: with
+// the lane groups a ds_read_b128 is served in, the fragments of 16 consecutive rows starting anywhere are then
+// conflict-free (modelled in tools/lds_conflicts.py).  Wave w computes all TO channels for rows 2w, 2w + 1 of the
+// rectangle (64 pixels): TO / 4 MFMAs per tap against TO / 16 + 4 fragment reads.
+// Weight rows are permuted inside groups of 32 (oc_of_row) so that a lane's two MFMA blocks of a group hold 8
+// consecutive channels of a pixel: one 16-byte store per (pixel, 8 channels) in bf16.
 #include <stdio.h>
-
-#include <mutex>
 
 #include "conv_gather.h"
 
@@ -29,27 +32,35 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr uint32_t kOutOfRange = 0x80000000u;
-constexpr int kTH = 16, kTW = 32, kTO = 128, kCK = 32;     // rectangle, channel tile, channels per chunk
-constexpr int kNW = 8;                                      // waves
-constexpr int kMaxPatch = 640;                              // pixels (40 DMA instructions of 16 pixels)
-constexpr int kPJ = 5;                                      // patch DMA instructions per wave per chunk (8 * 5 = 40)
-constexpr int kPatchBytes = kNW * kPJ * 1024;               // 40 KiB per buffer
-constexpr int kWBytes = kTO * kCK * 2;                      // 8 KiB per tap
-constexpr int kWSlots = 3;
-constexpr int smem_bytes(int ts) { return 2 * kPatchBytes + kWSlots * ts * kWBytes + kMaxTaps * 4; }
+constexpr int kTH = 8, kTW = 32, kCK = 32;                 // rectangle, channels per chunk
+constexpr int kNW = 4;                                      // waves
+constexpr int kPInstr = 22;                                 // patch DMA instructions of 16 pixels per chunk
+constexpr int kMaxPatch = kPInstr * 16;                     // 352 pixels
+constexpr int kPatchBytes = kPInstr * 1024;                 // 22 KiB per buffer
+constexpr int kWSlots = 4;
+constexpr int smem_bytes(int to) { return 2 * kPatchBytes + kWSlots * to * kCK * 2 + kMaxTaps * 4; }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
-template <typename TOut, int TS>
-__global__ __launch_bounds__(kNW * 64) void conv_patch_kernel(const GatherParams p) {
+// channel (relative to the tile) held by the weight row at LDS row `row`: MFMA block f = row >> 4, accumulator row
+// 4 g + e  <->  channel 32 (f >> 1) + 8 g + 4 (f & 1) + e
+__device__ __forceinline__ int oc_of_row(int row) {
+  const int f = (row >> 4) & 1, g = (row >> 2) & 3, e = row & 3;
+  return (row & ~31) + 8 * g + 4 * f + e;
+}
+
+template <typename TOut, int TO, bool MASK>
+__global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherParams p) {
+  constexpr int FO = TO / 16;              // MFMA blocks of output channels
+  constexpr int WJ = TO / 64;              // weight DMA instructions per wave and step
+  constexpr int kWBytes = TO * kCK * 2;    // one tap
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kSlot = TS * kWBytes;
   char* patch_base = smem;
   char* w_base = smem + 2 * kPatchBytes;
-  int* tap_lds = reinterpret_cast<int*>(w_base + kWSlots * kSlot);
+  int* tap_lds = reinterpret_cast<int*>(w_base + kWSlots * kWBytes);
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -62,7 +73,7 @@ __global__ __launch_bounds__(kNW * 64) void conv_patch_kernel(const GatherParams
   const uint32_t nblocks = (uint32_t)p.n_pix_tiles * (uint32_t)p.n_oc_tiles;
   const uint32_t lid = xcd_remap(blockIdx.x, nblocks);
   const int pix_tile = lid / p.n_oc_tiles;
-  const int oc0 = (lid % p.n_oc_tiles) * kTO;
+  const int oc0 = (lid % p.n_oc_tiles) * TO;
   int cls = 0;
 #pragma unroll
   for (int c = 1; c < kMaxClasses; c++)
@@ -88,11 +99,13 @@ __global__ __launch_bounds__(kNW * 64) void conv_patch_kernel(const GatherParams
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wp), 0, (int)p.w_bytes, 0x00020000);
 
-  // ---- per-lane source offsets: patch instruction j of this wave covers patch pixels 16 (j * 8 + wave) .. + 15
-  uint32_t a_off[kPJ];
-  int a_chunk[kPJ];
+  // ---- per-lane source offsets: patch instruction j * 4 + wave covers patch pixels 16 (j * 4 + wave) .. + 15
+  // (waves 0 and 1 issue six, waves 2 and 3 five of the 22 instructions)
+  const int npi = wave < 2 ? 6 : 5;
+  uint32_t a_off[6];
+  int a_chunk[6];
 #pragma unroll
-  for (int j = 0; j < kPJ; j++) {
+  for (int j = 0; j < 6; j++) {
     const int px = 16 * (j * kNW + wave) + (lane >> 2);
     const int pos = lane & 3;
     const int chunk = pos ^ ((px >> 1) & 3);
@@ -102,39 +115,39 @@ __global__ __launch_bounds__(kNW * 64) void conv_patch_kernel(const GatherParams
     a_chunk[j] = ok ? chunk * 8 : (1 << 30);     // a masked lane fails the channel check of every chunk
     a_off[j] = (uint32_t)((((size_t)n * p.IH + (ok ? ih : 0)) * p.IW + (ok ? iw : 0)) * p.in_cstride + p.in_coff + chunk * 8) * 2u;
   }
-  uint32_t w_voff;
-  {
-    const int row = wave * 16 + (lane >> 2), pos = lane & 3;
-    const int oc = oc0 + row;
-    w_voff = oc < p.OC ? (uint32_t)(((size_t)oc * p.row_pitch + (pos ^ ((row >> 1) & 3)) * 8) * 2) : kOutOfRange;
+  uint32_t w_voff[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; j++) {
+    const int row = (wave * WJ + j) * 16 + (lane >> 2), pos = lane & 3;
+    const int oc = oc0 + oc_of_row(row);
+    w_voff[j] = oc < p.OC ? (uint32_t)(((size_t)oc * p.row_pitch + (pos ^ ((row >> 1) & 3)) * 8) * 2) : kOutOfRange;
   }
 
   const int nchunks = p.ICp / kCK;
-  const int spc = T / TS;                 // steps per chunk
-  const int nsteps = nchunks * spc;
+  const int nsteps = nchunks * T;
 
   auto issue_patch = [&](int c) {
     char* pb = patch_base + (c & 1) * kPatchBytes;
     const int c0 = c * kCK;
 #pragma unroll
-    for (int j = 0; j < kPJ; j++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(pb + (j * kNW + wave) * 1024), 16,
-                                               (int)((c0 + a_chunk[j]) < p.IC ? a_off[j] : kOutOfRange), c0 * 2, 0, 0);
+    for (int j = 0; j < 6; j++)
+      if (j < 5 || npi == 6)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(pb + (j * kNW + wave) * 1024), 16,
+                                                 (int)((c0 + a_chunk[j]) < p.IC ? a_off[j] : kOutOfRange), c0 * 2, 0, 0);
   };
-  // weights of step (chunk c, tap group gi): TS taps of [128 oc][32 ch]
-  auto issue_w = [&](int slot, int c, int gi) {
+  // weights of step (chunk c, tap ti): [TO oc][32 ch]; steps past the last one load zeros (uniform wait counts)
+  auto issue_w = [&](int slot, int c, int ti, bool live) {
+    const int e = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + ti]);
+    const uint32_t soff = (uint32_t)(((e >> 16) * p.ICp + c * kCK) * 2);
 #pragma unroll
-    for (int k = 0; k < TS; k++) {
-      const int e = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + gi * TS + k]);
-      const uint32_t soff = (uint32_t)(((e >> 16) * p.ICp + c * kCK) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(w_base + slot * kSlot + k * kWBytes + wave * 1024), 16, (int)w_voff,
-                                               (int)soff, 0, 0);
-    }
+    for (int j = 0; j < WJ; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(w_base + slot * kWBytes + (wave * WJ + j) * 1024), 16,
+                                               (int)(live ? w_voff[j] : kOutOfRange), (int)(live ? soff : 0u), 0, 0);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[FO][4];
 #pragma unroll
-  for (int i = 0; i < 8; i++)
+  for (int i = 0; i < FO; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -142,72 +155,70 @@ __global__ __launch_bounds__(kNW * 64) void conv_patch_kernel(const GatherParams
   int base_idx[4];
 #pragma unroll
   for (int pg = 0; pg < 4; pg++) base_idx[pg] = (2 * wave + (pg >> 1)) * PW + (pg & 1) * 16 + c16;
-  // weight fragment offsets inside a tap's [128][32] tile
-  int a_addr[8];
+  // weight fragment offsets inside a tap's [TO][32] tile
+  int a_addr[FO];
 #pragma unroll
-  for (int ob = 0; ob < 8; ob++) {
+  for (int ob = 0; ob < FO; ob++) {
     const int row = ob * 16 + c16;
     a_addr[ob] = row * 64 + ((g ^ ((row >> 1) & 3)) << 4);
   }
 
-  auto compute = [&](int slot, int c, int gi) {
+  auto compute = [&](int slot, int c, int ti) {
     const char* pb = patch_base + (c & 1) * kPatchBytes;
+    const char* wb = w_base + slot * kWBytes;
+    const int e = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + ti]);
+    const int toff = ((int)(int8_t)(e & 0xff) - dh_min) * PW + ((int)(int8_t)((e >> 8) & 0xff) - dw_min);
+    bf16x8 b[4], a[FO];
 #pragma unroll
-    for (int k = 0; k < TS; k++) {
-      const char* wb = w_base + slot * kSlot + k * kWBytes;
-      const int e = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + gi * TS + k]);
-      const int toff = ((int)(int8_t)(e & 0xff) - dh_min) * PW + ((int)(int8_t)((e >> 8) & 0xff) - dw_min);
-      bf16x8 b[4], a[8];
-#pragma unroll
-      for (int pg = 0; pg < 4; pg++) {
-        const int idx = base_idx[pg] + toff;
-        b[pg] = *reinterpret_cast<const bf16x8*>(pb + idx * 64 + ((g ^ ((idx >> 1) & 3)) << 4));
-      }
-#pragma unroll
-      for (int ob = 0; ob < 8; ob++) a[ob] = *reinterpret_cast<const bf16x8*>(wb + a_addr[ob]);
-#pragma unroll
-      for (int ob = 0; ob < 8; ob++)
-#pragma unroll
-        for (int pg = 0; pg < 4; pg++) acc[ob][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ob], b[pg], acc[ob][pg], 0, 0, 0);
+    for (int pg = 0; pg < 4; pg++) {
+      const int idx = base_idx[pg] + toff;
+      b[pg] = *reinterpret_cast<const bf16x8*>(pb + idx * 64 + ((g ^ ((idx >> 1) & 3)) << 4));
     }
+#pragma unroll
+    for (int ob = 0; ob < FO; ob++) a[ob] = *reinterpret_cast<const bf16x8*>(wb + a_addr[ob]);
+#pragma unroll
+    for (int ob = 0; ob < FO; ob++)
+#pragma unroll
+      for (int pg = 0; pg < 4; pg++) acc[ob][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ob], b[pg], acc[ob][pg], 0, 0, 0);
   };
 
-  // ---- prologue: patch 0, then the weights of steps 0 and 1
+  // ---- prologue: patch 0, then the weights of steps 0 .. 2
   issue_patch(0);
-  int ic = 0, igi = 0, islot = 0;     // (chunk, tap group, ring slot) of the next weight step to issue
-  int issued = 0;
-  for (int s = 0; s < kWSlots - 1 && issued < nsteps; s++) {
-    issue_w(islot, ic, igi);
+  int ic = 0, iti = 0, islot = 0, issued = 0;     // (chunk, tap, ring slot) of the next weight step to issue
+  auto issue_next_w = [&]() {
+    issue_w(islot, ic, iti, issued < nsteps);
     issued++;
-    islot = islot + 1 == kWSlots ? 0 : islot + 1;
-    if (++igi == spc) { igi = 0; ic++; }
-  }
+    islot = (islot + 1) & (kWSlots - 1);
+    if (++iti == T) { iti = 0; ic++; }
+  };
+#pragma unroll
+  for (int s = 0; s < kWSlots - 1; s++) issue_next_w();
   // ---- steps
-  int cc = 0, cgi = 0, cslot = 0;     // (chunk, tap group, ring slot) of the step being computed
+  int cc = 0, cti = 0, cslot = 0;     // (chunk, tap, ring slot) of the step being computed
   for (int s = 0; s < nsteps; s++) {
-    // Loads younger than the weights of step s: the next step's weights, plus the next chunk's patch when it went out
-    // at the previous step (step 0 of this chunk).  The patch of THIS chunk went out a whole chunk earlier: older.
-    if (s + 1 >= nsteps) wait_vmcnt<0>();
-    else if (cgi == 1 && cc + 1 < nchunks) wait_vmcnt<TS + kPJ>();
-    else wait_vmcnt<TS>();
-    __builtin_amdgcn_s_barrier();        // step s has landed for every wave; the previous step's slot and the other patch buffer are free
-    __builtin_amdgcn_sched_barrier(0);
-    if (cgi == 0 && cc + 1 < nchunks) issue_patch(cc + 1);
-    if (issued < nsteps) {
-      issue_w(islot, ic, igi);
-      issued++;
-      islot = islot + 1 == kWSlots ? 0 : islot + 1;
-      if (++igi == spc) { igi = 0; ic++; }
+    // Younger than the weights of step s: the weights of steps s + 1 and s + 2, and the next chunk's patch when it went
+    // out at one of the two previous steps (i.e. this is tap 1 or 2 of a chunk that has a successor).
+    if ((cti == 1 || cti == 2) && cc + 1 < nchunks) {
+      if (npi == 6) wait_vmcnt<2 * WJ + 6>(); else wait_vmcnt<2 * WJ + 5>();
+    } else {
+      wait_vmcnt<2 * WJ>();
     }
-    compute(cslot, cc, cgi);
-    cslot = cslot + 1 == kWSlots ? 0 : cslot + 1;
-    if (++cgi == spc) { cgi = 0; cc++; }
+    __builtin_amdgcn_s_barrier();        // step s has landed for every wave; the slot of step s - 1 and the other patch buffer are free
+    __builtin_amdgcn_sched_barrier(0);
+    if (cti == 0 && cc + 1 < nchunks) issue_patch(cc + 1);
+    issue_next_w();
+    compute(cslot, cc, cti);
+    cslot = (cslot + 1) & (kWSlots - 1);
+    if (++cti == T) { cti = 0; cc++; }
     __builtin_amdgcn_sched_barrier(0);
   }
+  wait_vmcnt<0>();                       // the zero-filling tail loads target this workgroup's LDS: let them land
 
-  // ---- epilogue: lane owns 4 consecutive channels of one pixel per (channel block, pixel group)
+  // ---- epilogue: per (pixel group, group of 32 channels) a lane owns 8 consecutive channels of one pixel
   TOut* out = reinterpret_cast<TOut*>(p.out);
-  const bool vec_ok = p.out_vec != 0;
+  const bool vec8 = p.out_vec8 != 0;
+  const bool lean = p.act == GC_ACT_NONE || p.act == GC_ACT_RELU || p.act == GC_ACT_LRELU;
+  const float ls = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);
 #pragma unroll
   for (int pg = 0; pg < 4; pg++) {
     const int oh = th_ * kTH + 2 * wave + (pg >> 1), ow = tw_ * kTW + (pg & 1) * 16 + c16;
@@ -215,45 +226,85 @@ __global__ __launch_bounds__(kNW * 64) void conv_patch_kernel(const GatherParams
     const size_t pix = ((size_t)n * p.OH + (oh * p.b + p.tt.cls_ph[cls])) * p.OW + (ow * p.b + p.tt.cls_pw[cls]);
     TOut* dst = out + pix * p.out_cstride + p.out_coff;
 #pragma unroll
-    for (int ob = 0; ob < 8; ob++) {
-      const int oc = oc0 + ob * 16 + g * 4;
-      float v[4];
+    for (int m = 0; m < FO / 2; m++) {
+      const int oc = oc0 + 32 * m + 8 * g;
+      float v[8];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float x = acc[ob][pg][r];
-        if (p.bias != nullptr && oc + r < p.OC) x += p.bias[oc + r];
-        v[r] = apply_act(x, p.act, p.slope);
-      }
-      if (vec_ok && oc + 3 < p.OC) {
-        if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
-        else *reinterpret_cast<u32x2*>(dst + oc) = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+      for (int r = 0; r < 4; r++) { v[r] = acc[2 * m][pg][r]; v[4 + r] = acc[2 * m + 1][pg][r]; }
+      if (vec8 && oc + 7 < p.OC) {
+        if (p.bias != nullptr) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + oc), b1 = *reinterpret_cast<const f32x4*>(p.bias + oc + 4);
+#pragma unroll
+          for (int r = 0; r < 4; r++) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+        }
+        if (lean) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r] * ls);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; r++) v[r] = apply_act(v[r], p.act, p.slope);
+        }
+        if (MASK) {
+          const TOut* mk = reinterpret_cast<const TOut*>(p.mask) + pix * p.out_cstride + p.out_coff + oc;
+          float mv[8];
+          if (sizeof(TOut) == 4) {
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(mk), m1 = *reinterpret_cast<const f32x4*>(mk + 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) { mv[r] = m0[r]; mv[4 + r] = m1[r]; }
+          } else {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(mk);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              mv[2 * r] = __builtin_bit_cast(float, q[r] << 16);
+              mv[2 * r + 1] = __builtin_bit_cast(float, q[r] & 0xffff0000u);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; r++) v[r] = mv[r] > 0.f ? v[r] : v[r] * p.mask_slope;
+        }
+        if (sizeof(TOut) == 4) {
+          *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst + oc + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          const u32x2 lo = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]}), hi = cvt_bf16x4(f32x4{v[4], v[5], v[6], v[7]});
+          *reinterpret_cast<u32x4*>(dst + oc) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 8; r++)
           if (oc + r < p.OC) {
-            if (sizeof(TOut) == 4) reinterpret_cast<float*>(dst)[oc + r] = v[r];
-            else reinterpret_cast<uint16_t*>(dst)[oc + r] = float_to_bf16_bits(v[r]);
+            float x = v[r];
+            if (p.bias != nullptr) x += p.bias[oc + r];
+            x = apply_act(x, p.act, p.slope);
+            if (sizeof(TOut) == 4) reinterpret_cast<float*>(dst)[oc + r] = x;
+            else reinterpret_cast<uint16_t*>(dst)[oc + r] = float_to_bf16_bits(x);
           }
       }
     }
   }
 }
 
-template <typename TOut, int TS>
+template <typename TOut, int TO, bool MASK>
 int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
-  constexpr int kSmem = smem_bytes(TS);
-  auto kern = conv_patch_kernel<TOut, TS>;
-  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&]() {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-  });
-  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
+  constexpr int kSmem = smem_bytes(TO);
+  auto kern = conv_patch_kernel<TOut, TO, MASK>;
+  if (ensure_dynamic_smem(reinterpret_cast<const void*>(kern), kSmem) != GC_OK) return GC_HIP_ERROR;
   char name[96];
-  snprintf(name, sizeof(name), "gc::conv_patch_kernel<%s, %d>", sizeof(TOut) == 4 ? "float" : "unsigned short", TS);
+  snprintf(name, sizeof(name), "gc::conv_patch_kernel<%s, %d, %s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, MASK ? "true" : "false");
   ProfScope ps(name, flops, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles), dim3(kNW * 64), kSmem, stream, p);
   return check_hip(hipGetLastError(), "conv_patch launch");
+}
+
+template <typename TOut, int TO>
+int launch_mask(const GatherParams& p, double flops, bool mask, hipStream_t stream) {
+  return mask ? launch_one<TOut, TO, true>(p, flops, stream) : launch_one<TOut, TO, false>(p, flops, stream);
+}
+
+int patch_to(const GatherParams& p) {
+  static const bool no64 = getenv("GC_PATCH_NO64") != nullptr;
+  if (p.OC >= 128) return 128;
+  return (p.OC >= 64 && !no64) ? 64 : 0;
 }
 
 }  // namespace
@@ -262,14 +313,14 @@ int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
 // prefix, tile counts) by its own.  The caller has established: bf16 input, 16-byte aligned channel slices, both
 // tensors below 2 GiB, no reduction split.
 bool plan_patch(GatherParams& p, const GatherLaunch& l) {
-  if (!l.in_bf16 || l.mode != kVecLoads || p.a != 1 || p.OC < kTO || p.ICp % kCK != 0) return false;
+  const int to = patch_to(p);
+  if (!l.in_bf16 || l.mode != kVecLoads || p.a != 1 || to == 0 || p.ICp % kCK != 0) return false;
   if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
   long tiles = 0;
   int starts[kMaxClasses + 1];
   for (int c = 0; c < p.tt.n_classes; c++) {
     const int t0 = p.tt.cls_tap_start[c], t1 = p.tt.cls_tap_start[c + 1];
-    const int ts = (p.tt.cls_tap_start[1] - p.tt.cls_tap_start[0]) % 3 == 0 ? 3 : 2;   // taps per step, from class 0
-    if ((t1 - t0) % ts != 0 || (t1 - t0) / ts < 2) return false;   // the wait counts assume at least two steps per chunk
+    if (t1 - t0 < 4) return false;       // the wait counts assume that a chunk's patch has three steps to land
     int dh_min = 127, dh_max = -128, dw_min = 127, dw_max = -128;
     for (int e = t0; e < t1; e++) {
       dh_min = p.tt.dh[e] < dh_min ? p.tt.dh[e] : dh_min; dh_max = p.tt.dh[e] > dh_max ? p.tt.dh[e] : dh_max;
@@ -281,7 +332,7 @@ bool plan_patch(GatherParams& p, const GatherLaunch& l) {
     starts[c] = (int)tiles;
     tiles += (long)p.N * (oh / kTH) * (ow / kTW);
   }
-  const int n_oc_tiles = (p.OC + kTO - 1) / kTO;
+  const int n_oc_tiles = (p.OC + to - 1) / to;
   if (tiles * n_oc_tiles < 512 || tiles * n_oc_tiles >= (1l << 31)) return false;   // fewer: the tiled kernels fill the chip better
   for (int c = 0; c < p.tt.n_classes; c++) p.tt.cls_tile_start[c] = starts[c];
   for (int c = p.tt.n_classes; c <= kMaxClasses; c++) p.tt.cls_tile_start[c] = (int)tiles;
@@ -291,11 +342,15 @@ bool plan_patch(GatherParams& p, const GatherLaunch& l) {
   return true;
 }
 
-int launch_patch(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
+// Applies p.mask itself (and clears it) when the 16-byte store path holds for every lane; otherwise the caller's sweep does.
+int launch_patch(GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
   if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
-  if ((p.tt.cls_tap_start[1] - p.tt.cls_tap_start[0]) % 3 == 0)
-    return out_f32 ? launch_one<float, 3>(p, l.flops, stream) : launch_one<uint16_t, 3>(p, l.flops, stream);
-  return out_f32 ? launch_one<float, 2>(p, l.flops, stream) : launch_one<uint16_t, 2>(p, l.flops, stream);
+  const bool mask = p.mask != nullptr && p.out_vec8 && p.OC % 8 == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 15u) == 0;
+  int rc;
+  if (patch_to(p) == 128) rc = out_f32 ? launch_mask<float, 128>(p, l.flops, mask, stream) : launch_mask<uint16_t, 128>(p, l.flops, mask, stream);
+  else rc = out_f32 ? launch_mask<float, 64>(p, l.flops, mask, stream) : launch_mask<uint16_t, 64>(p, l.flops, mask, stream);
+  if (mask) p.mask = nullptr;
+  return rc;
 }
 
 }  // namespace gc

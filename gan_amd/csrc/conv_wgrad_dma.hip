@@ -242,13 +242,7 @@ template <int TO, int STAGES>
 static int launch_dma_one(const WgradParams& p, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * kStepPix * (TO + kTC) * 2;
   auto kern = conv_wgrad_dma_kernel<TO, STAGES>;
-  static std::once_flag once;            // (launches come from several host threads: the autograd engine's workers)
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&]() {
-    if (smem > 64 * 1024)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  });
-  if (check_hip(attr_err, "hipFuncSetAttribute")) return GC_HIP_ERROR;
+  if (smem > 64 * 1024 && ensure_dynamic_smem(reinterpret_cast<const void*>(kern), smem) != GC_OK) return GC_HIP_ERROR;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_wgrad_dma_kernel<%d, %d>", TO, STAGES);
   ProfScope ps(name, flops, stream);

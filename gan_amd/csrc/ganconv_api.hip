@@ -30,6 +30,35 @@ int check_hip(hipError_t e, const char* what) {
   return GC_HIP_ERROR;
 }
 
+// ---- per-device set-up ----------------------------------------------------------------------------------
+constexpr int kMaxDev = 64;
+static std::mutex g_attr_mu;
+static std::vector<const void*> g_attr_done[kMaxDev];
+
+int ensure_dynamic_smem(const void* kernel, int bytes) {
+  int dev = -1;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return GC_HIP_ERROR;
+  if (dev < 0 || dev >= kMaxDev) { set_error("device index %d out of range", dev); return GC_BAD_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  for (const void* k : g_attr_done[dev])
+    if (k == kernel) return GC_OK;
+  if (check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute")) return GC_HIP_ERROR;
+  g_attr_done[dev].push_back(kernel);
+  return GC_OK;
+}
+
+int device_cu_count() {
+  static std::atomic<int> cus[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 // ---- profiling ----------------------------------------------------------------------------------------
 struct ProfRec {
   std::string name;

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Developer tool: in-kernel cycle stamps (prologue / main loop / epilogue) of the LDS-DMA gather kernel per layer.
+# Needs the diagnostic build of the library: make -C gan_amd/csrc clean && make -C gan_amd/csrc DIAG=1 (the shipped build
+# has no allocating / synchronising code path).
 mkdir -p gpurun_out
 out=gpurun_out/diag_stamps.txt
 : > $out
