@@ -13,8 +13,11 @@ pass, fake pass, gradient-penalty double backward, Adam step) + 1 generator iter
                traffic = HBM bytes per launch of that kernel recorded by separate rocprofv3 counter passes
   cpu_baseline the same cycle on the host CPU through the oracle's restatement of the reference (stock torch
                CPU ops), rank 0 and N=1 only
-  families     (N=1) images/s of one training step of the other model families at the reference's per-GPU sizes, each
-               replayed as one HIP graph: DCGAN-64 batch 128, Pix2Pix-256 batch 8, StyleGAN-256 batch 32; not part of `value`
+  families     (N=1) images/s of one TRAINING step (both phases, both Adam steps, the generator's moving average) of the other
+               model families at the reference's per-GPU sizes, each replayed as one HIP graph: DCGAN-64 batch 128, Pix2Pix-256
+               batch 8 and 64, StyleGAN-256 batch 32, BigGAN-128 batch 256; not part of `value`
+
+    python bench.py --family stylegan256_b32 [--gpus N]      that family's training step as the benchmarked step
 """
 import argparse
 import json
@@ -55,15 +58,42 @@ def cpu_baseline(threads):
             "seconds": dt}
 
 
-def families(device, steps=8):
-    """{name: {"img_per_s", "ms_per_step", "batch", "what"}} for the steps of gan_amd.harness.steps, each one HIP graph."""
+def _dominant(prof, dt):
+    """Dominant conv kernel of a profiled eager step (library event timer) and the step's algorithmic conv FLOP rate."""
+    conv = {k: v for k, v in prof.items() if v["flops"] > 0}
+    if not conv:
+        return {}
+    dom = max(conv, key=lambda k: conv[k]["total_ms"])
+    tf = conv[dom]["flops"] / (conv[dom]["total_ms"] * 1e-3) / 1e12
+    flops = sum(v["flops"] for v in conv.values())
+    return {"dominant_kernel": dom, "dominant_kernel_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS, "dominant_kernel_launches": conv[dom]["launches"],
+            "dominant_kernel_avg_us": 1e3 * conv[dom]["total_ms"] / conv[dom]["launches"],
+            "conv_gflop_per_step": flops / 1e9, "step_tflops": flops / dt / 1e12,
+            "library_kernel_ms_per_step": sum(v["total_ms"] for v in prof.values())}
+
+
+def _family_traffic(name, dt):
+    """HBM bytes per step of a family from separate rocprofv3 --pmc passes (tools/family_pmc.sh; FETCH_SIZE doubled as the
+    gfx950 guide prescribes, summed over every kernel of an eager step), divided by the step time measured here."""
+    path = os.path.join(ROOT, "bench_family_traffic.json")
+    if not os.path.exists(path):
+        return None
+    b = json.load(open(path)).get(name, {}).get("hbm_bytes_per_step")
+    return None if b is None else b / dt / 1e9
+
+
+def families(device, steps=8, only=None):
+    """{name: {...}} for the training steps of gan_amd.harness.steps (both phases, both Adam steps, the generator's moving
+    average), each replayed as one HIP graph; then one eager pass under the library's event timer."""
     import gan_amd
     from gan_amd import _lib
     from gan_amd.harness import steps as S
     out = {}
     for name, make in S.FAMILIES.items():
+        if only is not None and name not in only:
+            continue
         try:
-            step, batch, what = make(device)
+            step = make(device)
             g = gan_amd.GraphedStep(step)
             for _ in range(2):
                 g()
@@ -73,28 +103,93 @@ def families(device, steps=8):
                 g()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
-            out[name] = {"img_per_s": batch / dt, "ms_per_step": 1e3 * dt, "batch": batch, "what": what, "hip_graph": True}
-            # one eager pass with the library's event timer: algorithmic conv FLOPs of a step and the dominant conv kernel
+            losses = step.losses.detach().float().cpu().tolist()
+            out[name] = {"img_per_s": step.batch / dt, "ms_per_step": 1e3 * dt, "batch": step.batch, "what": step.what, "hip_graph": True,
+                         "optimizer_steps": True, "losses": losses, "losses_finite": all(x == x and abs(x) != float("inf") for x in losses)}
             _lib.profile_enable(True)
             step()
             torch.cuda.synchronize()
             prof = _lib.profile_collect()
             _lib.profile_enable(False)
-            conv = {k: v for k, v in prof.items() if v["flops"] > 0}
-            if conv:
-                dom = max(conv, key=lambda k: conv[k]["total_ms"])
-                tf = conv[dom]["flops"] / (conv[dom]["total_ms"] * 1e-3) / 1e12
-                flops = sum(v["flops"] for v in conv.values())
-                out[name].update({"dominant_kernel": dom, "dominant_kernel_tflops": tf, "frac": tf / PEAK_BF16_TFLOPS,
-                                  "conv_gflop_per_step": flops / 1e9, "step_tflops": flops / dt / 1e12,
-                                  "library_kernel_ms_per_step": sum(v["total_ms"] for v in prof.values()),
-                                  "hbm_gb_s": None})      # (no byte counters in this run: rocprofv3 --pmc passes are separate)
+            out[name].update(_dominant(prof, dt))
+            out[name]["hbm_gb_s"] = _family_traffic(name, dt)
             del g, step
         except Exception as e:      # a family that fails does not take the headline line with it
             out[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
     S.reset_options()
     return out
+
+
+def family_main(a, rank, local_rank, world):
+    """bench.py --family NAME [--gpus N]: the training step of one of the other model families as the benchmarked step.  One
+    rank: the step replayed as one HIP graph.  N ranks (torch.distributed.run): every rank runs the step eagerly on its own
+    batch (weak scaling), gradients averaged over the ranks by gan_amd.ddp.GradReducer, whose bucket all-reduces (RCCL)
+    start from autograd hooks during the last backward pass of each phase and are waited for before the optimizer step."""
+    import torch.distributed as dist
+    import gan_amd
+    from gan_amd import _lib
+    from gan_amd.ddp import GradReducer
+    from gan_amd.harness import steps as S
+    device = f"cuda:{local_rank}"
+    distributed = world > 1 or a.force_reducer
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    step = S.FAMILIES[a.family](device, reducer_factory=GradReducer if distributed else None)
+    if distributed:
+        for t in step.parameters() + step.buffers():
+            gan_amd.ddp.broadcast(t.data, 0)
+        if hasattr(step, "averaged_G"):
+            step.averaged_G.load_state_dict(step.net_G.state_dict())
+    use_graph = not distributed and not a.no_graph
+    run = gan_amd.GraphedStep(step) if use_graph else step
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    if distributed:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    losses = step.losses.detach().float().cpu().tolist()
+    if rank == 0:
+        _lib.profile_enable(True)
+    step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        prof = _lib.profile_collect()
+        _lib.profile_enable(False)
+        per = dt / a.steps
+        dom = _dominant(prof, per)
+        roofline = None
+        if dom:
+            roofline = {"bound": "mfma", "kernel": dom["dominant_kernel"], "achieved": dom["dominant_kernel_tflops"], "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None, "launches": dom["dominant_kernel_launches"],
+                        "avg_launch_us": dom["dominant_kernel_avg_us"], "step_tflops": dom["step_tflops"]}
+        print(json.dumps({
+            "metric": "G+D train img/s", "value": world * step.batch * a.steps / dt, "unit": "img/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * per, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": step.what + "; activations stored in bf16 between layers, conv operands bf16 on MFMA with fp32 accumulate",
+                       "family": a.family, "global_batch": world * step.batch, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "gradient_all_reduce": "bucketed, started from autograd hooks during the last backward pass of a phase" if distributed else None,
+                       "losses": losses, "losses_finite": all(x == x and abs(x) != float("inf") for x in losses)},
+            "roofline": roofline}), flush=True)
+    if distributed:
+        dist.destroy_process_group()
 
 
 def main():
@@ -104,7 +199,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="run the cycle eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-families", action="store_true", help="skip the per-family figures (DCGAN, Pix2Pix, StyleGAN steps)")
+    ap.add_argument("--no-families", action="store_true", help="skip the per-family figures (DCGAN, Pix2Pix, StyleGAN, BigGAN training steps)")
+    ap.add_argument("--family", default=None, choices=["dcgan64_b128", "pix2pix256_b8", "pix2pix256_b64", "stylegan256_b32", "biggan128_b256"],
+                    help="benchmark the training step of this model family instead of the WGAN-GP cycle (with --gpus N: data parallel, "
+                         "that batch per GPU)")
     ap.add_argument("--overlap", action="store_true",
                     help="launch weight-gradient kernels on a second stream beside the data gradient (measured: about 1 %% faster)")
     ap.add_argument("--force-reducer", action="store_true", help="use the data-parallel gradient reducer even with one rank (test aid)")
@@ -131,6 +229,8 @@ def main():
             raise SystemExit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     torch.cuda.set_device(local_rank)
+    if a.family is not None:
+        return family_main(a, rank, local_rank, world)
     import torch.distributed as dist
     distributed = world > 1 or a.force_reducer
     if distributed:

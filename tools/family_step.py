@@ -8,7 +8,8 @@ import gan_amd
 from gan_amd.harness import steps
 
 for name in sys.argv[1:] or list(steps.FAMILIES):
-    step, batch, what = steps.FAMILIES[name]("cuda:0")
+    step = steps.FAMILIES[name]("cuda:0")
+    batch = step.batch
     g = gan_amd.GraphedStep(step)
     for _ in range(3):
         g()

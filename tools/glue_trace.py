@@ -23,7 +23,7 @@ if family == "wgan":
     step = tr.cycle_eager
 else:
     from gan_amd.harness import steps
-    step = steps.FAMILIES[family]("cuda:0")[0]
+    step = steps.FAMILIES[family]("cuda:0")
 for _ in range(2):
     step()
 torch.cuda.synchronize()
