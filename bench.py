@@ -137,7 +137,7 @@ def family_main(a, rank, local_rank, world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    step = S.FAMILIES[a.family](device, reducer_factory=GradReducer if distributed else None)
+    step = S.FAMILIES[a.family](device, reducer_factory=GradReducer if distributed else None, data_seed=6000 + rank)
     if distributed:
         for t in step.parameters() + step.buffers():
             gan_amd.ddp.broadcast(t.data, 0)

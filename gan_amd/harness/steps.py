@@ -22,6 +22,12 @@ from .. import ops, optim
 from . import basic_gans, biggan, pix2pix, stylegan
 
 
+def _reseed(data_seed):
+    """The networks are initialised from seed 5000 on every rank; the synthetic batch of a rank comes from its own seed."""
+    if data_seed is not None:
+        torch.manual_seed(data_seed)
+
+
 class TrainStep:
     """step() = discriminator phase, its Adam step, generator phase, its Adam step.  With `reducer_factory`
     (gan_amd.ddp.GradReducer) every network's gradients live in flat buckets that are all-reduced over the ranks: a bucket's
@@ -62,7 +68,7 @@ class TrainStep:
         return list(self.net_G.buffers()) + list(self.net_D.buffers())
 
 
-def dcgan(device, batch=128, reducer_factory=None):
+def dcgan(device, batch=128, reducer_factory=None, data_seed=None):
     torch.manual_seed(5000)
     G = basic_gans.Generator(100, 64, 3, 64, activation_dtype=torch.bfloat16).to(device)
     D = basic_gans.Discriminator(3, 64, 64, is_wgan=False, activation_dtype=torch.bfloat16).to(device)
@@ -70,6 +76,7 @@ def dcgan(device, batch=128, reducer_factory=None):
     D.apply(basic_gans.weights_init)
     oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     oD = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    _reseed(data_seed)
     real = (torch.rand(batch, 3, 64, 64, device=device) * 2 - 1).contiguous(memory_format=torch.channels_last)
     z = torch.randn(batch, 100, 1, 1, device=device)
     keep = {}
@@ -86,13 +93,14 @@ def dcgan(device, batch=128, reducer_factory=None):
                      f"DCGAN 64x64 (hidden 64, nz 100), batch {batch}: discriminator + generator update with Adam", 3, device, reducer_factory)
 
 
-def pix2pix_unet(device, batch=8, ch=64, size=256, reducer_factory=None):
+def pix2pix_unet(device, batch=8, ch=64, size=256, reducer_factory=None, data_seed=None):
     torch.manual_seed(5000)
     pix2pix.set_activation_dtype(torch.bfloat16)
     pix2pix.set_fused_norm(True)
     G, D = pix2pix.Generator(ch=ch).to(device), pix2pix.Discriminator(ch=ch).to(device)
     oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     oD = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    _reseed(data_seed)
     real = torch.rand(batch, 3, size, size, device=device) * 2 - 1
     label = torch.rand(batch, 3, size, size, device=device)
 
@@ -107,11 +115,11 @@ def pix2pix_unet(device, batch=8, ch=64, size=256, reducer_factory=None):
                      2, device, reducer_factory)
 
 
-def pix2pix_unet_b64(device, reducer_factory=None):
-    return pix2pix_unet(device, batch=64, reducer_factory=reducer_factory)
+def pix2pix_unet_b64(device, reducer_factory=None, data_seed=None):
+    return pix2pix_unet(device, batch=64, reducer_factory=reducer_factory, data_seed=data_seed)
 
 
-def stylegan_v1(device, batch=32, pg=6, reducer_factory=None):
+def stylegan_v1(device, batch=32, pg=6, reducer_factory=None, data_seed=None):
     torch.manual_seed(5000)
     stylegan.set_activation_dtype(torch.bfloat16)
     G, D = stylegan.StyleBasedGenerator().to(device), stylegan.Discriminator().to(device)
@@ -124,6 +132,7 @@ def stylegan_v1(device, batch=32, pg=6, reducer_factory=None):
                      {"params": list(G.mapping_network.parameters()), "lr": lr * 0.01}], lr=lr, betas=(0.0, 0.9))
     oG.average_into(averaged_G, G, 0.999)
     oD = optim.Adam(D.parameters(), lr=lr, betas=(0.0, 0.9))
+    _reseed(data_seed)
     real = torch.rand(batch, 3, res, res, device=device) * 2 - 1
     zs = torch.randn(4, batch, 512, device=device)
     eps = torch.rand(batch, 1, 1, 1, device=device)
@@ -142,7 +151,7 @@ def stylegan_v1(device, batch=32, pg=6, reducer_factory=None):
     return step
 
 
-def biggan_128(device, batch=256, ch=64, n_classes=10, reducer_factory=None):
+def biggan_128(device, batch=256, ch=64, n_classes=10, reducer_factory=None, data_seed=None):
     torch.manual_seed(5000)
     biggan.set_activation_dtype(torch.bfloat16)
     biggan.set_fused_attention(True)
@@ -155,6 +164,7 @@ def biggan_128(device, batch=256, ch=64, n_classes=10, reducer_factory=None):
     oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.0, 0.999))          # BigGAN/cfg.py
     oG.average_into(averaged_G, G, 0.9999)                                # BigGAN/train.py:83
     oD = optim.Adam(D.parameters(), lr=5e-5, betas=(0.0, 0.999))
+    _reseed(data_seed)
     real = torch.rand(batch, 3, 128, 128, device=device) * 2 - 1
     z1, z2 = torch.rand(batch, 120, device=device), torch.rand(batch, 120, device=device)      # torch.rand: BigGAN/train.py:182
     lab = torch.randint(0, n_classes, (3, batch), device=device)
