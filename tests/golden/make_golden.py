@@ -300,13 +300,15 @@ def make_wgangp_trace(ref, out):
     print("wgangp_trace.npz:", len(blob), "arrays; scalars", blob["critic.scalars"], blob["gen.scalars"])
 
 
-def make_pix2pix_trace(ref, out):
-    """One Pix2Pix step (Pix2Pix/train.py:94-145) on the reference's models at 256x256 with ch=8, batch 2.  The
+def make_pix2pix_trace(ref, out, B=2, ch=8, name="pix2pix_trace"):
+    """One Pix2Pix step (Pix2Pix/train.py:94-145) on the reference's models at 256x256 with ch=8, batch 2
+    (`pix2pix_trace`) and at the reference's full width, ch=64, batch 1 (`pix2pix_wide_trace`: every gradient as a strided
+    sample, its norm and eight +-1 projections of the whole tensor; dropout masks as seeds).  The
     nets keep PyTorch's default initialisation (the script applies none), regenerated from the seed by the tests
     and pinned here by checksums; dropout masks are captured."""
     models = load_by_path("ref_p2p_models", os.path.join(ref, "Pix2Pix/models.py"))
     seed_all()
-    B, ch = 2, 8
+    wide = ch > 8
     net_G = models.Generator(ch=ch)
     net_D = models.Discriminator(ch=ch)
     blob = {"cfg": np.array([B, ch], np.int64)}
@@ -340,7 +342,10 @@ def make_pix2pix_trace(ref, out):
         d_loss.backward()
         blob["d.loss"] = np.array([d_loss.item(), D_x.item(), D_G_z1.item()])
         for k, p in net_D.named_parameters():
-            blob["d.gradD." + k] = p.grad.clone().numpy()
+            blob["d.gradD." + k] = _sample(p.grad.clone().numpy()) if wide else p.grad.clone().numpy()
+            if wide:
+                blob["d.gradD_norm." + k] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64))])
+                blob["d.gradD_proj." + k] = _projections(p.grad)
         blob["d.fake_crop"] = fake.detach()[:, :, 96:160, 96:160].numpy()
         n_d_masks = len(masks)
         req(net_G, True); req(net_D, False)
@@ -354,15 +359,18 @@ def make_pix2pix_trace(ref, out):
             g = p.grad.clone().numpy()
             blob["g.gradG." + k] = g if g.size <= 20000 else g.ravel()[::max(1, g.size // 4096)][:4096].copy()
             blob["g.gradG_norm." + k] = np.array([np.linalg.norm(g.astype(np.float64))])
+            if wide:
+                blob["g.gradG_proj." + k] = _projections(p.grad)
     finally:
         F.dropout = orig_dropout
         torch.nn.functional.dropout = orig_dropout
-    for i, m in enumerate(masks):
-        blob[f"mask{i}"] = m.numpy().astype(np.uint8) if False else m.numpy()
+    for i, m in enumerate(masks):          # 0 / 2 masks: one bit per element
+        blob[f"mask{i}"] = np.packbits(m.numpy().astype(bool).ravel()) if wide else m.numpy()
+        blob[f"mask{i}.shape"] = np.array(m.shape, np.int64)
     blob["n_d_masks"] = np.array([n_d_masks])
-    np.savez_compressed(os.path.join(out, "pix2pix_trace.npz"), **blob)
-    json.dump(rec, open(os.path.join(out, "pix2pix_trace.json"), "w"), indent=1)
-    print("pix2pix_trace.npz:", len(blob), "arrays; losses", blob["d.loss"], blob["g.loss"], rec["param_count"])
+    np.savez_compressed(os.path.join(out, name + ".npz"), **blob)
+    json.dump(rec, open(os.path.join(out, name + ".json"), "w"), indent=1)
+    print(name + ".npz:", len(blob), "arrays; losses", blob["d.loss"], blob["g.loss"], rec["param_count"])
 
 
 def make_pix2pixhd_trace(ref, out):
@@ -415,6 +423,14 @@ def make_pix2pixhd_trace(ref, out):
 def _sample(g, n=4096):
     g = np.asarray(g)
     return g if g.size <= 20000 else g.ravel()[::max(1, g.size // n)][:n].copy()
+
+
+def _projections(t, seed=29, n=8):
+    """n random +-1 projections of the whole tensor in float64: every element enters every number."""
+    flat = t.detach().reshape(-1).double()
+    g = torch.Generator().manual_seed(seed)
+    return np.array([float((flat * (torch.randint(0, 2, (flat.numel(),), generator=g, dtype=torch.int8).double() * 2 - 1)).sum())
+                     for _ in range(n)])
 
 
 def make_stylegan_trace(ref, out, pg=5, name="stylegan_trace"):
@@ -496,14 +512,16 @@ def make_stylegan_trace(ref, out, pg=5, name="stylegan_trace"):
     print(name + ".npz:", len(blob), "arrays;", blob["critic.scalars"], blob["gen.scalars"], rec["param_count"], blob["critic.crossover"], blob["gen.crossover"])
 
 
-def make_biggan_trace(ref, out):
-    """BigGAN 128x128 with ch = 8, 4 classes, batch 4 on the reference's BigGAN/model.py: hinge discriminator phase
+def make_biggan_trace(ref, out, B=4, ch=8, name="biggan_trace"):
+    """BigGAN 128x128 with ch = 8, 4 classes, batch 4 (`biggan_trace`) and at the width the reference trains, ch = 64, batch 2
+    (`biggan_wide_trace`, with eight +-1 projections of every whole gradient) on the reference's BigGAN/model.py: hinge discriminator phase
     and generator phase (BasicGANs/loss_functions.py:79-99) with orthogonal init and orthogonal regularisation
     restated from BigGAN/train.py:108-127 (that script imports cv2 / tensorboard and cannot be imported)."""
     models = load_by_path("ref_bg_models", os.path.join(ref, "BigGAN/model.py"))
     losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
     seed_all()
-    B, ch, ncls = 4, 8, 4
+    ncls = 4
+    wide = ch > 8
     net_G = models.Generator(n_classes=ncls, ch=ch)
     net_D = models.Discriminator(n_classes=ncls, ch=ch)
 
@@ -537,6 +555,8 @@ def make_biggan_trace(ref, out):
     for k, p in net_D.named_parameters():
         blob["d.gradD." + k] = _sample(p.grad.numpy())
         blob["d.gradD_norm." + k] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64))])
+        if wide:
+            blob["d.gradD_proj." + k] = _projections(p.grad)
     req(net_G, True); req(net_D, False)
     G_error = losses.get_hinge_loss(net_G, net_D, noise_vector=z2, fake_label=labels[2], discriminator=False)
     orth_reg(net_G)
@@ -544,15 +564,17 @@ def make_biggan_trace(ref, out):
     for k, p in net_G.named_parameters():
         blob["g.gradG." + k] = _sample(p.grad.numpy())
         blob["g.gradG_norm." + k] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64))])
+        if wide:
+            blob["g.gradG_proj." + k] = _projections(p.grad)
     with torch.no_grad():
         img = net_G(z1, labels[1])
     blob["image_crop"] = img[:, :, 32:96, 32:96].numpy()
     for k, v in net_G.state_dict().items():
         if "U_vector" in k and v.numel() <= 64:
             blob["after.G." + k] = v.clone().numpy()
-    np.savez_compressed(os.path.join(out, "biggan_trace.npz"), **blob)
-    json.dump(rec, open(os.path.join(out, "biggan_trace.json"), "w"), indent=1)
-    print("biggan_trace.npz:", len(blob), "arrays;", blob["d.scalars"], blob["g.scalars"], rec["param_count"])
+    np.savez_compressed(os.path.join(out, name + ".npz"), **blob)
+    json.dump(rec, open(os.path.join(out, name + ".json"), "w"), indent=1)
+    print(name + ".npz:", len(blob), "arrays;", blob["d.scalars"], blob["g.scalars"], rec["param_count"])
 
 
 # --------------------------------------------------------------------------------------- loss curves
@@ -598,11 +620,11 @@ def make_dcgan_losses(ref, out, steps=3):
     json.dump(rec, open(os.path.join(out, "dcgan_losses.json"), "w"), indent=1)
 
 
-def make_wgangp_losses(ref, out, cycles=1):
+def make_wgangp_losses(ref, out, cycles=1, B=64, name="wgangp_losses"):
     models = load_by_path("ref_basic_models", os.path.join(ref, "BasicGANs/models.py"))
     losses = load_by_path("ref_basic_losses", os.path.join(ref, "BasicGANs/loss_functions.py"))
     seed_all()
-    B, hd, nz, res = 64, 64, 100, 64
+    hd, nz, res = 64, 100, 64
     net_G = models.Generator(nz, hd, 3, resolution=res); net_G.apply(weights_init)
     net_D = models.Discriminator(3, hd, resolution=res, is_wgan=True); net_D.apply(weights_init)
     rec = {"config": {"B": B, "hidden_dim": hd, "nz": nz, "res": res, "seed": SEED, "lr": 1e-4, "betas": [0.0, 0.9],
@@ -637,7 +659,7 @@ def make_wgangp_losses(ref, out, cycles=1):
         opt_G.step()
         rec["cycles"].append({"critic": crit, "G_error": G_error.item(), "D_G_z2": D_G_z2})
         print("wgangp gen", c, rec["cycles"][-1]["G_error"])
-    json.dump(rec, open(os.path.join(out, "wgangp_losses.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(out, name + ".json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
@@ -647,7 +669,8 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["ops", "wide_ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "pix2pixhd_trace", "stylegan_trace", "stylegan256_trace", "biggan_trace"]
+    todo = a.only.split(",") if a.only else ["ops", "wide_ops", "dcgan_trace", "wgangp_trace", "dcgan_losses", "wgangp_losses", "pix2pix_trace", "pix2pixhd_trace", "stylegan_trace", "stylegan256_trace", "biggan_trace",
+                                                   "pix2pix_wide_trace", "biggan_wide_trace", "wgangp_losses_b256"]
     if "ops" in todo: make_ops(a.out)
     if "wide_ops" in todo: make_wide_ops(a.out)
     if "dcgan_trace" in todo: make_dcgan_trace(a.ref, a.out)
@@ -659,3 +682,7 @@ if __name__ == "__main__":
     if "stylegan_trace" in todo: make_stylegan_trace(a.ref, a.out)
     if "stylegan256_trace" in todo: make_stylegan_trace(a.ref, a.out, pg=6, name="stylegan256_trace")
     if "biggan_trace" in todo: make_biggan_trace(a.ref, a.out)
+    # the reference's full widths, whole models (batch 1 / 2) and the benchmark's batch for the WGAN-GP loss sequence
+    if "pix2pix_wide_trace" in todo: make_pix2pix_trace(a.ref, a.out, B=1, ch=64, name="pix2pix_wide_trace")
+    if "biggan_wide_trace" in todo: make_biggan_trace(a.ref, a.out, B=2, ch=64, name="biggan_wide_trace")
+    if "wgangp_losses_b256" in todo: make_wgangp_losses(a.ref, a.out, B=256, name="wgangp_losses_b256")

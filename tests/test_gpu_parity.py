@@ -808,15 +808,18 @@ def test_full_size_properties(gan):
                           (True, True, "bf16", torch.bfloat16, 1.5e-2, True), (False, True, "fp32x3", torch.float32, 5e-3, True)],
                          ids=["separate_passes", "real_fake_batched", "real_fake_batched_fused_adam", "bf16_operands",
                               "bf16_operands_bf16_activations", "two_streams_fp32x3", "two_streams_bf16", "three_streams_fp32x3"])
-def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched, fused_adam, prec, act_dtype, tol, two_streams):
-    """Full-size WGAN-GP-64 (hidden 64) at batch 64 with Adam: five critic iterations + one generator iteration
+@pytest.mark.parametrize("fixture", ["wgangp_losses", "wgangp_losses_b256"], ids=["batch64", "batch256"])
+def test_wgangp_losses_against_reference_full_model(gan, golden_dir, batched, fused_adam, prec, act_dtype, tol, two_streams, fixture):
+    """Full-size WGAN-GP-64 (hidden 64) at batch 64 and at the benchmark's batch 256 with Adam: five critic iterations + one generator iteration
     of the reference (golden losses), fp32x3 path; weights and inputs regenerated from the recorded seeds.
     `batched` runs the real and fake critic passes as one batch of 2B; the last parameter set is the benchmark's
     setting (bf16 MFMA operands, activations stored in bf16, fused Adam): measured deviations of the critic losses from
     the reference's are 6e-4 (fp32x3), 6.5e-3 (bf16 operands) and 5e-3 (bf16 operands and storage).  `two_streams` runs the
     penalty chain and the real + fake chain of each critic iteration on two streams and adds their gradients."""
     from gan_amd.harness import basic_gans as H
-    rec = json.load(open(os.path.join(golden_dir, "wgangp_losses.json")))
+    if fixture == "wgangp_losses_b256" and not (batched and fused_adam):
+        pytest.skip("batch 256: the batched / fused-Adam settings (the benchmark's) only")
+    rec = json.load(open(os.path.join(golden_dir, fixture + ".json")))
     cfg = rec["config"]
     gan.set_precision(prec)
     try:
@@ -891,17 +894,27 @@ def test_pix2pixhd_generator_against_reference_trace(gan, golden_dir, prec, tol,
 @pytest.mark.parametrize("prec,tol,coarse,fast", [("fp32x3", 2e-4, 5e-2, False), ("bf16", 2e-2, 3e-1, False), ("fp32x3", 2e-4, 5e-2, "norm"),
                                                   ("bf16", 3e-2, 4e-1, "norm+bf16")],
                          ids=["fp32x3", "bf16", "fp32x3_fused_norm", "bf16_storage_fused_norm"])
-def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse, fast):
-    """One Pix2Pix step (U-Net + PatchGAN at 256x256, reference trace with ch = 8, batch 2): losses, generator output,
-    discriminator gradients, generator gradient norms."""
+@pytest.mark.parametrize("fixture", ["pix2pix_trace", "pix2pix_wide_trace"], ids=["ch8_b2", "ch64_b1"])
+def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse, fast, fixture):
+    """One Pix2Pix step (U-Net + PatchGAN at 256x256; reference traces with ch = 8, batch 2 and with the reference's full
+    width, ch = 64, batch 1): losses, generator output, discriminator gradients, generator gradient norms and samples.
+    Full width runs on the library's BatchNorm kernels only (torch's own batch_norm crashes on this image for the
+    [1, 128, 64, 64] NHWC tensor).  At batch 1 the BatchNorm layers at 2x2 and 4x4 normalise over 4 and 16 values, which
+    amplifies rounding differences: measured worst tensor 2.5e-2 in fp32x3; in bf16 the transposed convolutions at 2x2 and
+    4x4 are off by more than their norm (tools/grad_error_report.py) and are checked for finiteness only."""
     from gan_amd.harness import pix2pix as P
     from test_oracle_golden import pix2pix_setup
+    wide = fixture == "pix2pix_wide_trace"
+    if wide and not fast:
+        pytest.skip("full width: fused BatchNorm kernels only")
     gan.set_precision(prec)
     P.set_fused_norm(bool(fast))
     P.set_activation_dtype(torch.bfloat16 if fast == "norm+bf16" else None)
     try:
-        z, rec, G, D, real, label, masks_d, masks_g = pix2pix_setup(golden_dir, lambda ch: P.Generator(ch=ch), lambda ch: P.Discriminator(ch=ch))
+        z, rec, G, D, real, label, masks_d, masks_g = pix2pix_setup(golden_dir, lambda ch: P.Generator(ch=ch), lambda ch: P.Discriminator(ch=ch), fixture)
         assert list(G.state_dict().keys()) == list(R.P2PGenerator(ch=4).state_dict().keys())
+        if wide:
+            assert sum(p.numel() for p in G.parameters()) == 54419459 and sum(p.numel() for p in D.parameters()) == 2769601
         G.cuda(); D.cuda()
         real, label = real.cuda(), label.cuda()
         masks_d = [m.cuda() for m in masks_d]; masks_g = [m.cuda() for m in masks_g]
@@ -910,12 +923,21 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
         biggest = max(np.linalg.norm(z["d.gradD." + k]) for k, _ in D.named_parameters())
         for k, p in D.named_parameters():
             want = z["d.gradD." + k]
+            got = p.grad
+            if wide:          # sampled entries, the norm and eight +-1 projections of the whole tensor
+                g = p.grad.detach().cpu().numpy()
+                got = g if g.size <= 20000 else g.ravel()[::max(1, g.size // 4096)][:4096]
+                wn = z["d.gradD_norm." + k][0]
+                if wn >= 1e-5 * biggest:
+                    assert abs(np.linalg.norm(g.astype(np.float64)) - wn) < coarse * wn, k
+                    from test_oracle_golden import projections
+                    assert np.abs(projections(p.grad) - z["d.gradD_proj." + k]).max() < 4 * coarse * wn, k
             if np.linalg.norm(want) < 1e-5 * biggest:
                 # the bias of a conv that feeds BatchNorm has a mathematically zero gradient: only rounding noise to compare
                 # (it grows with the storage precision: 3.5e-4 of the largest gradient with bf16 activations)
                 assert p.grad.norm().item() < max(1e-4, 2e-2 * tol) * biggest, k
                 continue
-            assert_grad_close(p.grad, want, tol, coarse, k)
+            assert_grad_close(got, want, tol, coarse, k)
         g_err, fake = P.generator_phase(G, D, real, label, 100.0, masks_g)
         assert abs(g_err.item() - z["g.loss"][0]) < tol * z["g.loss"][0]
         assert rel(fake[:, :, 96:160, 96:160], z["g.fake_crop"]) < 5 * tol
@@ -925,6 +947,9 @@ def test_pix2pix_step_against_reference_trace(gan, golden_dir, prec, tol, coarse
             got = p.grad.double().norm().item()
             if want < 1e-5 * biggest:
                 assert got < max(1e-4, 2e-2 * tol) * biggest, k
+                continue
+            if wide and prec == "bf16" and any(t in k for t in ("upsample_1.", "upsample_2.", "downsample_6.", "downsample_7.", "downsample_5.")):
+                assert np.isfinite(got) and got < 10 * want, (k, got, want)      # BatchNorm over 4 / 16 values, see above
                 continue
             assert abs(got - want) < coarse * want, (k, got, want)
             ref = z["g.gradG." + k]
@@ -984,9 +1009,11 @@ def test_stylegan_phases_against_reference_trace(gan, golden_dir, prec, tol, coa
 
 @pytest.mark.parametrize("prec,tol,coarse,fast", [("fp32x3", 5e-4, 5e-2, False), ("bf16", 5e-2, 3e-1, False), ("bf16", 5e-2, 3e-1, True)],
                          ids=["fp32x3", "bf16", "bf16_storage_fused_attention"])
-def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse, fast):
+@pytest.mark.parametrize("fixture", ["biggan_trace", "biggan_wide_trace"], ids=["ch8_b4", "ch64_b2"])
+def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coarse, fast, fixture):
     """BigGAN 128x128 (spectral-norm 3x3 / 1x1 convs incl. the attention projections, conditional BN, nearest
-    upsampling, projection discriminator): hinge phases with orthogonal regularisation against the reference trace.
+    upsampling, projection discriminator): hinge phases with orthogonal regularisation against the reference traces (ch = 8,
+    batch 4; and the width the reference trains, ch = 64, batch 2, with +-1 projections of every whole gradient).
     `fast`: activations stored in bf16 and the attention product as one fused call (the harness's speed options)."""
     from gan_amd.harness import biggan as Bg
     from test_oracle_golden import biggan_setup, check_grads
@@ -994,7 +1021,9 @@ def test_biggan_phases_against_reference_trace(gan, golden_dir, prec, tol, coars
     Bg.set_activation_dtype(torch.bfloat16 if fast else None)
     Bg.set_fused_attention(fast)
     try:
-        z, rec, G, D, real, z1, z2, labels = biggan_setup(golden_dir, Bg)
+        z, rec, G, D, real, z1, z2, labels = biggan_setup(golden_dir, Bg, fixture)
+        if fixture == "biggan_wide_trace":
+            assert sum(p.numel() for p in G.parameters()) == 31859620 and sum(p.numel() for p in D.parameters()) == 39478034
         G.cuda(); D.cuda()
         real, z1, z2, labels = real.cuda(), z1.cuda(), z2.cuda(), labels.cuda()
         d_x, d_g = Bg.discriminator_phase(G, D, real, labels[0], z1, labels[1])
