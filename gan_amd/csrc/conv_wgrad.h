@@ -84,6 +84,7 @@ bool wgrad_image_geometry(const WgradParams& p);
 bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l);
 int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
 bool plan_wgrad_rows(WgradParams& p, const WgradLaunch& l, int n_seg, const int32_t* Ns);
+size_t wgrad_rows_workspace_cap();    // 0, or the calling thread's bound on the partial sums of the row-streaming plan
 int launch_wgrad_rows(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream);
 int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream);

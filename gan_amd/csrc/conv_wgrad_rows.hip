@@ -261,6 +261,9 @@ bool plan_wgrad_rows(WgradParams& p, const WgradLaunch& l, int n_seg, const int3
   if (want < 1) want = 1;
   p.strips_per_split = (int32_t)((strips + want - 1) / want);
   p.splits = (int32_t)((strips + p.strips_per_split - 1) / p.strips_per_split);
+  // a caller with a bounded workspace (the entry point that allocates nothing): leave the problem to the tiled kernels,
+  // whose partial sums are smaller for weights with few tiles, when the strips' partial sums would not fit
+  if (wgrad_rows_workspace_cap() != 0 && (size_t)p.splits * 9 * p.Cout * p.Cin * sizeof(float) > wgrad_rows_workspace_cap()) return false;
   p.total_strips = (int32_t)strips;
   p.rows = 1;
   return true;

@@ -668,6 +668,18 @@ int gc_conv2d_dgrad(const gc_conv_desc* d, const void* gy, const void* packed_w,
   return run_gather(p, l, out_dt, (hipStream_t)stream);
 }
 
+static thread_local size_t g_rows_cap = 0;
+}  // extern "C"
+namespace gc {
+size_t wgrad_rows_workspace_cap() { return g_rows_cap; }
+}
+extern "C" {
+struct RowsCap {        // bounds the row-streaming plan's workspace for the calls made inside its scope (this thread)
+  size_t prev;
+  explicit RowsCap(size_t bytes) : prev(g_rows_cap) { g_rows_cap = bytes; }
+  ~RowsCap() { g_rows_cap = prev; }
+};
+
 static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l, bool allow_dma) {
   memset(&p, 0, sizeof(p));
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
@@ -852,6 +864,7 @@ int gc_conv2d_wgrad_noalloc(const gc_conv_desc* d, const void* x, const void* gy
                             int accumulate, float* gbias, void* stream) {
   int rc = validate(d);
   if (rc != GC_OK) return rc;
+  RowsCap cap((size_t)GC_NOALLOC_SCRATCH_BYTES);
   const size_t need = gc_wgrad_workspace_bytes(d);
   if (need > (size_t)GC_NOALLOC_SCRATCH_BYTES) {
     set_error("gc_conv2d_wgrad_noalloc: the partial sums of this problem need %zu bytes, the built-in scratch holds %u; use "
@@ -863,6 +876,12 @@ int gc_conv2d_wgrad_noalloc(const gc_conv_desc* d, const void* x, const void* gy
   // (nothing in the scratch has to start at zero: every partial slab that the reduction reads is written in full by
   // the weight-gradient kernel of the same call)
   return gc_conv2d_wgrad(d, x, gy, gw, gw_strides, alpha, accumulate, gbias, ptr, (size_t)GC_NOALLOC_SCRATCH_BYTES, stream);
+}
+
+int gc_noalloc_scratch(void** ptr, size_t* bytes) {
+  if (ptr == nullptr || bytes == nullptr) { set_error("gc_noalloc_scratch: null pointer"); return GC_BAD_ARGUMENT; }
+  *bytes = (size_t)GC_NOALLOC_SCRATCH_BYTES;
+  return scratch_of_current_device(ptr);
 }
 
 int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {

@@ -24,10 +24,16 @@ class ImageBatcher:
     the image is resized before a random `size` window is cut out of it (Pix2Pix/dataset.py:262, 286 / 256); flip: mirror a
     sample left-right with probability 1/2 (the reference's "flip" augmentation drawn against "noaug", :276-279).
     mean / std: per-channel constants of transforms.Normalize.  linear=False, divisor=1: label masks (INTER_NEAREST, raw
-    values, :241, :313).  channels_last: memory format of the returned [N, C, H, W] tensor."""
+    values, :241, :313).  channels_last: memory format of the returned [N, C, H, W] tensor.
+
+    With `jitter` the reference resizes twice, each time to 8 bits: Resize(SIZE) (Pix2Pix/train.py:49-52, dataset.py:232) and
+    then the jitter's own resize (:285).  This class resizes once, from the source straight to int(size * jitter): the same
+    pixels when the source already has `size` (then the reference's first resize is the identity), slightly different ones
+    otherwise.  A source of another size is therefore refused unless single_resize=True says that one resize is wanted."""
 
     def __init__(self, size, mean=None, std=None, jitter=None, flip=False, linear=True, divisor=255.0, dtype=torch.float32,
-                 channels_last=True, device="cuda"):
+                 channels_last=True, device="cuda", single_resize=False):
+        self.single_resize = bool(single_resize)
         self.out_w, self.out_h = int(size[0]), int(size[1])
         self.mean = None if mean is None else (ctypes.c_float * len(mean))(*mean)
         self.std = None if std is None else (ctypes.c_float * len(std))(*std)
@@ -62,6 +68,12 @@ class ImageBatcher:
         channels = tensors[0].shape[2] if n else 3
         if any(t.shape[2] != channels for t in tensors):
             raise RuntimeError("ganconv: the images of a batch must have the same number of channels")
+        if self.jitter is not None and not self.single_resize:
+            for t in tensors:
+                if (t.shape[0], t.shape[1]) != (self.out_h, self.out_w):
+                    raise RuntimeError(f"ganconv: with jitter the reference resizes a {t.shape[1]}x{t.shape[0]} source to {self.out_w}x{self.out_h} first "
+                                       "and then to the jitter size (two 8-bit passes); this class resizes once: pass sources of the network's "
+                                       "input size, or single_resize=True")
         plans = self.plan([t.shape for t in tensors], rng) if plans is None else plans
         jobs = np.zeros(n, _JOB)
         for i, (t, (rh, rw, y, x, flip)) in enumerate(zip(tensors, plans)):

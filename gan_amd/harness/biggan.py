@@ -55,8 +55,8 @@ def _sigma(layer):
     """Largest singular value of layer.weight (as a [out, rest] matrix) by power iteration from the stored left vector
     U_vector [1, out], which is advanced in place.  No gradient flows through it."""
     ahead = layer.__dict__.pop("_sigma_ahead", None)      # computed for the whole network in front of this forward pass
-    if ahead is not None:
-        return ahead
+    if ahead is not None and ahead[1] == layer.weight._version:      # (a sigma left over from a pass that skipped this layer,
+        return ahead[0]                                               #  or from before the weights moved, is not used)
     if layer.weight.is_cuda and layer.norm == 2 and layer.weight.dtype == torch.float32:
         return ops.spectral_sigma_(layer.weight, layer.U_vector, layer.n_iterations)       # four launches per iteration
     with torch.no_grad():
@@ -87,7 +87,7 @@ def _sigmas_ahead(net):
         st.weights, st.us = [m.weight for m in layers], [m.U_vector for m in layers]       # (re-created tensors show in the key)
     sig = st.refresh()
     for i, m in enumerate(layers):
-        m.__dict__["_sigma_ahead"] = sig[i]
+        m.__dict__["_sigma_ahead"] = (sig[i], m.weight._version)
 
 
 class Conv2d(gnn.Conv2d):

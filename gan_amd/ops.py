@@ -354,8 +354,11 @@ _CAST_CACHE_MAX = 128
 
 
 def clear_cast_cache():
+    """Drops the bf16 operand copies and the statistics rows a convolution left for a BatchNorm that never asked for them
+    (an evaluation-mode norm behind a training-mode convolution, a dtype change in between): both keep activations alive."""
     with _lock:
         _cast_cache.clear()
+        _row_cache.clear()
 
 
 def clear_weight_cache():

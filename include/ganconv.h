@@ -166,6 +166,11 @@ int gc_conv2d_wgrad(const gc_conv_desc* desc, const void* x, const void* gy, flo
 int gc_conv2d_wgrad_noalloc(const gc_conv_desc* desc, const void* x, const void* gy, float* gw, const int64_t gw_strides[4],
                             float alpha, int accumulate, float* gbias, void* stream);
 
+/* Diagnostic accessor, no counterpart in the reference: the device address and size of the current device's scratch array
+ * that gc_conv2d_wgrad_noalloc uses (looked up with hipGetSymbolAddress once per device; nothing is allocated).  For tests
+ * that want to see that the array, and not some other buffer, took a call's partial sums. */
+int gc_noalloc_scratch(void** ptr, size_t* bytes);
+
 /* Depthwise 3x3 binomial blur ([1 2 1] x [1 2 1]) / 16, zero padding 1, NHWC, dtype gc_dtype.  The kernel is
  * symmetric, so the same call serves forward and backward (StyleGAN/model.py:82-150: BlurFunction,
  * BlurFunctionBackward; F.conv2d(x, kernel, padding=1, groups=C)). */

@@ -38,8 +38,12 @@ def test_pix2pix_pipeline_with_jitter_flip_and_label_masks(gan):
     rng = np.random.RandomState(62)
     images = _images(rng, 4, 3, [(256, 256), (512, 384), (200, 333), (286, 286)])
     masks = [rng.randint(0, 30, im.shape).astype(np.uint8) for im in images]
-    b = gan.data.ImageBatcher((256, 256), mean=(0.5,) * 3, std=(0.5,) * 3, jitter=1.1171875, flip=True)
-    m = gan.data.ImageBatcher((256, 256), jitter=1.1171875, flip=True, linear=False, divisor=1.0)
+    strict = gan.data.ImageBatcher((256, 256), jitter=1.1171875)
+    with pytest.raises(RuntimeError, match="resizes once"):      # the reference would resize a 512 x 384 source twice
+        strict(images)
+    assert strict(images[:1]).shape == (1, 3, 256, 256)            # a source of the input size: the reference's first resize is the identity
+    b = gan.data.ImageBatcher((256, 256), mean=(0.5,) * 3, std=(0.5,) * 3, jitter=1.1171875, flip=True, single_resize=True)
+    m = gan.data.ImageBatcher((256, 256), jitter=1.1171875, flip=True, linear=False, divisor=1.0, single_resize=True)
     plans = b.plan([im.shape for im in images], np.random.RandomState(5))
     assert all(p[0] == 286 and p[1] == 286 and 0 <= p[2] < 30 and 0 <= p[3] < 30 for p in plans) and {p[4] for p in plans} <= {0, 1}
     plans[0] = plans[0][:4] + (1,)

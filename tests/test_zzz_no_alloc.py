@@ -81,3 +81,70 @@ def test_no_alloc_accumulates_like_the_workspace_form():
                                      ctypes.c_void_p(b.data_ptr()), strides, 1.0, 1, None, stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(a, b) and not torch.equal(a, base)
+
+
+def test_no_alloc_call_writes_the_scratch_array_and_nothing_past_its_need():
+    """The array gc_noalloc_scratch names is the one the call uses: filled with a sentinel, its head holds the call's
+    partial sums afterwards (and reproduces the weight gradient when summed over the splits) while the bytes past the
+    call's need keep the sentinel."""
+    L = _lib.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    ptr, size = ctypes.c_void_p(), ctypes.c_size_t()
+    assert L.gc_noalloc_scratch(ctypes.byref(ptr), ctypes.byref(size)) == 0 and ptr.value and size.value == (32 << 20)
+    torch.manual_seed(5)
+    d, Ho = _desc(8, 16, 64, 64, 4, 2, 1, _lib.GC_BF16)
+    need = L.gc_wgrad_workspace_bytes(ctypes.byref(d))
+    assert 0 < need < size.value
+    x = torch.randn(8, 16, 16, 64, device="cuda").bfloat16()
+    gy = torch.randn(8, Ho, Ho, 64, device="cuda").bfloat16()
+    gw = torch.empty(64, 64, 4, 4, device="cuda")
+    strides = (ctypes.c_int64 * 4)(64 * 16, 16, 4, 1)
+    torch.cuda.synchronize()
+    assert hip.hipMemset(ptr, 0x5A, size.value) == 0
+    assert L.gc_conv2d_wgrad_noalloc(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(gy.data_ptr()), ctypes.c_void_p(gw.data_ptr()),
+                                     strides, 1.0, 0, None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    head = torch.empty(need, dtype=torch.uint8, device="cuda")
+    tail = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    assert hip.hipMemcpy(ctypes.c_void_p(head.data_ptr()), ptr, need, 3) == 0                                  # device to device
+    assert hip.hipMemcpy(ctypes.c_void_p(tail.data_ptr()), ctypes.c_void_p(ptr.value + size.value - 4096), 4096, 3) == 0
+    torch.cuda.synchronize()
+    assert bool((tail == 0x5A).all())
+    parts = head.view(torch.float32).view(-1, 16, 64, 64)          # [split][tap][Cout][Cin]
+    assert parts.shape[0] >= 1 and bool(torch.isfinite(parts).all())
+    assert torch.equal(parts.sum(0).permute(1, 2, 0).reshape(64, 64, 4, 4), gw) or torch.allclose(
+        parts.sum(0).permute(1, 2, 0).reshape(64, 64, 4, 4), gw, rtol=1e-5, atol=1e-4)
+
+
+def test_fp32_image_beside_bf16_gradient_is_refused_outside_the_image_kernel():
+    """An fp32 x with a bf16 gy is converted by the image-layer kernel only.  With a gy that is not 16-byte aligned, or a gy
+    channel slice, that kernel does not apply: the call must fail instead of reading the fp32 image as bf16."""
+    L = _lib.lib()
+    N, Cin, Cout = 4, 3, 32
+    d = _lib.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, 64, 64, Cin, 32, 32, Cout
+    d.kh = d.kw = 4; d.stride_h = d.stride_w = 2; d.pad_h = d.pad_w = 1
+    d.x_dtype, d.y_dtype, d.precision = _lib.GC_F32, _lib.GC_BF16, _lib.GC_PREC_BF16
+    x = torch.randn(N, 64, 64, Cin, device="cuda")
+    gy_store = torch.randn(N * 32 * 32 * Cout + 64, device="cuda").bfloat16()
+    gw = torch.empty(Cout, Cin, 4, 4, device="cuda")
+    strides = (ctypes.c_int64 * 4)(Cin * 16, 16, 4, 1)
+    ws = torch.empty(max(L.gc_wgrad_workspace_bytes(ctypes.byref(d)), 16), dtype=torch.uint8, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(gy_ptr):
+        return L.gc_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(gy_ptr), ctypes.c_void_p(gw.data_ptr()), strides,
+                                 1.0, 0, None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream)
+    assert call(gy_store.data_ptr()) == 0, L.gc_last_error()             # aligned: the image-layer kernel takes it
+    torch.cuda.synchronize()
+    ref = torch.zeros(Cout, Cin, 4, 4, requires_grad=True)
+    y = torch.nn.functional.conv2d(x.cpu().bfloat16().float().permute(0, 3, 1, 2), ref, None, 2, 1)
+    want, = torch.autograd.grad(y, ref, gy_store[:N * 32 * 32 * Cout].float().cpu().view(N, 32, 32, Cout).permute(0, 3, 1, 2))
+    assert torch.allclose(gw.cpu(), want, rtol=1e-4, atol=1e-3)
+    assert call(gy_store.data_ptr() + 8) != 0                              # gy offset by 8 bytes
+    assert b"fp32 x" in L.gc_last_error() or b"dtype" in L.gc_last_error()
+    d.y_cstride, d.y_coff = Cout + 8, 4                                    # a gy channel slice at an unaligned offset
+    assert call(gy_store.data_ptr()) != 0
+    torch.cuda.synchronize()
