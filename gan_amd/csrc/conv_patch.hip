@@ -14,7 +14,8 @@
 // rectangle on layers with few chunks (64 -> 128 at 256 x 256: 506 TFLOP/s).
 //
 // Pipeline: weights go through a 4-slot ring (three steps in flight), the patch is double-buffered and the next
-// chunk's patch is issued at the first step of the current one.  All loads are LDS-DMA with buffer addressing (per-lane
+// chunk's patch is issued at the first step of the current one; the LDS fragment reads of step s + 1 are issued in front
+// of the MFMAs of step s (two register sets), so a wave's matrix instructions never wait for its own LDS reads.  All loads are LDS-DMA with buffer addressing (per-lane
 // offsets fixed, chunk / tap moves only the scalar offset, masked lanes take an out-of-range offset and receive zeros);
 // past the last step the cursor keeps issuing out-of-range loads into free slots so that the counted waits stay uniform.
 // LDS rows are 64 bytes (32 channels); the 16-byte chunk position is XORed with (row >> 1) & 3 on the source side: with
@@ -95,6 +96,22 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
   }
   const int PH = kTH + dh_max - dh_min, PW = kTW + dw_max - dw_min;
   const int npatch = PH * PW;
+  // The taps of a class form a grid in row-major order (checked by plan_patch): tap (r, s) = r * nw + s has the patch
+  // offset to0 + r * dto_r + s * dto_s and the filter tap wt0 + r * dwt_r + s * dwt_s.  Kept in scalar registers, so no
+  // step waits for a table read.
+  const int nw = dw_max - dw_min + 1;
+  int to0, dto_r = 0, dto_s = 0, wt0, dwt_r = 0, dwt_s = 0;
+  {
+    auto tap_at = [&](int i, int& to, int& wt) {
+      const int v = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + i]);
+      to = ((int)(int8_t)(v & 0xff) - dh_min) * PW + ((int)(int8_t)((v >> 8) & 0xff) - dw_min);
+      wt = v >> 16;
+    };
+    tap_at(0, to0, wt0);
+    int t1, w1;
+    if (nw > 1) { tap_at(1, t1, w1); dto_s = t1 - to0; dwt_s = w1 - wt0; }
+    if (T > nw) { tap_at(nw, t1, w1); dto_r = t1 - to0; dwt_r = w1 - wt0; }
+  }
 
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.wp), 0, (int)p.w_bytes, 0x00020000);
@@ -136,9 +153,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
                                                  (int)((c0 + a_chunk[j]) < p.IC ? a_off[j] : kOutOfRange), c0 * 2, 0, 0);
   };
   // weights of step (chunk c, tap ti): [TO oc][32 ch]; steps past the last one load zeros (uniform wait counts)
-  auto issue_w = [&](int slot, int c, int ti, bool live) {
-    const int e = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + ti]);
-    const uint32_t soff = (uint32_t)(((e >> 16) * p.ICp + c * kCK) * 2);
+  auto issue_w = [&](int slot, int c, int tr, int ts, bool live) {
+    const uint32_t soff = (uint32_t)(((wt0 + tr * dwt_r + ts * dwt_s) * p.ICp + c * kCK) * 2);
 #pragma unroll
     for (int j = 0; j < WJ; j++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(w_base + slot * kWBytes + (wave * WJ + j) * 1024), 16,
@@ -163,12 +179,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
     a_addr[ob] = row * 64 + ((g ^ ((row >> 1) & 3)) << 4);
   }
 
-  auto compute = [&](int slot, int c, int ti) {
+  // fragments of step (chunk c, tap ti) out of ring slot `slot`: TO / 16 weight blocks and the four pixel groups
+  auto load_frags = [&](int slot, int c, int tr, int ts, bf16x8 (&a)[FO], bf16x8 (&b)[4]) {
     const char* pb = patch_base + (c & 1) * kPatchBytes;
     const char* wb = w_base + slot * kWBytes;
-    const int e = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + ti]);
-    const int toff = ((int)(int8_t)(e & 0xff) - dh_min) * PW + ((int)(int8_t)((e >> 8) & 0xff) - dw_min);
-    bf16x8 b[4], a[FO];
+    const int toff = to0 + tr * dto_r + ts * dto_s;
 #pragma unroll
     for (int pg = 0; pg < 4; pg++) {
       const int idx = base_idx[pg] + toff;
@@ -176,41 +191,67 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
     }
 #pragma unroll
     for (int ob = 0; ob < FO; ob++) a[ob] = *reinterpret_cast<const bf16x8*>(wb + a_addr[ob]);
+  };
+  auto mfmas = [&](const bf16x8 (&a)[FO], const bf16x8 (&b)[4]) {
 #pragma unroll
     for (int ob = 0; ob < FO; ob++)
 #pragma unroll
       for (int pg = 0; pg < 4; pg++) acc[ob][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ob], b[pg], acc[ob][pg], 0, 0, 0);
   };
 
-  // ---- prologue: patch 0, then the weights of steps 0 .. 2
+  // ---- prologue: patch 0, the weights of steps 0 .. 3, the fragments of step 0
   issue_patch(0);
-  int ic = 0, iti = 0, islot = 0, issued = 0;     // (chunk, tap, ring slot) of the next weight step to issue
+  int ic = 0, itr = 0, its = 0, islot = 0, issued = 0;     // (chunk, tap row, tap column, ring slot) of the next weight step to issue
   auto issue_next_w = [&]() {
-    issue_w(islot, ic, iti, issued < nsteps);
+    issue_w(islot, ic, itr, its, issued < nsteps);
     issued++;
     islot = (islot + 1) & (kWSlots - 1);
-    if (++iti == T) { iti = 0; ic++; }
+    if (++its == nw) {
+      its = 0;
+      if (++itr * nw == T) { itr = 0; ic++; }
+    }
   };
 #pragma unroll
-  for (int s = 0; s < kWSlots - 1; s++) issue_next_w();
-  // ---- steps
-  int cc = 0, cti = 0, cslot = 0;     // (chunk, tap, ring slot) of the step being computed
-  for (int s = 0; s < nsteps; s++) {
-    // Younger than the weights of step s: the weights of steps s + 1 and s + 2, and the next chunk's patch when it went
-    // out at one of the two previous steps (i.e. this is tap 1 or 2 of a chunk that has a successor).
+  for (int s = 0; s < kWSlots; s++) issue_next_w();
+  bf16x8 a0[FO], b0[4], a1[FO], b1[4];
+  wait_vmcnt<3 * WJ>();                  // the patch and the weights of step 0
+  __builtin_amdgcn_s_barrier();
+  load_frags(0, 0, 0, 0, a0, b0);
+  // ---- steps.  The fragments of step s + 1 are read while the MFMAs of step s run, so at the barrier of step s only the
+  // slot of step s + 1 is still needed: the weights of s + 2 and s + 3 are in flight and those of s + 4 go into the slot
+  // of step s (whose fragments sit in registers since the previous step).
+  int cc = 0, cti = 0;                   // (chunk, tap) of the step being multiplied
+  int nc = 0, ntr = 0, nts = 0, nslot = 1;   // (chunk, tap row, tap column, ring slot) of the step whose fragments are read next
+  auto next_frag_tap = [&]() {
+    if (++nts == nw) {
+      nts = 0;
+      if (++ntr * nw == T) { ntr = 0; nc++; }
+    }
+  };
+  next_frag_tap();
+  auto step = [&](int s, const bf16x8 (&a)[FO], const bf16x8 (&b)[4], bf16x8 (&an)[FO], bf16x8 (&bn)[4]) {
+    // Younger than the weights of step s + 1: those of steps s + 2 and s + 3, and the next chunk's patch when it went out at
+    // one of the two previous steps (this is tap 1 or 2 of a chunk that has a successor).
     if ((cti == 1 || cti == 2) && cc + 1 < nchunks) {
       if (npi == 6) wait_vmcnt<2 * WJ + 6>(); else wait_vmcnt<2 * WJ + 5>();
     } else {
       wait_vmcnt<2 * WJ>();
     }
-    __builtin_amdgcn_s_barrier();        // step s has landed for every wave; the slot of step s - 1 and the other patch buffer are free
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's reads of the slot about to be refilled have returned
+    __builtin_amdgcn_s_barrier();        // step s + 1 has landed for every wave; the slot of step s and the other patch buffer are free
     __builtin_amdgcn_sched_barrier(0);
     if (cti == 0 && cc + 1 < nchunks) issue_patch(cc + 1);
     issue_next_w();
-    compute(cslot, cc, cti);
-    cslot = (cslot + 1) & (kWSlots - 1);
+    if (s + 1 < nsteps) load_frags(nslot, nc, ntr, nts, an, bn);
+    mfmas(a, b);
+    nslot = (nslot + 1) & (kWSlots - 1);
+    next_frag_tap();
     if (++cti == T) { cti = 0; cc++; }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, a0, b0, a1, b1);
+    if (s + 1 < nsteps) step(s + 1, a1, b1, a0, b0);
   }
   wait_vmcnt<0>();                       // the zero-filling tail loads target this workgroup's LDS: let them land
 
@@ -327,6 +368,18 @@ bool plan_patch(GatherParams& p, const GatherLaunch& l) {
       dw_min = p.tt.dw[e] < dw_min ? p.tt.dw[e] : dw_min; dw_max = p.tt.dw[e] > dw_max ? p.tt.dw[e] : dw_max;
     }
     if ((kTH + dh_max - dh_min) * (kTW + dw_max - dw_min) > kMaxPatch) return false;
+    {   // taps in row-major grid order, offsets and filter taps affine in (row, column): the kernel derives them from three entries
+      const int nw = dw_max - dw_min + 1, nh = dh_max - dh_min + 1;
+      if (nw * nh != t1 - t0) return false;
+      const int ddh_r = nh > 1 ? p.tt.dh[t0 + nw] - p.tt.dh[t0] : 0, ddw_s = nw > 1 ? p.tt.dw[t0 + 1] - p.tt.dw[t0] : 0;
+      const int dwt_r = nh > 1 ? (int)p.tt.wtap[t0 + nw] - (int)p.tt.wtap[t0] : 0, dwt_s = nw > 1 ? (int)p.tt.wtap[t0 + 1] - (int)p.tt.wtap[t0] : 0;
+      for (int i = 0; i < t1 - t0; i++) {
+        const int r = i / nw, q = i % nw;
+        if (p.tt.dh[t0 + i] != p.tt.dh[t0] + r * ddh_r || p.tt.dw[t0 + i] != p.tt.dw[t0] + q * ddw_s ||
+            (int)p.tt.wtap[t0 + i] != (int)p.tt.wtap[t0] + r * dwt_r + q * dwt_s)
+          return false;
+      }
+    }
     const int oh = p.tt.cls_oh[c], ow = p.tt.cls_ow[c];
     if (oh % kTH != 0 || ow % kTW != 0) return false;    // partial rectangles would idle most of a workgroup
     starts[c] = (int)tiles;
