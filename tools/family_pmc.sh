@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel statistics and counter passes of ONE model family's training step (run on the GPU box from the repository root):
-#   tools/family_pmc.sh <tag> <family of tools/family_bench.py: stylegan | biggan | pix2pix | ...>
+#   tools/family_pmc.sh <tag> <family of bench.py --family: stylegan256_b32 | biggan128_b256 | pix2pix256_b8 | ...>
 # Writes gpurun_out/<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of eager steps), traffic.{json,txt}
 # (FETCH_SIZE / WRITE_SIZE passes, per kernel and launch) and sq.txt (matrix-core, wait and LDS counters per kernel).
 # Every counter pass is a run of its own; counters never share a run with a trace.
@@ -9,7 +9,7 @@ tag=$1; fam=$2
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="python3 tools/family_bench.py --only=$fam --no-cpu --full --fast --top=40"
+cmd="python3 bench.py --family $fam --no-graph --steps 3 --warmup 1"      # eager training steps (both phases, Adam): 5 steps per run
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $cmd > $out/family_table.txt 2>&1
 cp $(find $out/trace -name '*kernel_stats.csv') $out/kernel_stats.csv
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $cmd > /dev/null 2>&1
@@ -22,7 +22,13 @@ timeout -s KILL 240 rocprofv3 --pmc $P2 --output-format csv -d $out/sq2 -o p -- 
 python3 tools/pmc_summary.py $out/sq1 $out/sq2 > $out/sq.txt
 rm -rf $out/trace $out/fetch $out/write $out/sq1 $out/sq2
 python3 - <<PY
-import csv
+import csv, json
+# HBM bytes per step: every kernel of the run (5 eager steps), FETCH_SIZE doubled as for the per-kernel table
+tr = json.load(open("$out/traffic.json"))
+per_step = tr.pop("__all_kernels__")["hbm_bytes_total"] / 5
+print("HBM GB per step, every kernel:", per_step / 1e9, " library kernels:", sum(v["hbm_bytes_per_launch"] * v["launches"] for v in tr.values()) / 5 / 1e9)
+json.dump({"$fam": {"hbm_bytes_per_step": per_step, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over 5 eager training steps, FETCH_SIZE doubled (gfx950)"}},
+          open("$out/family_traffic.json", "w"), indent=1)
 rows = list(csv.DictReader(open("$out/kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total kernel ms over the run", tot / 1e6)

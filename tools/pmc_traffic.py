@@ -34,6 +34,10 @@ for k in fetch:
     wn, wb = write.get(k, [0, 0.0])
     out[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * fb / n, "write_bytes_per_launch": wb / max(wn, 1),
               "hbm_bytes_per_launch": 2.0 * fb / n + wb / max(wn, 1)}
+# every kernel of the run, the framework's own included (elementwise glue, GEMMs of the linear layers)
+out["__all_kernels__"] = {"launches": sum(v[0] for v in fetch.values()),
+                          "hbm_bytes_total": 2.0 * sum(v[1] for v in fetch.values()) + sum(v[1] for v in write.values())}
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+del out["__all_kernels__"]
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
     print(f"{k:70s} n={v['launches']:4d} fetch={v['fetch_bytes_per_launch'] / 1e6:8.2f} MB write={v['write_bytes_per_launch'] / 1e6:8.2f} MB")
