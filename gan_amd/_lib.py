@@ -23,7 +23,8 @@ EXPORTS = (
     "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_fwd_rows", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_channel_sum_workspace_bytes", "gc_channel_sum", "gc_act_backward_channel_sum", "gc_batchnorm_stats", "gc_batchnorm_act_bwd_sums", "gc_batchnorm_act_bwd_apply", "gc_adam_step", "gc_adam_ema_step", "gc_set_split_reduction", "gc_set_patch_kernel", "gc_pack_weights", "gc_attention_fwd", "gc_attention_bwd", "gc_pool2x2", "gc_replicate2x", "gc_reflect_pad", "gc_reflect_pad_adjoint",
     "gc_cond_batchnorm_workspace_bytes", "gc_cond_batchnorm_act_fwd", "gc_cond_batchnorm_act_bwd", "gc_noise_lrelu_adain_workspace_bytes", "gc_noise_lrelu_adain_fwd", "gc_noise_lrelu_adain_bwd",
     "gc_wgrad_multi_workspace_bytes", "gc_conv2d_wgrad_multi",
-    "gc_channel_scale", "gc_rowdot_workspace_bytes", "gc_rowdot", "gc_act_concat_fwd", "gc_act_concat_bwd",
+    "gc_channel_scale", "gc_rowdot_workspace_bytes", "gc_rowdot", "gc_modulated_act_backward_workspace_bytes",
+    "gc_modulated_act_backward", "gc_act_concat_fwd", "gc_act_concat_bwd",
     "gc_wgan_mix", "gc_gradient_penalty_workspace_bytes", "gc_gradient_penalty_fwd", "gc_gradient_penalty_bwd", "gc_wgan_critic_loss", "gc_image_batch_prepare", "gc_spectral_norm_workspace_bytes", "gc_spectral_norm_power_iteration", "gc_spectral_norm_multi_plan", "gc_spectral_norm_multi_run",
 )
 
@@ -38,7 +39,8 @@ class Epilogue(ctypes.Structure):
     _fields_ = [("act", ctypes.c_int32), ("slope", ctypes.c_float), ("bias", ctypes.c_void_p), ("ch_sum", ctypes.c_void_p),
                 ("ch_sumsq", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("grad_mask", ctypes.c_void_p),
                 ("stat_rows", ctypes.c_void_p), ("stat_rows_capacity", ctypes.c_int32), ("stat_rows_written", ctypes.POINTER(ctypes.c_int32)),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("sample_scale", ctypes.c_void_p), ("sample_scale_out", ctypes.c_void_p)]
 
 
 _lib = None
@@ -69,6 +71,9 @@ def lib():
     L.gc_rowdot_workspace_bytes.argtypes = [i32, i32, i32]
     L.gc_rowdot_workspace_bytes.restype = ctypes.c_size_t
     L.gc_rowdot.argtypes = [vp, vp, vp, vp, ctypes.c_size_t] + [i32] * 4 + [vp]
+    L.gc_modulated_act_backward_workspace_bytes.argtypes = [i32, i32, i32]
+    L.gc_modulated_act_backward_workspace_bytes.restype = ctypes.c_size_t
+    L.gc_modulated_act_backward.argtypes = [vp] * 8 + [ctypes.c_size_t] + [i32] * 4 + [ctypes.c_float, vp]
     L.gc_act_concat_fwd.argtypes = [vp, vp, vp, ctypes.c_int64, i32, i32, i32, ctypes.c_float, vp]
     L.gc_act_concat_bwd.argtypes = [vp, vp, vp, vp, ctypes.c_int64, i32, i32, i32, ctypes.c_float, vp]
     L.gc_replicate2x.argtypes = [vp, vp] + [i32] * 5 + [ctypes.c_float, vp]

@@ -32,6 +32,8 @@ struct GatherParams {
   size_t split_ws_bytes;
   uint16_t* out_bf16;  // null, or a bf16 copy of the fp32 output (same indexing)
   const void* mask;    // null, or a tensor indexed like `out` (same element type): out *= mask > 0 ? 1 : slope
+  const float* pre_scale;   // null, or [N][OC]: the accumulator of (sample n, channel oc) is multiplied by it in front of the bias
+  const float* post_scale;  // null, or [N][OC]: the activated value is multiplied by it before it is stored
   int32_t N, IH, IW, IC, ICp, OH, OW, OC, T;
   int32_t row_pitch;   // elements per packed weight row
   int32_t a, b;        // input-coordinate multiplier, output class stride

@@ -312,8 +312,10 @@ __global__ __launch_bounds__(kThreads) void conv_gather_kernel(const GatherParam
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         float x = acc[i][j][r];
+        if (p.pre_scale != nullptr && oc + r < p.OC) x *= p.pre_scale[(size_t)n * p.OC + oc + r];
         if (p.bias != nullptr && oc + r < p.OC && split == 0) x += p.bias[oc + r];
         x = apply_act(x, p.act, p.slope);
+        if (p.post_scale != nullptr && oc + r < p.OC) x *= p.post_scale[(size_t)n * p.OC + oc + r];
         if (!of32) x = bf16_bits_to_float(float_to_bf16_bits(x));
         v[r] = x;
         if (stats && mok && oc + r < p.OC) { ssum[i][r] += x; ssq[i][r] += x * x; }
@@ -429,7 +431,8 @@ void plan_gather(GatherParams& p, GatherLaunch& l) {
   // Split the reduction when the grid cannot fill the chip and the output can take fp32 adds.
   p.ksplit = 1;
   const long blocks = (long)tiles * p.n_oc_tiles;
-  const bool can_split = split_reduction_allowed() && p.out_f32 != 0 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.stat_rows == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0;
+  const bool can_split = split_reduction_allowed() && p.out_f32 != 0 && p.act == GC_ACT_NONE && p.ch_sum == nullptr && p.stat_rows == nullptr && p.out_bf16 == nullptr && p.out_cstride == p.OC && p.out_coff == 0 &&
+                         p.pre_scale == nullptr && p.post_scale == nullptr;
   // (only for small outputs: the partial tiles are added with per-lane fp32 atomics whose access shape is slow)
   static const long split_max_out = getenv("GC_SPLIT_MAX_OUT") ? atol(getenv("GC_SPLIT_MAX_OUT")) : 65536;
   if (can_split && blocks > 0 && blocks < 128 && min_steps >= 16 && (long)p.N * p.OH * p.OW * p.OC <= split_max_out) {

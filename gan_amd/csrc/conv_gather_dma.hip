@@ -271,6 +271,7 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
   const int oc_w = oc0 + wo * (TO / C::WO);          // first channel of this wave's rows
   const bool linear = p.tt.n_classes == 1 && p.b == 1;   // forward pass: output pixel index == GEMM column index
   const bool fast = (C::FO % 2 == 0) && (m0 + TP <= Mc) && (oc0 + TO <= p.OC) && p.out_vec8 != 0 && p.act <= GC_ACT_LRELU;
+  const bool scaled = p.pre_scale != nullptr || p.post_scale != nullptr;
   float ssum[C::FO][4], ssq[C::FO][4];
 #pragma unroll
   for (int i = 0; i < C::FO; i++)
@@ -289,19 +290,31 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
     for (int j = 0; j < C::FP; j++) {
       const uint32_t m = (uint32_t)(m0 + wp_ * (TP / C::WP) + j * 16 + (lane & 15));
       size_t pix = m;
-      if (!linear) {
+      uint32_t n_of = 0;
+      if (!linear || scaled) {
         const uint32_t tmp = fd_div(m, div_ow), n = fd_div(tmp, div_oh);
         const int ow = (int)(m - tmp * (uint32_t)OWc), oh = (int)(tmp - n * (uint32_t)OHc);
         pix = ((size_t)n * p.OH + (oh * p.b + p.tt.cls_ph[cls])) * p.OW + (ow * p.b + p.tt.cls_pw[cls]);
+        n_of = n;
       }
       const size_t eoff = pix * p.out_cstride + p.out_coff + oc_w + g * 8;
+      const size_t soff = (size_t)n_of * p.OC + oc_w + g * 8;     // per-sample scales: [N][OC]
 #pragma unroll
       for (int i = 0; i < C::FO; i += 2) {
-        f32x4 a = acc[i][j] + bias_v[i], b = acc[i + 1][j] + bias_v[i + 1];
+        f32x4 a = acc[i][j], b = acc[i + 1][j];
+        if (p.pre_scale != nullptr) {
+          a *= *reinterpret_cast<const f32x4*>(p.pre_scale + soff + (i >> 1) * 32);
+          b *= *reinterpret_cast<const f32x4*>(p.pre_scale + soff + (i >> 1) * 32 + 4);
+        }
+        a += bias_v[i]; b += bias_v[i + 1];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           a[r] = a[r] > 0.f ? a[r] : a[r] * sl;
           b[r] = b[r] > 0.f ? b[r] : b[r] * sl;
+        }
+        if (p.post_scale != nullptr) {
+          a *= *reinterpret_cast<const f32x4*>(p.post_scale + soff + (i >> 1) * 32);
+          b *= *reinterpret_cast<const f32x4*>(p.post_scale + soff + (i >> 1) * 32 + 4);
         }
         const u32x2 pa = cvt_bf16x4(a), pb = cvt_bf16x4(b);
         if (sizeof(TOut) == 2) {
@@ -339,8 +352,10 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           float x = acc[i][j][r];
+          if (p.pre_scale != nullptr && oc + r < p.OC) x *= p.pre_scale[(size_t)n * p.OC + oc + r];
           if (p.bias != nullptr && oc + r < p.OC) x += p.bias[oc + r];
           x = apply_act(x, p.act, p.slope);
+          if (p.post_scale != nullptr && oc + r < p.OC) x *= p.post_scale[(size_t)n * p.OC + oc + r];
           if (sizeof(TOut) == 2) x = bf16_bits_to_float(float_to_bf16_bits(x));
           v[r] = x;
           if (stats && mok && oc + r < p.OC) { ssum[i][r] += x; ssq[i][r] += x * x; }

@@ -273,6 +273,12 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
 #pragma unroll
       for (int r = 0; r < 4; r++) { v[r] = acc[2 * m][pg][r]; v[4 + r] = acc[2 * m + 1][pg][r]; }
       if (vec8 && oc + 7 < p.OC) {
+        if (p.pre_scale != nullptr) {
+          const float* sc = p.pre_scale + (size_t)n * p.OC + oc;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+#pragma unroll
+          for (int r = 0; r < 4; r++) { v[r] *= s0[r]; v[4 + r] *= s1[r]; }
+        }
         if (p.bias != nullptr) {
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + oc), b1 = *reinterpret_cast<const f32x4*>(p.bias + oc + 4);
 #pragma unroll
@@ -284,6 +290,12 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
         } else {
 #pragma unroll
           for (int r = 0; r < 8; r++) v[r] = apply_act(v[r], p.act, p.slope);
+        }
+        if (p.post_scale != nullptr) {
+          const float* sc = p.post_scale + (size_t)n * p.OC + oc;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+#pragma unroll
+          for (int r = 0; r < 4; r++) { v[r] *= s0[r]; v[4 + r] *= s1[r]; }
         }
         if (MASK) {
           const TOut* mk = reinterpret_cast<const TOut*>(p.mask) + pix * p.out_cstride + p.out_coff + oc;
@@ -315,8 +327,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
         for (int r = 0; r < 8; r++)
           if (oc + r < p.OC) {
             float x = v[r];
+            if (p.pre_scale != nullptr) x *= p.pre_scale[(size_t)n * p.OC + oc + r];
             if (p.bias != nullptr) x += p.bias[oc + r];
             x = apply_act(x, p.act, p.slope);
+            if (p.post_scale != nullptr) x *= p.post_scale[(size_t)n * p.OC + oc + r];
             if (sizeof(TOut) == 4) reinterpret_cast<float*>(dst)[oc + r] = x;
             else reinterpret_cast<uint16_t*>(dst)[oc + r] = float_to_bf16_bits(x);
           }

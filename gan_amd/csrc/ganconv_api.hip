@@ -359,6 +359,10 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
     set_error("out_bf16 needs an fp32 output whose channel slice is a multiple of 4 channels at a multiple of 4");
     return GC_UNSUPPORTED_GEOMETRY;
   }
+  // per-sample output scales (a modulated convolution): the tiled and patch-resident kernels apply them
+  const bool scaled = p.pre_scale != nullptr || p.post_scale != nullptr;
+  if (scaled && p.OC % 4 != 0) { set_error("sample_scale / sample_scale_out need a multiple of 4 output channels"); return GC_UNSUPPORTED_GEOMETRY; }
+  if (!scaled) {
   if (plan_dot(p, l)) return launch_dot(p, l, out_dt == GC_F32, stream);
   if (plan_outer(p, l)) {
     const int rc = launch_outer(p, l, out_dt == GC_F32, stream);    // applies grad_mask itself
@@ -368,6 +372,7 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
   if (plan_image(p, l)) return launch_image(p, l, out_dt == GC_F32, stream);
   if (plan_point(p, l)) return launch_point(p, l, out_dt == GC_F32, stream);
   if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
+  }
   l.big_tile_ok = true;
   plan_gather(p, l);
   for (int c = 0; c < p.tt.n_classes; c++) {
@@ -388,7 +393,7 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
   const int64_t limit = (1ll << 31) - (1 << 20);
   const bool dma = l.in_bf16 && l.mode == kVecLoads && p.ksplit == 1 && (l.to == 256 || l.to == 128 || l.to == 64) &&
                    p.in_bytes + p.a_bias < limit && p.w_bytes < limit;
-  if (!dma && p.ksplit > 1 && p.split_ws != nullptr && l.in_bf16 && l.mode == kVecLoads && (l.to == 128 || l.to == 64) &&
+  if (!dma && !scaled && p.ksplit > 1 && p.split_ws != nullptr && l.in_bf16 && l.mode == kVecLoads && (l.to == 128 || l.to == 64) &&
       p.in_bytes + p.a_bias < limit && p.w_bytes < limit &&
       p.split_ws_bytes >= (size_t)p.n_pix_tiles * p.n_oc_tiles * l.to * 128 * sizeof(float) * 8) {
     // a small output planned as a split reduction with atomic adds: with scratch memory on offer the wave-specialised
@@ -403,7 +408,7 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
     }
   }
   if (dma && patch_kernel_allowed() && plan_patch(p, l)) return launch_patch(p, l, out_dt == GC_F32, stream);
-  if (dma && plan_ws(p, l)) {
+  if (dma && !scaled && plan_ws(p, l)) {
     const int rc = launch_ws(p, l, out_dt == GC_F32, stream);    // applies grad_mask in its epilogue
     p.mask = nullptr;
     return rc;
@@ -432,7 +437,9 @@ int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 static void fill_epilogue(GatherParams& p, const gc_epilogue* ep) {
   p.bias = nullptr; p.ch_sum = nullptr; p.ch_sumsq = nullptr; p.out_bf16 = nullptr; p.mask = nullptr; p.act = GC_ACT_NONE; p.slope = 0.f;
   p.stat_rows = nullptr; p.stat_cap = 0; p.stat_written = nullptr; p.split_ws = nullptr; p.split_ws_bytes = 0;
+  p.pre_scale = nullptr; p.post_scale = nullptr;
   if (ep != nullptr) {
+    p.pre_scale = ep->sample_scale; p.post_scale = ep->sample_scale_out;
     p.bias = ep->bias; p.ch_sum = ep->ch_sum; p.ch_sumsq = ep->ch_sumsq; p.act = ep->act; p.slope = ep->slope;
     p.out_bf16 = (uint16_t*)ep->out_bf16; p.mask = ep->grad_mask;
     if (p.mask != nullptr) { p.mask_slope = ep->slope; p.slope = 0.f; }
@@ -455,6 +462,14 @@ static int check_epilogue(const gc_epilogue* ep) {
     if (reinterpret_cast<uintptr_t>(ep->grad_mask) & 15u) { set_error("grad_mask must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
   }
   if (reinterpret_cast<uintptr_t>(ep->out_bf16) & 7u) { set_error("out_bf16 must be 8-byte aligned"); return GC_BAD_ARGUMENT; }
+  if (ep->sample_scale != nullptr || ep->sample_scale_out != nullptr) {
+    if (ep->ch_sum != nullptr || ep->stat_rows != nullptr || ep->grad_mask != nullptr || ep->out_bf16 != nullptr) {
+      set_error("sample_scale / sample_scale_out exclude statistics, grad_mask and out_bf16"); return GC_BAD_ARGUMENT;
+    }
+    if ((reinterpret_cast<uintptr_t>(ep->sample_scale) & 15u) || (reinterpret_cast<uintptr_t>(ep->sample_scale_out) & 15u)) {
+      set_error("sample_scale / sample_scale_out must be 16-byte aligned"); return GC_BAD_ARGUMENT;
+    }
+  }
   if (ep->ch_sumsq != nullptr && ep->ch_sum == nullptr) { set_error("ch_sumsq needs ch_sum"); return GC_BAD_ARGUMENT; }
   if (ep->stat_rows != nullptr) {
     if (ep->stat_rows_written == nullptr || ep->stat_rows_capacity < 0 || (reinterpret_cast<uintptr_t>(ep->stat_rows) & 7u)) {

@@ -126,32 +126,41 @@ def upsample2x_conv3x3(input, weight, bias=None, *, _wkey=0, precision=None, act
 
 
 def modulated_conv2d(input, weight, style, bias=None, stride=1, padding=0, demodulate=True, eps=1e-8, *, _wkey=0, precision=None,
-                     activation=None, negative_slope=0.2, out_dtype=None, weight_scale=1.0):
+                     activation=None, negative_slope=0.2, out_dtype=None, weight_scale=1.0, input_modulated=False, next_style=None):
     """EXTENSION -- not part of the reference, whose StyleGAN is version 1 (AdaIN, StyleGAN/model.py:179-261).  StyleGAN2's
     modulated convolution: per sample n the weight is w'[o, i, k] = style[n, i] * c * weight[o, i, k] (c = weight_scale)
     and, with `demodulate`, each output channel of w' is normalised to unit L2 norm (plus eps under the root); the result
-    is conv2d(input[n], w'[n]) (+ bias, activation).  Computed without per-sample weights: the style scales the INPUT
-    channels in front of one ordinary convolution (gan_amd kernels), the normalisation factor
-    d[n, o] = rsqrt(sum_i style[n, i]^2 * sum_k (c * weight[o, i, k])^2 + eps) scales the OUTPUT channels behind it.
-    style: [N, Cin].  Differentiable to second order in input, weight and style."""
+    is conv2d(input[n], w'[n]) (+ bias, activation).  Computed without per-sample weights, as one ordinary convolution
+    whose kernel applies the normalisation factor d[n, o] = rsqrt(sum_i style[n, i]^2 * sum_k (c * weight[o, i, k])^2 + eps)
+    to its accumulators in front of bias and activation.  The style scales the INPUT channels: by a sweep over the input
+    here, or -- `input_modulated=True` -- by whoever produced the input.  `next_style` ([N, Cout]) asks this call to be that
+    producer for the next layer: its output stage multiplies the activated result by next_style[n, o], so a chain of
+    modulated convolutions is one launch per layer.  style: [N, Cin].  Differentiable (to second order) in input, weight,
+    bias, style and next_style; an entry of next_style that is exactly zero receives a zero gradient."""
     _check_input(input, weight)
-    N, Cin = input.shape[0], input.shape[1]
+    N, Cin, Cout = input.shape[0], input.shape[1], weight.shape[0]
     if style.shape != (N, Cin):
         raise RuntimeError(f"ganconv: style must be [N, Cin] = [{N}, {Cin}], got {tuple(style.shape)}")
-    if Cin % 4 or weight.shape[0] % 4:
+    if next_style is not None and next_style.shape != (N, Cout):
+        raise RuntimeError(f"ganconv: next_style must be [N, Cout] = [{N}, {Cout}], got {tuple(next_style.shape)}")
+    if Cin % 4 or Cout % 4:
         raise RuntimeError("ganconv: modulated_conv2d needs channel counts that are multiples of 4")
     style = style.to(torch.float32)
-    y = conv2d(ops.channel_scale(input, style), weight, None, stride, padding, _wkey=_wkey, precision=precision, out_dtype=out_dtype,
-               weight_scale=weight_scale)
+    x = input if input_modulated else ops.channel_scale(input, style)
+    pre = None
     if demodulate:
         w2 = (weight.to(torch.float32) * float(weight_scale)).square().sum((2, 3))          # [Cout, Cin]
-        y = ops.channel_scale(y, torch.rsqrt(style.square() @ w2.t() + eps))
-    if bias is not None:
-        y = y + bias.to(y.dtype).view(1, -1, 1, 1)
-    if activation is not None:
-        code = _act_code(activation)
-        y = (torch.relu(y) if code == 1 else torch.nn.functional.leaky_relu(y, negative_slope) if code == 2 else
-             torch.tanh(y) if code == 3 else torch.sigmoid(y))
+        pre = torch.rsqrt(style.square() @ w2.t() + eps)
+    code = _act_code(activation)
+    prec = ops.get_precision() if precision is None else precision
+    fused_act = code if code <= 2 else 0
+    y = ops.modconv_fprop(x, weight, bias, pre, next_style if fused_act == code else None, _single(stride, "stride"),
+                          _single(padding, "padding"), prec, _wkey, fused_act, float(negative_slope), _out_code(out_dtype),
+                          float(weight_scale))
+    if fused_act != code:      # tanh / sigmoid: behind the kernel
+        y = torch.tanh(y) if code == 3 else torch.sigmoid(y)
+        if next_style is not None:
+            y = ops.channel_scale(y, next_style.to(torch.float32))
     return y
 
 

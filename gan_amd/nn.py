@@ -125,9 +125,21 @@ class ModulatedConv2d(_KeyedWeight, torch.nn.Module):
         torch.nn.init.ones_(self.affine.bias)
         self.scale = 1.0 / (in_channels * kernel_size * kernel_size) ** 0.5
 
-    def forward(self, input, latent):
-        return F.modulated_conv2d(input, self.weight, self.affine(latent), self.bias, 1, self.padding, self.demodulate, self.eps,
-                                  _wkey=self._wkey_for(self.weight), weight_scale=self.scale)
+    def style(self, latent):
+        """The per-input-channel scale [N, Cin] of this layer for a latent [N, style_dim]."""
+        return self.affine(latent)
+
+    def forward(self, input, latent=None, *, style=None, input_modulated=False, next_style=None, activation=None, negative_slope=0.2):
+        """`style` (= self.style(latent)) may be passed instead of the latent.  A chain of these layers runs as one launch per
+        layer when every layer hands the next one's style to its own call:
+            s1, s2 = conv1.style(w), conv2.style(w)
+            h = conv1(x, style=s1, next_style=s2, activation="leaky_relu")        # stores s2 * lrelu(...)
+            y = conv2(h, style=s2, input_modulated=True, activation="leaky_relu")"""
+        if style is None:
+            style = self.affine(latent)
+        return F.modulated_conv2d(input, self.weight, style, self.bias, 1, self.padding, self.demodulate, self.eps,
+                                  _wkey=self._wkey_for(self.weight), weight_scale=self.scale, activation=activation,
+                                  negative_slope=negative_slope, input_modulated=input_modulated, next_style=next_style)
 
 
 class BlurLayer(torch.nn.Module):

@@ -942,6 +942,32 @@ def _wanted(ctx, i):
         return True
 
 
+def _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_x, need_w, x_act_slope=-1.0):
+    """(gx, gw) of y = conv(x, alpha * w) from gy: the data-gradient and weight-gradient launches (the weight gradient goes to
+    an active weight_gradient_sink instead when one accepts it; with backward overlap on, it runs on the side stream)."""
+    gx = gw = None
+
+    def dgrad():
+        if x_act_slope >= 0.0:
+            return conv_dgrad_masked(gy, w, x, x_act_slope, stride, padding, precision, wkey, _code_of(x.dtype), alpha)
+        return conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
+
+    if need_w and _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
+        need_w = False
+    if _overlap and need_x and need_w and gy.is_cuda:
+        with _SideLaunch(gy.device) as side:
+            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
+        gx = dgrad()
+        side.join()
+        gw = gw.to(w.dtype)
+    else:
+        if need_x:
+            gx = dgrad()
+        if need_w:
+            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
+    return gx, gw
+
+
 def _fprop_setup(ctx, inputs, output):
     x, w, bias, stride, padding, precision, wkey, act, slope, _, alpha, defer_act_grad, x_act_slope = inputs
     ctx.edges = _edges(x, w, bias)
@@ -969,26 +995,7 @@ def _fprop_backward(ctx, gy):
             gy = _act_backward(gy, y, act, slope)
     else:
         x, w = ctx.saved_tensors
-    gx = gw = None
-
-    def dgrad():
-        if ctx.x_act_slope >= 0.0:
-            return conv_dgrad_masked(gy, w, x, ctx.x_act_slope, stride, padding, precision, wkey, _code_of(x.dtype), alpha)
-        return conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
-
-    if need_w and _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
-        need_w = False
-    if _overlap and need_x and need_w and gy.is_cuda:
-        with _SideLaunch(gy.device) as side:
-            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
-        gx = dgrad()
-        side.join()
-        gw = gw.to(w.dtype)
-    else:
-        if need_x:
-            gx = dgrad()
-        if need_w:
-            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
+    gx, gw = _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_x, need_w, ctx.x_act_slope)
     if need_b and gb is None:
         gb = channel_sum(gy)
     return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
@@ -1616,6 +1623,150 @@ torch.library.register_autograd("ganconv::channel_scale", _channel_scale_backwar
                                 setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1]))
 torch.library.register_autograd("ganconv::rowdot", _rowdot_backward,
                                 setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1]))
+
+
+# ---- the fused form: both per-sample scales in the convolution's output stage ---------------------------------------
+_MOD_SLOPES = {_lib.GC_ACT_NONE: 1.0, _lib.GC_ACT_RELU: 0.0}
+
+
+@torch.library.custom_op("ganconv::modconv_fprop", mutates_args=())
+def modconv_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], pre: Optional[Tensor], post: Optional[Tensor], stride: int, padding: int,
+                  precision: int, wkey: int, act: int = 0, slope: float = 0.0, out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
+    """post[n, o] * act(pre[n, o] * conv2d(x, alpha * w)[n, o] + bias[o]) as ONE launch: pre (the demodulation factor) and post
+    (the style of the modulated convolution that reads this output next) are float [N, Cout] tables applied in the kernel's
+    output stage.  act: none, ReLU or LeakyReLU.  An extension: the reference has no modulated convolution
+    (StyleGAN/model.py:179-261 is version 1)."""
+    _check_cuda(x, w, bias, pre, post)
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = w.shape
+    if Cin_w != Cin:
+        raise RuntimeError(f"ganconv: weight expects {Cin_w} input channels, input has {Cin}")
+    if act not in (_lib.GC_ACT_NONE, _lib.GC_ACT_RELU, _lib.GC_ACT_LRELU):
+        raise RuntimeError("ganconv: the fused modulated convolution takes no activation, ReLU or LeakyReLU")
+    if Cout % 4:
+        raise RuntimeError("ganconv: the fused modulated convolution needs a multiple of 4 output channels")
+    for t in (pre, post):
+        if t is not None and t.shape != (N, Cout):
+            raise RuntimeError(f"ganconv: per-sample output scales must be [N, Cout] = [{N}, {Cout}], got {tuple(t.shape)}")
+    Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
+    x = _nhwc(x)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=_out_dtype(x, out_dtype), device=x.device, memory_format=torch.channels_last)
+    if _dma_ok(x, Cin, Cout, precision):
+        x = _to_bf16(x)
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(y))
+    wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey, alpha)
+    ep = Epilogue()
+    ep.act, ep.slope = act, slope
+    keep = [t if t is None else t.to(torch.float32).contiguous() for t in (bias, pre, post)]
+    if keep[0] is not None:
+        ep.bias = keep[0].data_ptr()
+    if keep[1] is not None:
+        ep.sample_scale = keep[1].data_ptr()
+    if keep[2] is not None:
+        ep.sample_scale_out = keep[2].data_ptr()
+    _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
+                                          ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep), _stream()), "gc_conv2d_fprop")
+    return y
+
+
+@modconv_fprop.register_fake
+def _(x, w, bias, pre, post, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1, alpha=1.0):
+    N, _, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    return x.new_empty((N, Cout, (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1),
+                       dtype=_out_dtype(x, out_dtype))
+
+
+@torch.library.custom_op("ganconv::mod_act_backward", mutates_args=())
+def mod_act_backward(g: Tensor, out: Tensor, pre: Optional[Tensor], post: Optional[Tensor], slope: float) -> tuple[Tensor, Tensor, Tensor]:
+    """The backward sweep of modconv_fprop's output stage from the incoming gradient g and the stored output (slope: 1 for no
+    activation, 0 for ReLU):  (gc, dot, sum) with gc = pre * m * post * g the gradient of the raw convolution output
+    (m = 1 where post * out > 0, else slope), dot[n, c] = sum_p g * out and sum[n, c] = sum_p m * post * g."""
+    _check_cuda(g, out, pre, post)
+    N, C, H, W = out.shape
+    if g.shape != out.shape:
+        raise RuntimeError("ganconv: gradient and output shapes differ")
+    out = _nhwc(out)
+    g = _nhwc(g if g.dtype == out.dtype else g.to(out.dtype))
+    pre = None if pre is None else pre.to(torch.float32).contiguous()
+    post = None if post is None else post.to(torch.float32).contiguous()
+    gc = torch.empty_like(out, memory_format=torch.channels_last)
+    dot = torch.empty(N, C, dtype=torch.float32, device=out.device)
+    sm = torch.empty(N, C, dtype=torch.float32, device=out.device)
+    L = _lib.lib()
+    ws = torch.empty(max(L.gc_modulated_act_backward_workspace_bytes(N, H * W, C), 16), dtype=torch.uint8, device=out.device)
+    _lib.check(L.gc_modulated_act_backward(_ptr(g), _ptr(out), None if pre is None else _ptr(pre), None if post is None else _ptr(post),
+                                           _ptr(gc), _ptr(dot), _ptr(sm), _ptr(ws), ws.numel(), N, H * W, C, _dtype_code(out), slope,
+                                           _stream()), "gc_modulated_act_backward")
+    return gc, dot, sm
+
+
+@mod_act_backward.register_fake
+def _(g, out, pre, post, slope):
+    N, C = out.shape[0], out.shape[1]
+    return (torch.empty_like(out, memory_format=torch.channels_last), out.new_empty(N, C, dtype=torch.float32),
+            out.new_empty(N, C, dtype=torch.float32))
+
+
+def _modconv_setup(ctx, inputs, output):
+    x, w, bias, pre, post, stride, padding, precision, wkey, act, slope, _, alpha = inputs
+    ctx.edges = _edges(x, w, bias)
+    ctx.save_for_backward(x, w, output, bias, pre, post)
+    ctx.cfg = (stride, padding, precision, wkey, _MOD_SLOPES.get(act, slope), alpha)
+
+
+def _modconv_backward(ctx, g):
+    """out = post * z, z = act(u), u = pre * c + bias, c = conv(x, w).  Only out is kept: for these activations
+    act'(u) * u = z, hence sum_p (dL/du) * u = sum_p g * out, which gives dL/dpre = sum_p (dL/du) * c without c."""
+    stride, padding, precision, wkey, slope, alpha = ctx.cfg
+    x, w, out, bias, pre, post = ctx.saved_tensors
+    gc, dot, sm = mod_act_backward(g, out, pre, post, slope)
+    need_x, need_w = _wanted(ctx, 0), _wanted(ctx, 1)
+    gx, gw = _input_weight_grads(x, w, gc, stride, padding, precision, wkey, alpha, need_x, need_w)
+    gb = gpre = gpost = None
+    if bias is not None and ctx.needs_input_grad[2]:
+        gb = sm.sum(0).to(bias.dtype)
+    if pre is not None and ctx.needs_input_grad[3]:
+        gpre = ((dot if bias is None else dot - bias.to(torch.float32) * sm) / pre.to(torch.float32)).to(pre.dtype)
+    if post is not None and ctx.needs_input_grad[4]:
+        pf = post.to(torch.float32)
+        gpost = torch.where(pf != 0, dot / torch.where(pf != 0, pf, torch.ones_like(pf)), torch.zeros_like(pf)).to(post.dtype)
+    return gx, gw, gb, gpre, gpost, None, None, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::modconv_fprop", _modconv_backward, setup_context=_modconv_setup)
+
+
+def _mod_bwd_setup(ctx, inputs, output):
+    g, out, pre, post, slope = inputs
+    ctx.save_for_backward(g, out, pre, post)
+    ctx.slope = slope
+
+
+def _mod_bwd_backward(ctx, v_gc, v_dot, v_sum):
+    """Second order (a penalty on gradients taken through a modulated convolution): the sweep is linear in g for a fixed
+    activation pattern; written with differentiable torch operators."""
+    g, out, pre, post = ctx.saved_tensors
+    f = torch.float32
+    gf, of = g.to(f), out.to(f)
+    one = torch.ones((), dtype=f, device=out.device)
+    pr = (one if pre is None else pre.to(f)[:, :, None, None])
+    po = (one if post is None else post.to(f)[:, :, None, None])
+    m = torch.where(po * of > 0, one, one * ctx.slope)
+    vg = torch.zeros_like(of) if v_gc is None else v_gc.to(f)
+    vd = None if v_dot is None else v_dot.to(f)[:, :, None, None]
+    vs = None if v_sum is None else v_sum.to(f)[:, :, None, None]
+    inner = pr * vg if vs is None else pr * vg + vs            # cotangent of m * post * g
+    g_g = po * m * inner
+    if vd is not None:
+        g_g = g_g + of * vd
+    g_out = None if vd is None else (gf * vd).to(out.dtype)
+    g_pre = None if pre is None else (po * m * gf * vg).sum((2, 3)).to(pre.dtype)
+    g_post = None if post is None else (m * gf * inner).sum((2, 3)).to(post.dtype)
+    return g_g.to(g.dtype), g_out, g_pre, g_post, None
+
+
+torch.library.register_autograd("ganconv::mod_act_backward", _mod_bwd_backward, setup_context=_mod_bwd_setup)
 
 
 # ---- channel concatenation fused with the activation behind it (U-Net skip connections, Pix2Pix/models.py:128-145) ----

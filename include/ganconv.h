@@ -107,6 +107,14 @@ typedef struct gc_epilogue {
                              split over more workgroups, whose fp32 partial tiles meet here and are added in a fixed order by a
                              second launch (bit-wise reproducible).  4 * 32 bytes per output element is always enough. */
   size_t workspace_bytes;
+  const float* sample_scale;     /* NULL, or float[N][C], 16-byte aligned: the accumulator of (sample n, channel c) is multiplied by
+                             it in front of the bias:  v = sample_scale[n][c] * acc + bias[c].  The demodulation factor of a
+                             StyleGAN2-style modulated convolution -- an EXTENSION, the reference has none (its StyleGAN is
+                             version 1, StyleGAN/model.py:179-261). */
+  const float* sample_scale_out; /* NULL, or float[N][C], 16-byte aligned: the stored value is sample_scale_out[n][c] * act(v) --
+                             the modulation (style) of the NEXT modulated convolution applied by the producer of its input, so
+                             that a chain of modulated convolutions is one launch per layer.  Both need C a multiple of 4 and
+                             exclude statistics, grad_mask and out_bf16. */
 } gc_epilogue;
 
 int gc_version(void);
@@ -347,6 +355,20 @@ int gc_channel_scale(const void* x, const float* s, void* y, int32_t N, int32_t 
 size_t gc_rowdot_workspace_bytes(int32_t N, int32_t HW, int32_t C);
 int gc_rowdot(const void* a, const void* b, float* out, void* workspace, size_t workspace_bytes, int32_t N, int32_t HW, int32_t C,
               int32_t dtype, void* stream);
+
+/* EXTENSION, as above: the backward sweep of the fused form, where gc_epilogue's sample_scale (pre) and sample_scale_out
+ * (post) put both per-sample scales into the convolution's output stage,  out = post * act(pre * conv + bias)  with act
+ * none (slope 1), ReLU (slope 0) or LeakyReLU.  From the incoming gradient g and the STORED out (nothing else is kept from
+ * the forward pass: act'(u) * u = act(u) for these activations), one pass writes
+ *   gc[n, p, c] = pre[n, c] * m * post[n, c] * g[n, p, c]     m = 1 where post * out > 0, else slope: the gradient of the
+ *                                                             convolution's raw output, input of its dgrad / wgrad
+ *   dot[n, c]   = sum over p of g * out                       d L / d post = dot / post
+ *   sum[n, c]   = sum over p of m * post * g                  d L / d bias = sum over n;  d L / d pre = (dot - bias * sum) / pre
+ * pre / post may be NULL (= 1).  Fixed-order reductions, workspace as for gc_rowdot. */
+size_t gc_modulated_act_backward_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int gc_modulated_act_backward(const void* g, const void* out, const float* pre, const float* post, void* gc, float* dot, float* sum,
+                              void* workspace, size_t workspace_bytes, int32_t N, int32_t HW, int32_t C, int32_t dtype, float slope,
+                              void* stream);
 
 /* The weight gradient of ONE layer summed over several (x, gy) pairs in one launch: gw (+)= alpha * sum over segments g of
  * wgrad(xs[g], gys[g]), segment g holding Ns[g] samples (1 to 4 segments; desc->N is ignored, everything else in the
