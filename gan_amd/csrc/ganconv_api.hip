@@ -209,9 +209,10 @@ __device__ __forceinline__ void blur_load(const T* x, size_t off, bool ok, float
   }
 }
 
-template <typename T, int V>
-__global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int CV,
-                                                             int strips, uint32_t total) {
+// MASK: the stored value is multiplied by 1 where mask > 0 and by `slope` elsewhere (mask: a tensor like y).
+template <typename T, int V, bool MASK>
+__global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ mask, float slope,
+                                                             int N, int H, int W, int CV, int strips, uint32_t total) {
   const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
   if (e >= total) return;
   const int cv = (int)(e % (uint32_t)CV);
@@ -247,6 +248,12 @@ __global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* __restrict
 #pragma unroll
     for (int i = 0; i < V; i++) o[i] = (prev[i] + 2.f * cur[i] + nxt[i]) * (1.f / 16.f);
     const size_t off = base + (size_t)h * rowp;
+    if constexpr (MASK) {
+      float m[V];
+      blur_load<T, V>(mask, off, true, m);
+#pragma unroll
+      for (int i = 0; i < V; i++) o[i] = m[i] > 0.f ? o[i] : o[i] * slope;
+    }
     if constexpr (sizeof(T) == 4) {
       *reinterpret_cast<f32x4*>(y + off) = f32x4{o[0], o[1], o[2], o[3]};
     } else if constexpr (V == 8) {
@@ -899,31 +906,51 @@ int gc_noalloc_scratch(void** ptr, size_t* bytes) {
   return scratch_of_current_device(ptr);
 }
 
-int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
-  if (N < 0 || H <= 0 || W <= 0 || C <= 0) { set_error("gc_dwblur3x3: bad shape"); return GC_BAD_ARGUMENT; }
-  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("gc_dwblur3x3: unknown dtype"); return GC_BAD_ARGUMENT; }
+}  // extern "C"
+
+template <typename T, int V>
+static void launch_blur(const void* x, void* y, const void* mask, float slope, int N, int H, int W, int C, int strips, size_t total,
+                        hipStream_t stream) {
+  const unsigned blocks = (unsigned)((total + kThreads - 1) / kThreads);
+  if (mask != nullptr)
+    hipLaunchKernelGGL((dwblur3x3_kernel<T, V, true>), dim3(blocks), dim3(kThreads), 0, stream, (const T*)x, (T*)y, (const T*)mask, slope, N, H, W,
+                       C / V, strips, (uint32_t)total);
+  else
+    hipLaunchKernelGGL((dwblur3x3_kernel<T, V, false>), dim3(blocks), dim3(kThreads), 0, stream, (const T*)x, (T*)y, (const T*)nullptr, 0.f, N, H,
+                       W, C / V, strips, (uint32_t)total);
+}
+
+static int blur_run(const void* x, void* y, const void* mask, float slope, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                    void* stream, const char* who) {
+  if (N < 0 || H <= 0 || W <= 0 || C <= 0) { set_error("%s: bad shape", who); return GC_BAD_ARGUMENT; }
+  if (dtype != GC_F32 && dtype != GC_BF16) { set_error("%s: unknown dtype", who); return GC_BAD_ARGUMENT; }
   if (N == 0) return GC_OK;
-  if (x == nullptr || y == nullptr) { set_error("gc_dwblur3x3: null pointer"); return GC_BAD_ARGUMENT; }
-  if (C % 4 != 0 || !aligned16(x) || !aligned16(y)) {
-    set_error("gc_dwblur3x3: channels must be a multiple of 4 and buffers 16-byte aligned (C=%d)", C);
+  if (x == nullptr || y == nullptr) { set_error("%s: null pointer", who); return GC_BAD_ARGUMENT; }
+  if (C % 4 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(mask)) {
+    set_error("%s: channels must be a multiple of 4 and buffers 16-byte aligned (C=%d)", who, C);
     return GC_UNSUPPORTED_GEOMETRY;
   }
   const int V = (dtype == GC_BF16 && C % 8 == 0) ? 8 : 4;
   const int strips = (H + kBlurRows - 1) / kBlurRows;
   const size_t total = (size_t)N * strips * W * (C / V);
-  if (total >= (1ull << 32) - kThreads) { set_error("gc_dwblur3x3: tensor too large"); return GC_UNSUPPORTED_GEOMETRY; }
-  const unsigned blocks = (unsigned)((total + kThreads - 1) / kThreads);
-  ProfScope ps("gc::dwblur3x3_kernel", 0.0, (hipStream_t)stream);
-  if (dtype == GC_F32)
-    hipLaunchKernelGGL((dwblur3x3_kernel<float, 4>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W,
-                       C / 4, strips, (uint32_t)total);
-  else if (V == 4)
-    hipLaunchKernelGGL((dwblur3x3_kernel<uint16_t, 4>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
-                       (uint16_t*)y, N, H, W, C / 4, strips, (uint32_t)total);
-  else
-    hipLaunchKernelGGL((dwblur3x3_kernel<uint16_t, 8>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
-                       (uint16_t*)y, N, H, W, C / 8, strips, (uint32_t)total);
+  if (total >= (1ull << 32) - kThreads) { set_error("%s: tensor too large", who); return GC_UNSUPPORTED_GEOMETRY; }
+  ProfScope ps(mask != nullptr ? "gc::dwblur3x3_masked_kernel" : "gc::dwblur3x3_kernel", 0.0, (hipStream_t)stream);
+  if (dtype == GC_F32) launch_blur<float, 4>(x, y, mask, slope, N, H, W, C, strips, total, (hipStream_t)stream);
+  else if (V == 4) launch_blur<uint16_t, 4>(x, y, mask, slope, N, H, W, C, strips, total, (hipStream_t)stream);
+  else launch_blur<uint16_t, 8>(x, y, mask, slope, N, H, W, C, strips, total, (hipStream_t)stream);
   return check_hip(hipGetLastError(), "dwblur3x3 launch");
+}
+
+extern "C" {
+
+int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+  return blur_run(x, y, nullptr, 0.f, N, H, W, C, dtype, stream, "gc_dwblur3x3");
+}
+
+int gc_dwblur3x3_masked(const void* x, void* y, const void* mask, float slope, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                        void* stream) {
+  if (mask == nullptr) { set_error("gc_dwblur3x3_masked: null mask"); return GC_BAD_ARGUMENT; }
+  return blur_run(x, y, mask, slope, N, H, W, C, dtype, stream, "gc_dwblur3x3_masked");
 }
 
 int gc_profile_enable(int on) {

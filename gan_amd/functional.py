@@ -164,8 +164,11 @@ def modulated_conv2d(input, weight, style, bias=None, stride=1, padding=0, demod
     return y
 
 
-def blur3x3(input):
-    return ops.blur3x3(input)
+def blur3x3(input, input_activation_slope=None):
+    """Depthwise [1 2 1] x [1 2 1] / 16 blur, zero padding 1.  `input_activation_slope`: as for conv2d -- the input is the
+    output of a convolution called with defer_activation_grad=True whose only consumer this blur is; the blur's backward
+    sweep applies that activation's derivative."""
+    return ops.blur3x3(input, -1.0 if input_activation_slope is None else float(input_activation_slope))
 
 
 def avg_pool2x2(input):

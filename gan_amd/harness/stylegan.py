@@ -80,12 +80,13 @@ class _EqConvCore(gnn.Conv2d):
     def effective_weight(self):          # what the reference's forward pre-hook would store in `.weight`
         return self.weight_orig * self.scale
 
-    def forward(self, x, out_dtype=None, upsample=False):
+    def forward(self, x, out_dtype=None, upsample=False, defer=False, in_slope=None):
         if upsample:      # nearest x2 in front of the 3x3 convolution (StyleGAN/model.py:236-238), folded into the weight
             return GF.upsample2x_conv3x3(x, self.weight_orig, self.bias, activation=self.activation, negative_slope=self.negative_slope,
                                          out_dtype=out_dtype, weight_scale=self.scale)
         return GF.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, _wkey=self._wkey_for(self.weight_orig),
-                         activation=self.activation, negative_slope=self.negative_slope, out_dtype=out_dtype, weight_scale=self.scale)
+                         activation=self.activation, negative_slope=self.negative_slope, out_dtype=out_dtype, weight_scale=self.scale,
+                         defer_activation_grad=defer, input_activation_slope=in_slope)
 
 
 class EqualizedConv2d(torch.nn.Module):
@@ -98,8 +99,10 @@ class EqualizedConv2d(torch.nn.Module):
             self.conv2d.activation, self.conv2d.negative_slope = "leaky_relu", LRELU
         self.keep_fp32 = keep_fp32
 
-    def forward(self, x, out_dtype=None, upsample=False):
-        return self.conv2d(x, torch.float32 if self.keep_fp32 else (out_dtype or _store["dtype"]), upsample)
+    def forward(self, x, out_dtype=None, upsample=False, defer=False, in_slope=None):
+        """defer / in_slope: the LeakyReLU's derivative is applied by the one consumer of this layer's output (its data-gradient
+        kernel or the blur's backward sweep) instead of a sweep of its own; in_slope marks this layer as such a consumer."""
+        return self.conv2d(x, torch.float32 if self.keep_fp32 else (out_dtype or _store["dtype"]), upsample, defer, in_slope)
 
 
 class _EqLinearCore(torch.nn.Linear):
@@ -165,8 +168,8 @@ class Blur(torch.nn.Module):
         self.register_buffer("weight", k)
         self.register_buffer("weight_flip", k.clone())      # the kernel is symmetric: its flip is itself
 
-    def forward(self, x):
-        return GF.blur3x3(x)
+    def forward(self, x, in_slope=None):
+        return GF.blur3x3(x, in_slope)
 
 
 class LearnedConstant(torch.nn.Module):
@@ -326,15 +329,20 @@ class CriticBlock(torch.nn.Module):
         else:
             self.convolution_2 = EqualizedConv2d(cout, cout, k2, padding=p2, lrelu=True)
 
-    def forward(self, x, out_dtype=None):
-        h = _children(self.convolution_1)[0](x)
+    def forward(self, x, out_dtype=None, in_slope=None, defer_out=False):
+        """in_slope: x is the activated output of the block in front, which left its LeakyReLU's derivative to this block's first
+        data-gradient kernel; defer_out: this block leaves its last LeakyReLU's derivative to the next block in the same way.
+        Inside the block the blur's backward sweep applies the first LeakyReLU's derivative.  Results are unchanged; the
+        backward pass loses one elementwise sweep per LeakyReLU."""
+        fuse = _store["fused_chain"] and x.is_cuda
+        conv1 = _children(self.convolution_1)[0]
         if self.mode == "plain":
-            return self.convolution_2(h, out_dtype)
+            return self.convolution_2(conv1(x, in_slope=in_slope), out_dtype)
         blur, conv = _children(self.convolution_2)[:2]
-        h = conv(blur(h), out_dtype)
+        h = blur(conv1(x, defer=fuse, in_slope=in_slope), LRELU if fuse else None)
         if self.mode == "pooled":
-            h = torch.nn.functional.leaky_relu(_children(self.convolution_2)[2](h), LRELU)
-        return h
+            return torch.nn.functional.leaky_relu(_children(self.convolution_2)[2](conv(h, out_dtype)), LRELU)
+        return conv(h, out_dtype, defer=defer_out)
 
 
 class Discriminator(torch.nn.Module):
@@ -362,12 +370,19 @@ class Discriminator(torch.nn.Module):
         # The minibatch statistic divides by a spread over the batch that bf16 rounding can collapse to exactly zero: the
         # features it is taken of (the output of the last block but one) are produced and kept in fp32.
         h = entry(x, torch.float32 if pg == 0 else None)
+        fuse = _store["fused_chain"] and x.is_cuda
+        deferred = False                            # h's LeakyReLU derivative is left to the block that reads h
         for level in range(first, n):
             last = level == n - 1
             if last:                                # minibatch standard deviation as one more feature map
                 spread = h.std(dim=0, unbiased=False).mean()
                 h = torch.cat([h, spread.expand(h.shape[0], 1, h.shape[2], h.shape[3])], dim=1)
-            h = self.downsampling_blocks[level](h, torch.float32 if level == n - 2 else None)
+            block = self.downsampling_blocks[level]
+            # the next block's first convolution is the only reader of this block's output: not in front of the statistic's
+            # concatenation (and its fp32 features), nor where the output is blended with the down-scaled image
+            defer_out = (fuse and block.mode == "strided" and level < n - 2 and not (level == first and 0 <= alpha < 1))
+            h = block(h, torch.float32 if level == n - 2 else None, in_slope=LRELU if deferred else None, defer_out=defer_out)
+            deferred = defer_out
             if level == first and 0 <= alpha < 1 and not last:
                 if self.use_activations:
                     # the reference down-scales the image and converts it, then overwrites the result with LeakyReLU(h):

@@ -1096,25 +1096,73 @@ def _wgrad_backward(ctx, v):
 torch.library.register_autograd("ganconv::conv_wgrad", _wgrad_backward, setup_context=_wgrad_setup)
 
 
-@torch.library.custom_op("ganconv::blur3x3", mutates_args=())
-def blur3x3(x: Tensor) -> Tensor:
-    """Depthwise [1 2 1]x[1 2 1]/16 blur with zero padding 1 (reference StyleGAN/model.py:82-150)."""
-    _check_cuda(x)
+def _blur_launch(x, mask, slope):
+    _check_cuda(x, mask)
     N, C, H, W = x.shape
     x = _nhwc(x)
     y = torch.empty_like(x, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().gc_dwblur3x3(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), N, H, W, C, _dtype_code(x), _stream()),
-               "gc_dwblur3x3")
+    if mask is None:
+        _lib.check(_lib.lib().gc_dwblur3x3(_ptr(x), _ptr(y), N, H, W, C, _dtype_code(x), _stream()), "gc_dwblur3x3")
+    else:
+        if mask.shape != x.shape:
+            raise RuntimeError("ganconv: the activated tensor does not have the gradient's shape")
+        mask = _nhwc(mask if mask.dtype == x.dtype else mask.to(x.dtype))
+        _lib.check(_lib.lib().gc_dwblur3x3_masked(_ptr(x), _ptr(y), _ptr(mask), slope, N, H, W, C, _dtype_code(x), _stream()),
+                   "gc_dwblur3x3_masked")
     return y
 
 
+@torch.library.custom_op("ganconv::blur3x3", mutates_args=())
+def blur3x3(x: Tensor, x_act_slope: float = -1.0) -> Tensor:
+    """Depthwise [1 2 1]x[1 2 1]/16 blur with zero padding 1 (reference StyleGAN/model.py:82-150).  x_act_slope >= 0 (the
+    forward result is unchanged): x is the output of a ReLU (0) / LeakyReLU epilogue called with defer_act_grad, and the
+    gradient returned for x is already multiplied by that activation's derivative (one sweep: blur3x3_masked)."""
+    return _blur_launch(x, None, 0.0)
+
+
 @blur3x3.register_fake
-def _(x):
+def _(x, x_act_slope=-1.0):
     return torch.empty_like(x)
 
 
-# the kernel is symmetric, so the blur is self-adjoint: its backward (and double backward) is the blur itself
-torch.library.register_autograd("ganconv::blur3x3", lambda ctx, g: blur3x3(g), setup_context=lambda ctx, inputs, output: None)
+@torch.library.custom_op("ganconv::blur3x3_masked", mutates_args=())
+def blur3x3_masked(g: Tensor, x: Tensor, x_act_slope: float) -> Tensor:
+    """blur3x3(g) * (x > 0 ? 1 : x_act_slope)."""
+    return _blur_launch(g, x, x_act_slope)
+
+
+@blur3x3_masked.register_fake
+def _(g, x, x_act_slope):
+    return torch.empty_like(g)
+
+
+def _blur_setup(ctx, inputs, output):
+    ctx.slope = inputs[1]
+    if ctx.slope >= 0.0:
+        ctx.save_for_backward(inputs[0])
+
+
+def _blur_backward(ctx, g):
+    # the kernel is symmetric, so the blur is self-adjoint: its backward (and double backward) is the blur itself
+    if ctx.slope >= 0.0:
+        return blur3x3_masked(g, ctx.saved_tensors[0], ctx.slope), None
+    return blur3x3(g), None
+
+
+def _blur_masked_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1])
+    ctx.slope = inputs[2]
+
+
+def _blur_masked_backward(ctx, u):
+    """Linear in g for a fixed mask: the adjoint applies the mask first, then the blur."""
+    (x,) = ctx.saved_tensors
+    u = _act_backward(u, x, _lib.GC_ACT_LRELU if ctx.slope != 0.0 else _lib.GC_ACT_RELU, ctx.slope)
+    return blur3x3(u), None, None
+
+
+torch.library.register_autograd("ganconv::blur3x3", _blur_backward, setup_context=_blur_setup)
+torch.library.register_autograd("ganconv::blur3x3_masked", _blur_masked_backward, setup_context=_blur_masked_setup)
 
 
 # ---- InstanceNorm (+ LeakyReLU), with explicit first- and second-order backward kernels --------------------------
