@@ -48,7 +48,7 @@ SYNTHESIS_PLAN = ((512, 512, "const"), (512, 512, "nearest"), (512, 512, "neares
 CRITIC_PLAN = ((16, 32, True), (32, 64, True), (64, 128, True), (128, 256, True), (256, 512, False), (512, 512, False),
                (512, 512, False), (512, 512, False))
 
-_store = {"dtype": None, "fused_chain": True}
+_store = {"dtype": None, "fused_chain": True, "defer": True}
 
 
 def set_activation_dtype(dtype):
@@ -58,6 +58,11 @@ def set_activation_dtype(dtype):
 def set_fused_chain(on):
     """Noise -> LeakyReLU -> InstanceNorm -> style as one kernel (default) or as separate torch / library ops."""
     _store["fused_chain"] = bool(on)
+
+
+def set_deferred_activations(on):
+    """Whether the critic leaves its LeakyReLU derivatives to the consuming kernels (default) or sweeps them itself."""
+    _store["defer"] = bool(on)
 
 
 def _he_constant(weight):
@@ -334,7 +339,7 @@ class CriticBlock(torch.nn.Module):
         data-gradient kernel; defer_out: this block leaves its last LeakyReLU's derivative to the next block in the same way.
         Inside the block the blur's backward sweep applies the first LeakyReLU's derivative.  Results are unchanged; the
         backward pass loses one elementwise sweep per LeakyReLU."""
-        fuse = _store["fused_chain"] and x.is_cuda
+        fuse = _store["fused_chain"] and _store["defer"] and x.is_cuda
         conv1 = _children(self.convolution_1)[0]
         if self.mode == "plain":
             return self.convolution_2(conv1(x, in_slope=in_slope), out_dtype)
@@ -370,7 +375,7 @@ class Discriminator(torch.nn.Module):
         # The minibatch statistic divides by a spread over the batch that bf16 rounding can collapse to exactly zero: the
         # features it is taken of (the output of the last block but one) are produced and kept in fp32.
         h = entry(x, torch.float32 if pg == 0 else None)
-        fuse = _store["fused_chain"] and x.is_cuda
+        fuse = _store["fused_chain"] and _store["defer"] and x.is_cuda
         deferred = False                            # h's LeakyReLU derivative is left to the block that reads h
         for level in range(first, n):
             last = level == n - 1
