@@ -10,6 +10,7 @@ struct WgradParams {
   const void* x;    // [N, H, W, x_cstride]
   const void* gy;   // [N, Ho, Wo, y_cstride]
   float* part;      // split-K partial sums [S][T][Cout][Cin] fp32
+  float* bias_part; // null, or [S][Cout] fp32: per split the sum of gy over its pixels (LDS-DMA and row-streaming kernels)
   int32_t N, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw;
   int32_t x_cstride, x_coff, y_cstride, y_coff;
   int32_t K;             // N*Ho*Wo: length of the reduction
@@ -75,6 +76,9 @@ struct WgradReduceParams {
   float alpha;
   int32_t accumulate;
   int32_t thin, ICp;     // layout of part: [split][tap][Cout][Cin], or thin: [split][Cout][tap][ICp]
+  const float* bias_part;   // null, or [splits][Cout]: the extra workgroups of the launch add them in split order into gbias
+  float* gbias;
+  int32_t main_blocks;      // workgroups in front of the bias ones
 };
 
 void plan_wgrad(WgradParams& p, WgradLaunch& l, bool allow_dma);

@@ -231,10 +231,26 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const WgradParams 
 // Workgroup = 64 runs of V consecutive partial elements x SL split lanes (SL = waves of the launch: 4, or 16 for the
 // many short slabs of a thin layer, whose few output elements would otherwise each wait for a long serial sum); each lane
 // keeps four loads in flight.
+// The workgroups behind the main ones add the per-split bias partials [splits][Cout] in split order: 64 channels per
+// workgroup, wave w takes the splits w, w + SL, ..., wave 0 adds the waves' sums in order.
+__device__ __forceinline__ void wgrad_bias_reduce(const WgradReduceParams& p, float* red) {
+  const int SL = blockDim.x >> 6, lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int co = (int)(blockIdx.x - p.main_blocks) * 64 + lane;
+  float sum = 0.f;
+  if (co < p.Cout)
+    for (int sp = sl; sp < p.splits; sp += SL) sum += p.bias_part[(size_t)sp * p.Cout + co];
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (sl != 0 || co >= p.Cout) return;
+  for (int w = 1; w < SL; w++) sum += red[lane + 64 * w];
+  p.gbias[co] = sum;
+}
+
 template <int V>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReduceParams p) {
   typedef float vec_t __attribute__((ext_vector_type(V)));
   __shared__ vec_t red[1024];
+  if (p.bias_part != nullptr && (int)blockIdx.x >= p.main_blocks) { wgrad_bias_reduce(p, reinterpret_cast<float*>(red)); return; }
   const int SL = blockDim.x >> 6;
   const int T = p.kh * p.kw;
   const int inner = p.thin ? p.ICp : p.Cin;
@@ -287,6 +303,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
 template <int SW>
 __global__ __launch_bounds__(SW * 64) void wgrad_reduce_dense_kernel(const WgradReduceParams p) {
   __shared__ f32x4 red[(SW > 2 ? SW - 1 : 2) * 64 * 4];   // [wave - 1][j][lane]; reused as the [pair][tap] tile (4352 bytes)
+  if (p.bias_part != nullptr && (int)blockIdx.x >= p.main_blocks) { wgrad_bias_reduce(p, reinterpret_cast<float*>(red)); return; }
   const int T = p.kh * p.kw;
   const size_t pairs = (size_t)p.Cout * p.Cin;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -464,15 +481,18 @@ int launch_wgrad(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {
   return l.aligned ? launch_tile<float, false, true>(p, l, s) : launch_tile<float, false, false>(p, l, s);
 }
 
-int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
+int launch_wgrad_reduce(const WgradReduceParams& p0, hipStream_t stream) {
+  WgradReduceParams p = p0;
   const size_t total = (size_t)p.Cout * (p.thin ? p.ICp : p.Cin) * p.kh * p.kw;
   if (total == 0) return GC_OK;
+  const unsigned bias_blocks = p.bias_part != nullptr ? (unsigned)((p.Cout + 63) / 64) : 0u;
   const int T = p.kh * p.kw;
   if (!p.thin && T <= 16 && p.Cin % 4 == 0 && p.s_s == 1 && p.s_r == p.kw && p.s_ci == T && p.s_co == (int64_t)p.Cin * T) {
     const size_t pairs = (size_t)p.Cout * p.Cin;
-    const dim3 grid((unsigned)((pairs + 63) / 64));
     // enough waves to pull the slabs at full rate: more split waves per workgroup when there are few pairs
     const size_t wgs = (pairs + 63) / 64;
+    p.main_blocks = (int32_t)wgs;
+    const dim3 grid((unsigned)wgs + bias_blocks);
     if (p.splits >= 16 && wgs * 4 < 2048) hipLaunchKernelGGL(wgrad_reduce_dense_kernel<16>, grid, dim3(1024), 0, stream, p);
     else if (p.splits >= 4) hipLaunchKernelGGL(wgrad_reduce_dense_kernel<4>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(wgrad_reduce_dense_kernel<1>, grid, dim3(64), 0, stream, p);
@@ -481,11 +501,13 @@ int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream) {
   if (total % 4 == 0) {   // slabs stay 16-byte aligned: 4 elements per lane
     const size_t blocks = (total / 4 + 63) / 64;
     const unsigned threads = (p.splits >= 64 && blocks * 16 <= 4096) ? 1024u : (unsigned)kThreads;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, stream, p);
+    p.main_blocks = (int32_t)blocks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks + bias_blocks), dim3(threads), 0, stream, p);
   } else {
     const size_t blocks = (total + 63) / 64;
     const unsigned threads = (p.splits >= 64 && blocks * 16 <= 4096) ? 1024u : (unsigned)kThreads;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(threads), 0, stream, p);
+    p.main_blocks = (int32_t)blocks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks + bias_blocks), dim3(threads), 0, stream, p);
   }
   return check_hip(hipGetLastError(), "wgrad_reduce launch");
 }

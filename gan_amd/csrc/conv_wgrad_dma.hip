@@ -145,6 +145,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
   const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
   typedef short s16x8 __attribute__((ext_vector_type(8)));
+  // bias gradient: in the workgroups of input-channel block 0 and tap group 0, the two waves of column half 0 multiply
+  // their gy fragments by a fragment of ones as well, which sums them over the step's 32 pixels (pixels past the end of the
+  // range were loaded as zeros)
+  const bool do_bias = p.bias_part != nullptr && ci0 == 0 && tap0 == 0 && wc == 0;
+  f32x4 bacc[FO];
+#pragma unroll
+  for (int i = 0; i < FO; i++) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
   auto compute = [&](int stage) {
     const uint32_t sb = smem_base + (uint32_t)(stage * STAGE);
     s16x4 ylo[FO], yhi[FO], xlo[FC], xhi[FC];
@@ -187,6 +196,10 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
     for (int i = 0; i < FO; i++)
 #pragma unroll
       for (int j = 0; j < FC; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < FO; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], bacc[i], 0, 0, 0);
+    }
   };
 
   // ---- ring: steps it+1 .. it+STAGES-1 are in flight while step it is multiplied
@@ -234,6 +247,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
         float* dst = p.part + (((size_t)split * T + tap) * p.Cout + co) * p.Cin + ci;
         *reinterpret_cast<f32x4*>(dst) = acc[i][j];
       }
+    }
+  }
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int i = 0; i < FO; i++) {
+      const int co = co0 + wo * (TO / 2) + i * 16 + lane;
+      if (co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = bacc[i][0];
     }
   }
 }

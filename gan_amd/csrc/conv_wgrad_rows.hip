@@ -160,6 +160,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_rows_kernel(const Wgra
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient: wave 0 of the workgroups that own input-channel block 0 multiplies the gy fragments it has in registers
+  // by a fragment of ones as well, which sums them over the step's 32 pixels (every row of the result holds that sum)
+  const bool do_bias = p.bias_part != nullptr && ci0 == 0 && wave == 0;
+  f32x4 bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
+
   auto compute = [&](int ring) {
     const uint32_t yb = smem_base + (uint32_t)(kXBytes + ring * kYRow);
     uint32_t xb[3];
@@ -203,6 +212,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_rows_kernel(const Wgra
       for (int i = 0; i < 4; i++) acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[tap][i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], bacc[i], 0, 0, 0);
+    }
   };
 
   // ---- ring: slots q + 1 .. q + kD are in flight while slot q is multiplied; past the last slot the cursor issues
@@ -235,6 +248,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_rows_kernel(const Wgra
       float* dst = p.part + (((size_t)split * T + tap) * p.Cout + co) * p.Cin + ci;
       *reinterpret_cast<f32x4*>(dst) = acc[tap][i];
     }
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) p.bias_part[(size_t)split * p.Cout + co0 + i * 16 + lane] = bacc[i][0];
+  }
 }
 
 // Takes the problem when the geometry is the kernel's: 3x3, stride 1, padding 1, bf16, channel counts multiples of 64,
@@ -263,7 +280,10 @@ bool plan_wgrad_rows(WgradParams& p, const WgradLaunch& l, int n_seg, const int3
   p.splits = (int32_t)((strips + p.strips_per_split - 1) / p.strips_per_split);
   // a caller with a bounded workspace (the entry point that allocates nothing): leave the problem to the tiled kernels,
   // whose partial sums are smaller for weights with few tiles, when the strips' partial sums would not fit
-  if (wgrad_rows_workspace_cap() != 0 && (size_t)p.splits * 9 * p.Cout * p.Cin * sizeof(float) > wgrad_rows_workspace_cap()) return false;
+  // (the bias partials [splits][Cout] follow the weight partials)
+  if (wgrad_rows_workspace_cap() != 0 &&
+      (size_t)p.splits * 9 * p.Cout * p.Cin * sizeof(float) + (size_t)p.splits * p.Cout * sizeof(float) + 16 > wgrad_rows_workspace_cap())
+    return false;
   p.total_strips = (int32_t)strips;
   p.rows = 1;
   return true;

@@ -715,8 +715,14 @@ static void wgrad_setup(const gc_conv_desc* d, WgradParams& p, WgradLaunch& l, b
   plan_wgrad(p, l, allow_dma);
 }
 
+// Weight partials [splits][T][Cout][Cin] (16-byte multiple), then the bias partials [splits][Cout] of the kernels that sum gy
+// themselves.
+static size_t wgrad_weight_part_bytes(const gc_conv_desc* d, const WgradParams& p) {
+  const size_t b = (size_t)p.splits * d->kh * d->kw * d->Cout * (p.thin ? p.ICp : d->Cin) * sizeof(float);
+  return (b + 15) / 16 * 16;
+}
 static size_t wgrad_need(const gc_conv_desc* d, const WgradParams& p) {
-  return (size_t)p.splits * d->kh * d->kw * d->Cout * (p.thin ? p.ICp : d->Cin) * sizeof(float);
+  return wgrad_weight_part_bytes(d, p) + (size_t)p.splits * d->Cout * sizeof(float);
 }
 
 // The LDS-DMA plan needs 16-byte aligned operands, which only the call knows: the advertised size covers both plans.
@@ -768,6 +774,7 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
   }
   if (!aligned16(workspace)) { set_error("%s: workspace must be 16-byte aligned", who); return GC_BAD_ARGUMENT; }
   p.x = xs[0]; p.gy = gys[0]; p.part = (float*)workspace;
+  p.bias_part = nullptr;
   for (int g = 0; g < n_seg && (n_seg > 1 || rows); g++) {
     p.seg_x[g] = xs[g]; p.seg_gy[g] = gys[g];
     p.seg_x_bytes[g] = (int64_t)Ns[g] * d->H * d->W * p.x_cstride * 2;
@@ -791,6 +798,9 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
     set_error("%s: an fp32 x with a bf16 gy needs the image layer's geometry with 16-byte aligned, unsliced operands", who);
     return GC_UNSUPPORTED_GEOMETRY;
   }
+  // the LDS-DMA and row-streaming kernels sum gy next to the products (a fragment of ones): no pass of its own over gy
+  const bool bias_fused = gbias != nullptr && (rows || l.dma) && d->N > 0;
+  if (bias_fused) p.bias_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + wgrad_weight_part_bytes(d, p));
   if (rows) rc = launch_wgrad_rows(p, l, (hipStream_t)stream);
   else rc = l.dma ? launch_wgrad_dma(p, l, (hipStream_t)stream) : launch_wgrad(p, l, (hipStream_t)stream);
   if (rc != GC_OK) return rc;
@@ -799,11 +809,12 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
   r.s_co = gw_strides[0]; r.s_ci = gw_strides[1]; r.s_r = gw_strides[2]; r.s_s = gw_strides[3];
   r.Cout = d->Cout; r.Cin = d->Cin; r.kh = d->kh; r.kw = d->kw; r.splits = d->N == 0 ? 0 : p.splits;
   r.alpha = alpha; r.accumulate = accumulate; r.thin = p.thin; r.ICp = p.ICp;
+  r.bias_part = bias_fused ? p.bias_part : nullptr; r.gbias = gbias; r.main_blocks = 0;
   {
     ProfScope ps("gc::wgrad_reduce_kernel", 0.0, (hipStream_t)stream);
     if ((rc = launch_wgrad_reduce(r, (hipStream_t)stream)) != GC_OK) return rc;
   }
-  if (gbias != nullptr) {
+  if (gbias != nullptr && !bias_fused) {
     ProfScope ps("gc::colsum_kernel", 0.0, (hipStream_t)stream);
     if ((rc = launch_colsum(gys[0], gbias, p.K, d->Cout, p.y_cstride, p.y_coff, l.bf16, (hipStream_t)stream)) != GC_OK) return rc;
   }
@@ -815,6 +826,14 @@ int gc_conv2d_wgrad(const gc_conv_desc* d, const void* x, const void* gy, float*
   if (d == nullptr) { set_error("gc_conv2d_wgrad: null descriptor"); return GC_BAD_ARGUMENT; }
   const int32_t n = d->N;
   return wgrad_run(d, 1, &x, &gy, &n, gw, gw_strides, alpha, accumulate, gbias, workspace, workspace_bytes, stream, "gc_conv2d_wgrad");
+}
+
+int gc_wgrad_sums_bias(const gc_conv_desc* d, const void* x, const void* gy) {
+  if (d == nullptr || validate(d) != GC_OK || d->N == 0) return 0;
+  WgradParams p; WgradLaunch l;
+  wgrad_setup(d, p, l, aligned16(x) && aligned16(gy));
+  const bool rows = plan_wgrad_rows(p, l, 1, &d->N);
+  return (rows || l.dma) ? 1 : 0;
 }
 
 static int multi_desc(const gc_conv_desc* d, int32_t n_seg, const int32_t* Ns, gc_conv_desc* total, const char* who) {

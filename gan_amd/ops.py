@@ -746,21 +746,30 @@ def _wgrad_operands(x, gy, precision, geom=None):
     return x, gy
 
 
-def _wgrad_launch(x, gy, gw, kh, kw, stride, padding, precision, alpha, accumulate, stream_of):
-    """gw (+)= alpha * weight gradient.  stream_of(*tensors to keep alive) names the launch stream once the operands exist."""
+def _wgrad_launch(x, gy, gw, kh, kw, stride, padding, precision, alpha, accumulate, stream_of, want_bias=False):
+    """gw (+)= alpha * weight gradient.  stream_of(*tensors to keep alive) names the launch stream once the operands exist.
+    want_bias: returns gy summed over (n, h, w) -- by the weight-gradient kernel itself where it holds gy in its operand
+    storage type already (no extra rounding) and its plan sums it on the way, otherwise by channel_sum."""
     N, Cin, H, W = x.shape
     N2, Cout, Ho, Wo = gy.shape
     if N2 != N or (H + 2 * padding - kh) // stride + 1 != Ho or (W + 2 * padding - kw) // stride + 1 != Wo:
         raise RuntimeError("ganconv: x and gy shapes are inconsistent with the convolution geometry")
+    gy_given = gy
     x, gy = _wgrad_operands(x, gy, precision, (kh, kw, stride, padding))
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(gy))
     L = _lib.lib()
     ws_bytes = L.gc_wgrad_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    stream = stream_of(ws, x, gy, gw)
+    gb = None
+    if want_bias and gy_given.dtype == gy.dtype and L.gc_wgrad_sums_bias(ctypes.byref(d), _ptr(x), _ptr(gy)):
+        gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    stream = stream_of(ws, x, gy, gw, gb)
     _lib.check(L.gc_conv2d_wgrad(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(gy.data_ptr()),
-                                 ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), float(alpha), 1 if accumulate else 0, None,
-                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream), "gc_conv2d_wgrad")
+                                 ctypes.c_void_p(gw.data_ptr()), _lib.strides4(gw), float(alpha), 1 if accumulate else 0,
+                                 None if gb is None else _ptr(gb), ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream), "gc_conv2d_wgrad")
+    if want_bias and gb is None:
+        gb = channel_sum(gy_given)
+    return gb
 
 
 @torch.library.custom_op("ganconv::conv_wgrad", mutates_args=())
@@ -772,6 +781,24 @@ def conv_wgrad(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: in
     side = _SideLaunch.active
     _wgrad_launch(x, gy, gw, kh, kw, stride, padding, precision, alpha, False, side.fork if side is not None else (lambda *keep: _stream()))
     return gw
+
+
+@torch.library.custom_op("ganconv::conv_wgrad_bias", mutates_args=())
+def conv_wgrad_bias(x: Tensor, gy: Tensor, kh: int, kw: int, stride: int, padding: int, precision: int,
+                    alpha: float = 1.0) -> tuple[Tensor, Tensor]:
+    """(conv_wgrad(x, gy, ...), gy.sum((0, 2, 3)) in float32): weight and bias gradient of a convolution from one launch
+    where the weight-gradient kernel sums gy next to its products (channel_sum otherwise)."""
+    _check_cuda(x, gy)
+    gw = torch.empty((gy.shape[1], x.shape[1], kh, kw), dtype=torch.float32, device=x.device)
+    side = _SideLaunch.active
+    gb = _wgrad_launch(x, gy, gw, kh, kw, stride, padding, precision, alpha, False,
+                       side.fork if side is not None else (lambda *keep: _stream()), want_bias=True)
+    return gw, gb
+
+
+@conv_wgrad_bias.register_fake
+def _(x, gy, kh, kw, stride, padding, precision, alpha=1.0):
+    return (x.new_empty((gy.shape[1], x.shape[1], kh, kw), dtype=torch.float32), x.new_empty((gy.shape[1],), dtype=torch.float32))
 
 
 def _wgrad_launch_multi(pairs, gw, kh, kw, stride, padding, precision, alpha, accumulate):
@@ -942,21 +969,27 @@ def _wanted(ctx, i):
         return True
 
 
-def _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_x, need_w, x_act_slope=-1.0):
-    """(gx, gw) of y = conv(x, alpha * w) from gy: the data-gradient and weight-gradient launches (the weight gradient goes to
-    an active weight_gradient_sink instead when one accepts it; with backward overlap on, it runs on the side stream)."""
-    gx = gw = None
+def _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_x, need_w, x_act_slope=-1.0, need_b=False):
+    """(gx, gw, gb) of y = conv(x, alpha * w) + b from gy: the data-gradient and weight-gradient launches (the weight gradient
+    goes to an active weight_gradient_sink instead when one accepts it; with backward overlap on, it runs on the side
+    stream).  The bias gradient comes out of the weight-gradient launch where that kernel sums gy on the way."""
+    gx = gw = gb = None
 
     def dgrad():
         if x_act_slope >= 0.0:
             return conv_dgrad_masked(gy, w, x, x_act_slope, stride, padding, precision, wkey, _code_of(x.dtype), alpha)
         return conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
 
+    def wgrad():
+        if need_b:
+            return conv_wgrad_bias(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
+        return conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha), None
+
     if need_w and _wgrad_to_sink(w, x, gy, stride, padding, precision, alpha):
         need_w = False
     if _overlap and need_x and need_w and gy.is_cuda:
         with _SideLaunch(gy.device) as side:
-            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
+            gw, gb = wgrad()
         gx = dgrad()
         side.join()
         gw = gw.to(w.dtype)
@@ -964,8 +997,11 @@ def _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_
         if need_x:
             gx = dgrad()
         if need_w:
-            gw = conv_wgrad(x, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
-    return gx, gw
+            gw, gb = wgrad()
+            gw = gw.to(w.dtype)
+    if need_b and gb is None:
+        gb = channel_sum(gy)
+    return gx, gw, gb
 
 
 def _fprop_setup(ctx, inputs, output):
@@ -995,10 +1031,9 @@ def _fprop_backward(ctx, gy):
             gy = _act_backward(gy, y, act, slope)
     else:
         x, w = ctx.saved_tensors
-    gx, gw = _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_x, need_w, ctx.x_act_slope)
-    if need_b and gb is None:
-        gb = channel_sum(gy)
-    return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
+    gx, gw, gb2 = _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_x, need_w, ctx.x_act_slope,
+                                      need_b and gb is None)
+    return gx, gw, (gb if gb is not None else gb2), None, None, None, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("ganconv::conv_fprop", _fprop_backward, setup_context=_fprop_setup)
@@ -1094,6 +1129,24 @@ def _wgrad_backward(ctx, v):
 
 
 torch.library.register_autograd("ganconv::conv_wgrad", _wgrad_backward, setup_context=_wgrad_setup)
+
+
+def _wgrad_bias_backward(ctx, v, vb):
+    """Both outputs are linear in gy (and the weight gradient in x): gy receives conv(x, v) + vb per channel."""
+    x, gy = ctx.saved_tensors
+    stride, padding, precision, alpha = ctx.cfg
+    g_x = g_gy = None
+    if v is not None and _wanted(ctx, 0):
+        g_x = conv_dgrad(gy, v, None, x.shape[2], x.shape[3], stride, padding, precision, 0, 0, 0.0, _code_of(x.dtype), alpha)
+    if _wanted(ctx, 1):
+        if v is not None:
+            g_gy = conv_fprop(x, v, vb, stride, padding, precision, 0, 0, 0.0, _code_of(gy.dtype), alpha)
+        elif vb is not None:
+            g_gy = vb.to(gy.dtype).view(1, -1, 1, 1).expand_as(gy)
+    return g_x, g_gy, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::conv_wgrad_bias", _wgrad_bias_backward, setup_context=_wgrad_setup)
 
 
 def _blur_launch(x, mask, slope):
@@ -1770,7 +1823,7 @@ def _modconv_backward(ctx, g):
     x, w, out, bias, pre, post = ctx.saved_tensors
     gc, dot, sm = mod_act_backward(g, out, pre, post, slope)
     need_x, need_w = _wanted(ctx, 0), _wanted(ctx, 1)
-    gx, gw = _input_weight_grads(x, w, gc, stride, padding, precision, wkey, alpha, need_x, need_w)
+    gx, gw, _ = _input_weight_grads(x, w, gc, stride, padding, precision, wkey, alpha, need_x, need_w)
     gb = gpre = gpost = None
     if bias is not None and ctx.needs_input_grad[2]:
         gb = sm.sum(0).to(bias.dtype)

@@ -161,6 +161,11 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* desc);
  * its output gradient as x). */
 int gc_conv2d_wgrad(const gc_conv_desc* desc, const void* x, const void* gy, float* gw, const int64_t gw_strides[4],
                     float alpha, int accumulate, float* gbias, void* workspace, size_t workspace_bytes, void* stream);
+/* 1 when gc_conv2d_wgrad on these operands computes gbias inside the weight-gradient launch (the LDS-DMA and row-streaming
+ * kernels multiply the gy fragments they hold by a fragment of ones: partial sums per split, added in split order by the
+ * reduction launch, bit-wise reproducible), 0 when a pass of its own over gy would follow (which adds with float atomics).
+ * A caller that wants a reproducible bias gradient either way asks here and otherwise sums gy itself (gc_channel_sum). */
+int gc_wgrad_sums_bias(const gc_conv_desc* desc, const void* x, const void* gy);
 
 /* gc_conv2d_wgrad for callers that cannot allocate: code under HIP-graph capture, tight serving / training loops and
  * harnesses that forbid hipMalloc (and so cannot provide a workspace of a size known only at call time).  No counterpart

