@@ -86,6 +86,12 @@ class _EqConvCore(gnn.Conv2d):
         return self.weight_orig * self.scale
 
     def forward(self, x, out_dtype=None, upsample=False, defer=False, in_slope=None):
+        if x.shape[1] > self.in_channels:
+            # an input padded with zero channels to a multiple of 8 (the 513-channel layer behind the minibatch statistic): the
+            # weight gets zero input channels to match, so that the kernels read aligned 16-byte channel groups
+            w = torch.nn.functional.pad(self.weight_orig, (0, 0, 0, 0, 0, x.shape[1] - self.in_channels))
+            return GF.conv2d(x, w, self.bias, self.stride, self.padding, activation=self.activation, negative_slope=self.negative_slope,
+                             out_dtype=out_dtype, weight_scale=self.scale, defer_activation_grad=defer, input_activation_slope=in_slope)
         if upsample:      # nearest x2 in front of the 3x3 convolution (StyleGAN/model.py:236-238), folded into the weight
             return GF.upsample2x_conv3x3(x, self.weight_orig, self.bias, activation=self.activation, negative_slope=self.negative_slope,
                                          out_dtype=out_dtype, weight_scale=self.scale)
@@ -381,7 +387,10 @@ class Discriminator(torch.nn.Module):
             last = level == n - 1
             if last:                                # minibatch standard deviation as one more feature map
                 spread = h.std(dim=0, unbiased=False).mean()
-                h = torch.cat([h, spread.expand(h.shape[0], 1, h.shape[2], h.shape[3])], dim=1)
+                parts = [h, spread.expand(h.shape[0], 1, h.shape[2], h.shape[3])]
+                if _store["fused_chain"] and x.is_cuda and (h.shape[1] + 1) % 8:       # zero channels up to a multiple of 8 (matched by zero weights)
+                    parts.append(h.new_zeros(h.shape[0], 8 - (h.shape[1] + 1) % 8, h.shape[2], h.shape[3]))
+                h = torch.cat(parts, dim=1)
             block = self.downsampling_blocks[level]
             # the next block's first convolution is the only reader of this block's output: not in front of the statistic's
             # concatenation (and its fp32 features), nor where the output is blended with the down-scaled image
