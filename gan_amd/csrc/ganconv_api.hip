@@ -740,6 +740,14 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
   return need;
 }
 
+size_t gc_workspace_bytes(const gc_conv_desc* d, int pass) {
+  if (validate(d) != GC_OK) return 0;
+  if (pass == GC_PASS_WGRAD) return gc_wgrad_workspace_bytes(d);
+  if (pass != GC_PASS_FPROP && pass != GC_PASS_DGRAD) { set_error("gc_workspace_bytes: unknown pass"); return 0; }
+  const size_t out_elems = pass == GC_PASS_FPROP ? (size_t)d->N * d->Ho * d->Wo * d->Cout : (size_t)d->N * d->H * d->W * d->Cin;
+  return out_elems * 4 * 32;        // partial fp32 tiles of up to 32 reduction splits
+}
+
 // Splits per segment for a plan made on the summed reduction length: every segment keeps the plan's k_per_split.
 static void wgrad_split_segments(WgradParams& p, int32_t n_seg, const int32_t* Ns, int pix_per_sample) {
   p.n_seg = n_seg;

@@ -96,16 +96,8 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
 # 2i-1, 2i, 2i+1 = input rows i-1, i, i: taps (w0 | w1 + w2) on rows (i-1 | i); output row 2i+1 reads 2i, 2i+1, 2i+2 =
 # input rows i, i, i+1: taps (w0 + w1 | w2) on rows (i | i+1).  That is the tap pattern of a 4-tap stride-2 padding-1
 # transposed convolution with k = (w2, w1 + w2, w0 + w1, w0) per dimension, and the zero padding of the replicated image
-# coincides with the transposed convolution's missing neighbours at the border.
-_UP_FOLD = ((0.0, 0.0, 1.0), (0.0, 1.0, 1.0), (1.0, 1.0, 0.0), (1.0, 0.0, 0.0))
-_up_fold_cache = {}
-
-
-def _up_fold(device):
-    m = _up_fold_cache.get(device)
-    if m is None:
-        m = _up_fold_cache[device] = torch.tensor(_UP_FOLD, dtype=torch.float32, device=device)
-    return m
+# coincides with the transposed convolution's missing neighbours at the border.  The fold (and its adjoint for the
+# gradient) is one launch of the library's weight-space kernel (ops.upsample_weight_fold, fold 1).
 
 
 def upsample2x_conv3x3(input, weight, bias=None, *, _wkey=0, precision=None, activation=None, negative_slope=0.2, out_dtype=None,
@@ -119,8 +111,7 @@ def upsample2x_conv3x3(input, weight, bias=None, *, _wkey=0, precision=None, act
     _check_input(input, weight)
     if tuple(weight.shape[2:]) != (3, 3):
         raise RuntimeError(f"ganconv: upsample2x_conv3x3 takes a 3x3 weight, got {tuple(weight.shape[2:])}")
-    m = _up_fold(weight.device)
-    k4 = torch.einsum("ar,ocrs,bs->coab", m, weight.to(torch.float32), m)
+    k4 = ops.upsample_weight_fold(weight, 1, True)          # [Cout, Cin, 3, 3] -> [Cin, Cout, 4, 4]
     return conv_transpose2d(input, k4, bias, 2, 1, _wkey=_wkey, precision=precision, activation=activation,
                             negative_slope=negative_slope, out_dtype=out_dtype, weight_scale=weight_scale)
 

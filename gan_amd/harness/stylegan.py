@@ -205,7 +205,10 @@ class UpsampleConvT(torch.nn.Module):
         self.scale = math.sqrt(2.0 / (cin * 9))
 
     def forward(self, x):
-        w4 = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(self.weight, [1, 1, 1, 1]), 2, stride=1)     # [Cin, Cout, 4, 4]
+        if x.is_cuda:       # the pad + four-shift average as one launch (and one for its gradient)
+            w4 = ops.upsample_weight_fold(self.weight, 0, False)                                                # [Cin, Cout, 4, 4]
+        else:
+            w4 = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(self.weight, [1, 1, 1, 1]), 2, stride=1)
         return GF.conv_transpose2d(x, w4, self.bias, stride=2, padding=1, out_dtype=_store["dtype"], weight_scale=self.scale)
 
 

@@ -1666,6 +1666,63 @@ torch.library.register_autograd("ganconv::pool2x2", lambda ctx, g: (replicate2x(
 torch.library.register_autograd("ganconv::replicate2x", lambda ctx, g: (pool2x2(g, ctx.scale), None), setup_context=_scale_ctx)
 
 
+# ---- weight-space prologue of the up-sampling convolutions (StyleGAN/model.py:396-402, BigGAN/model.py:116-120) ------
+def _fold_launch(src, dst, n0, n1, s0, s1, adjoint, fold):
+    _lib.check(_lib.lib().gc_fused_upsample_weight(_ptr(src), _ptr(dst), n0, n1, s0, s1, 1.0, 1 if adjoint else 0, fold, _stream()),
+               "gc_fused_upsample_weight")
+
+
+@torch.library.custom_op("ganconv::upsample_weight_fold", mutates_args=())
+def upsample_weight_fold(w: Tensor, fold: int, swap: bool) -> Tensor:
+    """The [A, B, 4, 4] filter of the stride-2 transposed convolution that equals "nearest x2, then the 3 x 3 convolution w":
+    fold 0 = the four-shift average of StyleGAN's FusedUpsample, fold 1 = the exact fold of the replication.  swap=False:
+    w is [A, B, 3, 3] (a transposed convolution's layout); swap=True: w is [B, A, 3, 3] (a convolution's [Cout, Cin, 3, 3],
+    read as its transpose).  One launch; fp32."""
+    _check_cuda(w)
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise RuntimeError(f"ganconv: upsample_weight_fold takes a [., ., 3, 3] weight, got {tuple(w.shape)}")
+    w = w.to(torch.float32).contiguous()
+    n0, n1 = (w.shape[1], w.shape[0]) if swap else (w.shape[0], w.shape[1])
+    out = torch.empty(n0, n1, 4, 4, dtype=torch.float32, device=w.device)
+    _fold_launch(w, out, n0, n1, 9 if swap else n1 * 9, n0 * 9 if swap else 9, False, fold)
+    return out
+
+
+@upsample_weight_fold.register_fake
+def _(w, fold, swap):
+    n0, n1 = (w.shape[1], w.shape[0]) if swap else (w.shape[0], w.shape[1])
+    return w.new_empty(n0, n1, 4, 4, dtype=torch.float32)
+
+
+@torch.library.custom_op("ganconv::upsample_weight_unfold", mutates_args=())
+def upsample_weight_unfold(g: Tensor, fold: int, swap: bool) -> Tensor:
+    """The adjoint of upsample_weight_fold: a [A, B, 4, 4] gradient back to the 3 x 3 weight's layout."""
+    _check_cuda(g)
+    g = g.to(torch.float32).contiguous()
+    n0, n1 = g.shape[0], g.shape[1]
+    out = torch.empty((n1, n0, 3, 3) if swap else (n0, n1, 3, 3), dtype=torch.float32, device=g.device)
+    _fold_launch(g, out, n0, n1, 9 if swap else n1 * 9, n0 * 9 if swap else 9, True, fold)
+    return out
+
+
+@upsample_weight_unfold.register_fake
+def _(g, fold, swap):
+    n0, n1 = g.shape[0], g.shape[1]
+    return g.new_empty((n1, n0, 3, 3) if swap else (n0, n1, 3, 3), dtype=torch.float32)
+
+
+def _fold_ctx(ctx, inputs, output):
+    ctx.cfg = (inputs[1], inputs[2], inputs[0].dtype)
+
+
+torch.library.register_autograd("ganconv::upsample_weight_fold",
+                                lambda ctx, g: (upsample_weight_unfold(g, ctx.cfg[0], ctx.cfg[1]).to(ctx.cfg[2]), None, None),
+                                setup_context=_fold_ctx)
+torch.library.register_autograd("ganconv::upsample_weight_unfold",
+                                lambda ctx, g: (upsample_weight_fold(g, ctx.cfg[0], ctx.cfg[1]).to(ctx.cfg[2]), None, None),
+                                setup_context=_fold_ctx)
+
+
 # ---- per-sample channel scaling and its adjoint reduction: the halves of a modulated convolution (an extension: the
 # reference's StyleGAN is version 1, StyleGAN/model.py:179-261, and has none) ------------------------------------------
 @torch.library.custom_op("ganconv::channel_scale", mutates_args=())

@@ -355,6 +355,25 @@ int gc_act_concat_fwd(const void* a, const void* b, void* y, int64_t P, int32_t 
 int gc_act_concat_bwd(const void* g, const void* y, void* ga, void* gb, int64_t P, int32_t Ca, int32_t Cb, int32_t dtype, float slope,
                       void* stream);
 
+/* Weight-space prologue of the up-sampling convolutions: "nearest x2, then 3 x 3 convolution" as ONE 4 x 4 stride-2
+ * transposed convolution of the small input.  w (fp32) holds n0 * n1 filters of 3 x 3, filter (i0, i1) at
+ * w + i0 * stride0 + i1 * stride1 (elements; r, s contiguous), so a [Cout][Cin][3][3] tensor is read as its [Cin][Cout]
+ * transpose by swapping the strides; w_out is dense [n0][n1][4][4]:
+ *   w_out[a][b] = mult * sum_{r,s} M[a][r] M[b][s] w[r][s]
+ *   fold 0: M = [[1 0 0] [1 1 0] [0 1 1] [0 0 1]] / 2  -- FusedUpsample's pad + four-shift average (StyleGAN/model.py:396-402)
+ *   fold 1: M = [[0 0 1] [0 1 1] [1 1 0] [1 0 0]]      -- exact fold of interpolate(scale_factor=2) + conv 3x3 padding 1
+ *                                                         (BigGAN/model.py:116-120, StyleGAN/model.py:236-238)
+ * transpose_grad != 0 runs the adjoint for the gradient: w is then the dense [n0][n1][4][4] gradient and w_out the 3 x 3
+ * side (strides as above), w_out[r][s] = mult * sum_{a,b} M[a][r] M[b][s] w[a][b].  One launch each way, in place of the
+ * pad / shift / add (or einsum) chain and its autograd graph. */
+int gc_fused_upsample_weight(const float* w, float* w_out, int32_t n0, int32_t n1, int64_t stride0, int64_t stride1, float mult,
+                             int transpose_grad, int fold, void* stream);
+
+/* Scratch memory a pass of this problem can use: GC_PASS_WGRAD = gc_wgrad_workspace_bytes (required by gc_conv2d_wgrad);
+ * GC_PASS_FPROP / GC_PASS_DGRAD = what gc_epilogue.workspace may offer for the optional split of a long reduction (0 for
+ * an empty problem).  One query for all three passes. */
+size_t gc_workspace_bytes(const gc_conv_desc* desc, int pass);
+
 /* EXTENSION (no counterpart in the reference, whose StyleGAN is version 1 with AdaIN: StyleGAN/model.py:179-261): the two
  * memory-bound halves of a StyleGAN2-style modulated convolution written without per-sample weights,
  *   y[n, o] = d[n, o] * conv(x[n, i] * s[n, i], w)[o],  d[n, o] = rsqrt(sum_i s[n, i]^2 * sum_k w[o, i, k]^2 + eps),

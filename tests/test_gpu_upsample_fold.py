@@ -79,3 +79,52 @@ def test_one_by_one_shortcut_commutes_with_replication(gan):
     a = gan.functional.conv2d(gan.functional.upsample_nearest2x(x), w, b)
     c = gan.functional.upsample_nearest2x(gan.functional.conv2d(x, w, b))
     assert torch.equal(a, c)
+
+
+# ---- the weight-space fold kernel itself (gc_fused_upsample_weight) ---------------------------------------------------
+_M = {0: torch.tensor([[1.0, 0, 0], [1, 1, 0], [0, 1, 1], [0, 0, 1]]) / 2, 1: torch.tensor([[0.0, 0, 1], [0, 1, 1], [1, 1, 0], [1, 0, 0]])}
+
+
+@pytest.mark.parametrize("fold", [0, 1])
+@pytest.mark.parametrize("swap", [False, True])
+def test_weight_fold_and_its_adjoint_against_torch(fold, swap):
+    """fold 0 against the reference's own expression (pad to 5 x 5, mean of the four one-step shifts:
+    StyleGAN/model.py:396-402), fold 1 against the 4 x 3 matrix form; the adjoint through <fold(w), g> = <w, unfold(g)> and
+    through autograd, twice."""
+    import gan_amd
+    ops = gan_amd.ops
+    g = torch.Generator().manual_seed(3 + fold)
+    A, B = 37, 20
+    w = torch.randn((B, A, 3, 3) if swap else (A, B, 3, 3), generator=g).cuda().requires_grad_(True)
+    w4 = ops.upsample_weight_fold(w, fold, swap)
+    assert w4.shape == (A, B, 4, 4)
+    wt = w.detach().transpose(0, 1) if swap else w.detach()
+    m = _M[fold].cuda()
+    want = torch.einsum("ar,xyrs,bs->xyab", m, wt, m)
+    assert torch.allclose(w4, want, rtol=1e-6, atol=1e-6)
+    if fold == 0:
+        p = torch.nn.functional.pad(wt, [1, 1, 1, 1])
+        ref = (p[:, :, 1:, 1:] + p[:, :, :-1, 1:] + p[:, :, 1:, :-1] + p[:, :, :-1, :-1]) / 4
+        assert torch.allclose(w4, ref, rtol=1e-6, atol=1e-6)
+    g4 = torch.randn(A, B, 4, 4, generator=g).cuda().requires_grad_(True)
+    g3 = ops.upsample_weight_unfold(g4, fold, swap)
+    assert g3.shape == w.shape
+    lhs, rhs = (w4 * g4).sum(), (w * g3).sum()
+    assert abs(float((lhs - rhs).detach())) < 1e-3 * abs(float(lhs.detach())) + 1e-3
+    gw, = torch.autograd.grad((w4 * g4).sum(), w, create_graph=True)           # = unfold(g4), still a function of g4
+    assert torch.allclose(gw, g3.detach(), rtol=1e-6, atol=1e-6)
+    gg, = torch.autograd.grad((gw * w.detach()).sum(), g4)                     # second order: the fold again
+    assert torch.allclose(gg, w4.detach(), rtol=1e-6, atol=1e-6)
+
+
+def test_weight_fold_multiplier_through_the_c_abi():
+    import ctypes
+    import gan_amd
+    L = gan_amd._lib
+    w = torch.randn(8, 5, 3, 3, device="cuda")
+    out = torch.empty(8, 5, 4, 4, device="cuda")
+    L.check(L.lib().gc_fused_upsample_weight(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(out.data_ptr()), 8, 5, 45, 9, 0.25, 0, 0, None), "fold")
+    torch.cuda.synchronize()
+    m = _M[0].cuda()
+    assert torch.allclose(out, 0.25 * torch.einsum("ar,xyrs,bs->xyab", m, w, m), rtol=1e-6, atol=1e-6)
+    assert L.lib().gc_fused_upsample_weight(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(out.data_ptr()), 8, 5, 45, 9, 1.0, 0, 2, None) == -5
