@@ -43,7 +43,11 @@ def test_sizes_and_descriptor_validation():
     assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_DGRAD) == 8 * 16 * 64 * 2
     d.precision = _lib.GC_PREC_F32X3
     assert L.gc_packed_weight_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == 2 * 16 * 16 * 8 * 2
-    assert L.gc_wgrad_workspace_bytes(ctypes.byref(d)) % (16 * 16 * 8 * 4) == 0 and L.gc_wgrad_workspace_bytes(ctypes.byref(d)) > 0
+    # per split: one fp32 slab of the weight's (padded) shape and one row [Cout] for the bias partial sums
+    need = L.gc_wgrad_workspace_bytes(ctypes.byref(d))
+    assert need > 0 and need % (16 * 16 * 8 * 4 + 16 * 4) == 0
+    assert L.gc_workspace_bytes(ctypes.byref(d), _lib.GC_PASS_WGRAD) == need
+    assert L.gc_workspace_bytes(ctypes.byref(d), _lib.GC_PASS_FPROP) == d.N * d.Ho * d.Wo * d.Cout * 128
     bad = _desc(Ho=9)
     assert L.gc_packed_weight_bytes(ctypes.byref(bad), _lib.GC_PASS_FPROP) == 0
     assert b"do not match" in L.gc_last_error()
