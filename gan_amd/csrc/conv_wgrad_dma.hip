@@ -36,7 +36,8 @@ __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcnt(N) only (expcnt
 
 }  // namespace
 
-template <int TO, int STAGES>
+// BIAS: the variant that also sums gy (a build of its own, so that the plain one keeps its registers and schedule)
+template <int TO, int STAGES, bool BIAS>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradParams p) {
   constexpr int ROWBY = TO * 2, ROWBX = kTC * 2;
   constexpr int Y_BYTES = kStepPix * ROWBY, X_BYTES = kStepPix * ROWBX;
@@ -148,10 +149,10 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
   // bias gradient: in the workgroups of input-channel block 0 and tap group 0, the two waves of column half 0 multiply
   // their gy fragments by a fragment of ones as well, which sums them over the step's 32 pixels (pixels past the end of the
   // range were loaded as zeros)
-  const bool do_bias = p.bias_part != nullptr && ci0 == 0 && tap0 == 0 && wc == 0;
-  f32x4 bacc[FO];
+  const bool do_bias = BIAS && p.bias_part != nullptr && ci0 == 0 && tap0 == 0 && wc == 0;
+  f32x4 bacc[BIAS ? FO : 1];
 #pragma unroll
-  for (int i = 0; i < FO; i++) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < (BIAS ? FO : 1); i++) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const s16x8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
   auto compute = [&](int stage) {
@@ -196,9 +197,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
     for (int i = 0; i < FO; i++)
 #pragma unroll
       for (int j = 0; j < FC; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-    if (do_bias) {
+    if constexpr (BIAS) {
+      if (do_bias) {
 #pragma unroll
-      for (int i = 0; i < FO; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], bacc[i], 0, 0, 0);
+        for (int i = 0; i < FO; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], bacc[i], 0, 0, 0);
+      }
     }
   };
 
@@ -249,19 +252,21 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_dma_kernel(const WgradPar
       }
     }
   }
-  if (do_bias && lane < 16) {
+  if constexpr (BIAS) {
+    if (do_bias && lane < 16) {
 #pragma unroll
-    for (int i = 0; i < FO; i++) {
-      const int co = co0 + wo * (TO / 2) + i * 16 + lane;
-      if (co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = bacc[i][0];
+      for (int i = 0; i < FO; i++) {
+        const int co = co0 + wo * (TO / 2) + i * 16 + lane;
+        if (co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = bacc[i][0];
+      }
     }
   }
 }
 
-template <int TO, int STAGES>
-static int launch_dma_one(const WgradParams& p, double flops, hipStream_t stream) {
+template <int TO, int STAGES, bool BIAS>
+static int launch_dma_bias(const WgradParams& p, double flops, hipStream_t stream) {
   constexpr int smem = STAGES * kStepPix * (TO + kTC) * 2;
-  auto kern = conv_wgrad_dma_kernel<TO, STAGES>;
+  auto kern = conv_wgrad_dma_kernel<TO, STAGES, BIAS>;
   if (smem > 64 * 1024 && ensure_dynamic_smem(reinterpret_cast<const void*>(kern), smem) != GC_OK) return GC_HIP_ERROR;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_wgrad_dma_kernel<%d, %d>", TO, STAGES);
@@ -269,6 +274,11 @@ static int launch_dma_one(const WgradParams& p, double flops, hipStream_t stream
   const unsigned nblocks = (unsigned)(p.n_co_tiles * p.n_ci_tiles * p.n_tap_groups * p.splits);
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kThreads), smem, stream, p);
   return check_hip(hipGetLastError(), "conv_wgrad_dma launch");
+}
+
+template <int TO, int STAGES>
+static int launch_dma_one(const WgradParams& p, double flops, hipStream_t stream) {
+  return p.bias_part != nullptr ? launch_dma_bias<TO, STAGES, true>(p, flops, stream) : launch_dma_bias<TO, STAGES, false>(p, flops, stream);
 }
 
 int launch_wgrad_dma(const WgradParams& p, const WgradLaunch& l, hipStream_t s) {

@@ -52,6 +52,8 @@ __device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
 
 }  // namespace
 
+// BIAS: the variant that also sums gy (a build of its own, so that the plain one keeps its registers and schedule)
+template <bool BIAS>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_rows_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -162,10 +164,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_rows_kernel(const Wgra
 
   // bias gradient: wave 0 of the workgroups that own input-channel block 0 multiplies the gy fragments it has in registers
   // by a fragment of ones as well, which sums them over the step's 32 pixels (every row of the result holds that sum)
-  const bool do_bias = p.bias_part != nullptr && ci0 == 0 && wave == 0;
-  f32x4 bacc[4];
+  const bool do_bias = BIAS && p.bias_part != nullptr && ci0 == 0 && wave == 0;
+  f32x4 bacc[BIAS ? 4 : 1];
 #pragma unroll
-  for (int i = 0; i < 4; i++) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < (BIAS ? 4 : 1); i++) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const s16x8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
@@ -212,9 +214,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_rows_kernel(const Wgra
       for (int i = 0; i < 4; i++) acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[tap][i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (do_bias) {
+    if constexpr (BIAS) {
+      if (do_bias) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], bacc[i], 0, 0, 0);
+        for (int i = 0; i < 4; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], bacc[i], 0, 0, 0);
+      }
     }
   };
 
@@ -248,9 +252,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_rows_kernel(const Wgra
       float* dst = p.part + (((size_t)split * T + tap) * p.Cout + co) * p.Cin + ci;
       *reinterpret_cast<f32x4*>(dst) = acc[tap][i];
     }
-  if (do_bias && lane < 16) {
+  if constexpr (BIAS) {
+    if (do_bias && lane < 16) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) p.bias_part[(size_t)split * p.Cout + co0 + i * 16 + lane] = bacc[i][0];
+      for (int i = 0; i < 4; i++) p.bias_part[(size_t)split * p.Cout + co0 + i * 16 + lane] = bacc[i][0];
+    }
   }
 }
 
@@ -293,7 +299,8 @@ int launch_wgrad_rows(const WgradParams& p, const WgradLaunch& l, hipStream_t st
   if (p.total_strips <= 0 || p.splits <= 0) return GC_OK;
   ProfScope ps("gc::conv_wgrad_rows_kernel", l.flops, stream);
   const unsigned nblocks = (unsigned)(p.n_co_tiles * p.n_ci_tiles * p.splits);
-  hipLaunchKernelGGL(conv_wgrad_rows_kernel, dim3(nblocks), dim3(kThreads), kSmem, stream, p);
+  if (p.bias_part != nullptr) hipLaunchKernelGGL(conv_wgrad_rows_kernel<true>, dim3(nblocks), dim3(kThreads), kSmem, stream, p);
+  else hipLaunchKernelGGL(conv_wgrad_rows_kernel<false>, dim3(nblocks), dim3(kThreads), kSmem, stream, p);
   return check_hip(hipGetLastError(), "conv_wgrad_rows launch");
 }
 
