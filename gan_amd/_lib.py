@@ -97,7 +97,7 @@ def lib():
     L.gc_conv2d_wgrad_noalloc.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, i64p, ctypes.c_float, ctypes.c_int, vp, vp]
     L.gc_noalloc_scratch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     L.gc_dwblur3x3.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
-    L.gc_dwblur3x3_masked.argtypes = [vp, vp, vp, ctypes.c_float, i32, i32, i32, i32, i32, vp]
+    L.gc_dwblur3x3_masked.argtypes = [vp, vp, vp, ctypes.c_float, ctypes.c_int, i32, i32, i32, i32, i32, vp]
     f32 = ctypes.c_float
     L.gc_instnorm_act_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp]
     L.gc_instnorm_act_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp]

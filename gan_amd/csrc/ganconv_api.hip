@@ -209,8 +209,9 @@ __device__ __forceinline__ void blur_load(const T* x, size_t off, bool ok, float
   }
 }
 
-// MASK: the stored value is multiplied by 1 where mask > 0 and by `slope` elsewhere (mask: a tensor like y).
-template <typename T, int V, bool MASK>
+// MASK 1: the stored value is multiplied by 1 where mask > 0 and by `slope` elsewhere (mask: a tensor like y).
+// MASK 2: every value READ is multiplied that way (mask: a tensor like x) -- the adjoint of MASK 1.
+template <typename T, int V, int MASK>
 __global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ mask, float slope,
                                                              int N, int H, int W, int CV, int strips, uint32_t total) {
   const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
@@ -237,6 +238,18 @@ __global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* __restrict
     blur_load<T, V>(x, off - (size_t)CV * V, lok, a);
     blur_load<T, V>(x, off, true, c);
     blur_load<T, V>(x, off + (size_t)CV * V, rok, b);
+    if constexpr (MASK == 2) {
+      float ma[V], mc[V], mb[V];
+      blur_load<T, V>(mask, off - (size_t)CV * V, lok, ma);
+      blur_load<T, V>(mask, off, true, mc);
+      blur_load<T, V>(mask, off + (size_t)CV * V, rok, mb);
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+        a[i] = ma[i] > 0.f ? a[i] : a[i] * slope;
+        c[i] = mc[i] > 0.f ? c[i] : c[i] * slope;
+        b[i] = mb[i] > 0.f ? b[i] : b[i] * slope;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < V; i++) o[i] = a[i] + 2.f * c[i] + b[i];
   };
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void dwblur3x3_kernel(const T* __restrict
 #pragma unroll
     for (int i = 0; i < V; i++) o[i] = (prev[i] + 2.f * cur[i] + nxt[i]) * (1.f / 16.f);
     const size_t off = base + (size_t)h * rowp;
-    if constexpr (MASK) {
+    if constexpr (MASK == 1) {
       float m[V];
       blur_load<T, V>(mask, off, true, m);
 #pragma unroll
@@ -936,18 +949,21 @@ int gc_noalloc_scratch(void** ptr, size_t* bytes) {
 }  // extern "C"
 
 template <typename T, int V>
-static void launch_blur(const void* x, void* y, const void* mask, float slope, int N, int H, int W, int C, int strips, size_t total,
+static void launch_blur(const void* x, void* y, const void* mask, float slope, int mode, int N, int H, int W, int C, int strips, size_t total,
                         hipStream_t stream) {
   const unsigned blocks = (unsigned)((total + kThreads - 1) / kThreads);
-  if (mask != nullptr)
-    hipLaunchKernelGGL((dwblur3x3_kernel<T, V, true>), dim3(blocks), dim3(kThreads), 0, stream, (const T*)x, (T*)y, (const T*)mask, slope, N, H, W,
+  if (mask != nullptr && mode == 2)
+    hipLaunchKernelGGL((dwblur3x3_kernel<T, V, 2>), dim3(blocks), dim3(kThreads), 0, stream, (const T*)x, (T*)y, (const T*)mask, slope, N, H, W,
+                       C / V, strips, (uint32_t)total);
+  else if (mask != nullptr)
+    hipLaunchKernelGGL((dwblur3x3_kernel<T, V, 1>), dim3(blocks), dim3(kThreads), 0, stream, (const T*)x, (T*)y, (const T*)mask, slope, N, H, W,
                        C / V, strips, (uint32_t)total);
   else
-    hipLaunchKernelGGL((dwblur3x3_kernel<T, V, false>), dim3(blocks), dim3(kThreads), 0, stream, (const T*)x, (T*)y, (const T*)nullptr, 0.f, N, H,
+    hipLaunchKernelGGL((dwblur3x3_kernel<T, V, 0>), dim3(blocks), dim3(kThreads), 0, stream, (const T*)x, (T*)y, (const T*)nullptr, 0.f, N, H,
                        W, C / V, strips, (uint32_t)total);
 }
 
-static int blur_run(const void* x, void* y, const void* mask, float slope, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+static int blur_run(const void* x, void* y, const void* mask, float slope, int mode, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
                     void* stream, const char* who) {
   if (N < 0 || H <= 0 || W <= 0 || C <= 0) { set_error("%s: bad shape", who); return GC_BAD_ARGUMENT; }
   if (dtype != GC_F32 && dtype != GC_BF16) { set_error("%s: unknown dtype", who); return GC_BAD_ARGUMENT; }
@@ -961,23 +977,24 @@ static int blur_run(const void* x, void* y, const void* mask, float slope, int32
   const int strips = (H + kBlurRows - 1) / kBlurRows;
   const size_t total = (size_t)N * strips * W * (C / V);
   if (total >= (1ull << 32) - kThreads) { set_error("%s: tensor too large", who); return GC_UNSUPPORTED_GEOMETRY; }
-  ProfScope ps(mask != nullptr ? "gc::dwblur3x3_masked_kernel" : "gc::dwblur3x3_kernel", 0.0, (hipStream_t)stream);
-  if (dtype == GC_F32) launch_blur<float, 4>(x, y, mask, slope, N, H, W, C, strips, total, (hipStream_t)stream);
-  else if (V == 4) launch_blur<uint16_t, 4>(x, y, mask, slope, N, H, W, C, strips, total, (hipStream_t)stream);
-  else launch_blur<uint16_t, 8>(x, y, mask, slope, N, H, W, C, strips, total, (hipStream_t)stream);
+  ProfScope ps(mask == nullptr ? "gc::dwblur3x3_kernel" : (mode == 2 ? "gc::dwblur3x3_premasked_kernel" : "gc::dwblur3x3_masked_kernel"), 0.0,
+               (hipStream_t)stream);
+  if (dtype == GC_F32) launch_blur<float, 4>(x, y, mask, slope, mode, N, H, W, C, strips, total, (hipStream_t)stream);
+  else if (V == 4) launch_blur<uint16_t, 4>(x, y, mask, slope, mode, N, H, W, C, strips, total, (hipStream_t)stream);
+  else launch_blur<uint16_t, 8>(x, y, mask, slope, mode, N, H, W, C, strips, total, (hipStream_t)stream);
   return check_hip(hipGetLastError(), "dwblur3x3 launch");
 }
 
 extern "C" {
 
 int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
-  return blur_run(x, y, nullptr, 0.f, N, H, W, C, dtype, stream, "gc_dwblur3x3");
+  return blur_run(x, y, nullptr, 0.f, 0, N, H, W, C, dtype, stream, "gc_dwblur3x3");
 }
 
-int gc_dwblur3x3_masked(const void* x, void* y, const void* mask, float slope, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
-                        void* stream) {
+int gc_dwblur3x3_masked(const void* x, void* y, const void* mask, float slope, int mask_input, int32_t N, int32_t H, int32_t W, int32_t C,
+                        int32_t dtype, void* stream) {
   if (mask == nullptr) { set_error("gc_dwblur3x3_masked: null mask"); return GC_BAD_ARGUMENT; }
-  return blur_run(x, y, mask, slope, N, H, W, C, dtype, stream, "gc_dwblur3x3_masked");
+  return blur_run(x, y, mask, slope, mask_input ? 2 : 1, N, H, W, C, dtype, stream, "gc_dwblur3x3_masked");
 }
 
 int gc_profile_enable(int on) {

@@ -1149,7 +1149,7 @@ def _wgrad_bias_backward(ctx, v, vb):
 torch.library.register_autograd("ganconv::conv_wgrad_bias", _wgrad_bias_backward, setup_context=_wgrad_setup)
 
 
-def _blur_launch(x, mask, slope):
+def _blur_launch(x, mask, slope, mask_input=False):
     _check_cuda(x, mask)
     N, C, H, W = x.shape
     x = _nhwc(x)
@@ -1160,7 +1160,8 @@ def _blur_launch(x, mask, slope):
         if mask.shape != x.shape:
             raise RuntimeError("ganconv: the activated tensor does not have the gradient's shape")
         mask = _nhwc(mask if mask.dtype == x.dtype else mask.to(x.dtype))
-        _lib.check(_lib.lib().gc_dwblur3x3_masked(_ptr(x), _ptr(y), _ptr(mask), slope, N, H, W, C, _dtype_code(x), _stream()),
+        _lib.check(_lib.lib().gc_dwblur3x3_masked(_ptr(x), _ptr(y), _ptr(mask), slope, 1 if mask_input else 0, N, H, W, C, _dtype_code(x),
+                                                  _stream()),
                    "gc_dwblur3x3_masked")
     return y
 
@@ -1179,13 +1180,13 @@ def _(x, x_act_slope=-1.0):
 
 
 @torch.library.custom_op("ganconv::blur3x3_masked", mutates_args=())
-def blur3x3_masked(g: Tensor, x: Tensor, x_act_slope: float) -> Tensor:
-    """blur3x3(g) * (x > 0 ? 1 : x_act_slope)."""
-    return _blur_launch(g, x, x_act_slope)
+def blur3x3_masked(g: Tensor, x: Tensor, x_act_slope: float, mask_input: bool = False) -> Tensor:
+    """blur3x3(g) * (x > 0 ? 1 : x_act_slope), or with mask_input blur3x3(g * (x > 0 ? 1 : x_act_slope)): each other's adjoint."""
+    return _blur_launch(g, x, x_act_slope, mask_input)
 
 
 @blur3x3_masked.register_fake
-def _(g, x, x_act_slope):
+def _(g, x, x_act_slope, mask_input=False):
     return torch.empty_like(g)
 
 
@@ -1204,14 +1205,13 @@ def _blur_backward(ctx, g):
 
 def _blur_masked_setup(ctx, inputs, output):
     ctx.save_for_backward(inputs[1])
-    ctx.slope = inputs[2]
+    ctx.slope, ctx.mask_input = inputs[2], inputs[3]
 
 
 def _blur_masked_backward(ctx, u):
-    """Linear in g for a fixed mask: the adjoint applies the mask first, then the blur."""
+    """Linear in g for a fixed mask: the adjoint applies the mask on the other side of the blur."""
     (x,) = ctx.saved_tensors
-    u = _act_backward(u, x, _lib.GC_ACT_LRELU if ctx.slope != 0.0 else _lib.GC_ACT_RELU, ctx.slope)
-    return blur3x3(u), None, None
+    return blur3x3_masked(u, x, ctx.slope, not ctx.mask_input), None, None, None
 
 
 torch.library.register_autograd("ganconv::blur3x3", _blur_backward, setup_context=_blur_setup)

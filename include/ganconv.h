@@ -188,13 +188,15 @@ int gc_noalloc_scratch(void** ptr, size_t* bytes);
  * symmetric, so the same call serves forward and backward (StyleGAN/model.py:82-150: BlurFunction,
  * BlurFunctionBackward; F.conv2d(x, kernel, padding=1, groups=C)). */
 int gc_dwblur3x3(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
-/* The same blur with the derivative of a ReLU (slope 0) / LeakyReLU applied to what it stores:
- *   y = blur(x) * (mask > 0 ? 1 : slope),  mask a tensor of y's shape, dtype and layout.
- * The blur is self-adjoint, so this is the backward pass of "activation, then blur" in one sweep: x = the gradient arriving
- * at the blur, mask = the activated tensor the blur read in the forward pass (the critic block's LeakyReLU -> Blur,
- * StyleGAN/model.py:428-441), replacing blur + aten::leaky_relu_backward. */
-int gc_dwblur3x3_masked(const void* x, void* y, const void* mask, float slope, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
-                        void* stream);
+/* The same blur with the derivative of a ReLU (slope 0) / LeakyReLU applied to what it stores (mask_input = 0):
+ *   y = blur(x) * (mask > 0 ? 1 : slope),  mask a tensor of y's shape, dtype and layout,
+ * or to what it reads (mask_input != 0):  y = blur(x * (mask > 0 ? 1 : slope)), its adjoint.
+ * The blur is self-adjoint, so the first is the backward pass of "activation, then blur" in one sweep: x = the gradient
+ * arriving at the blur, mask = the activated tensor the blur read in the forward pass (the critic block's LeakyReLU -> Blur,
+ * StyleGAN/model.py:428-441), replacing blur + aten::leaky_relu_backward; the second is that sweep's own backward pass
+ * (the gradient penalty's double backward, StyleGAN/train.py:226-238). */
+int gc_dwblur3x3_masked(const void* x, void* y, const void* mask, float slope, int mask_input, int32_t N, int32_t H, int32_t W, int32_t C,
+                        int32_t dtype, void* stream);
 
 /* InstanceNorm2d (affine = false, no running statistics, biased variance, eps inside the square root) fused with
  * an optional LeakyReLU, NHWC, all tensors of one gc_dtype, `dtype` ( arithmetic and statistics in fp32), C a multiple of

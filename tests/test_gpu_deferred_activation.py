@@ -38,6 +38,13 @@ def test_masked_blur_against_torch(gan, shape, dt, slope):
     plain = gan.ops.blur3x3(gy)
     if dt == torch.float32:       # the same sums, then one product
         assert torch.equal(got, plain * torch.where(act > 0, 1.0, slope).to(dt))
+    # the adjoint: the derivative applied to what the blur reads
+    pre = gan.ops.blur3x3_masked(gy, act, slope, True)
+    want_pre = torch.nn.functional.conv2d(gy.double().cpu() * torch.where(act.double().cpu() > 0, 1.0, slope), k, None, 1, 1, 1, C)
+    assert pre.dtype == dt and rel(pre, want_pre) < (1e-6 if dt == torch.float32 else 4e-3)
+    u = torch.randn(shape, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    lhs, rhs = (got.double() * u.double()).sum(), (gy.double() * gan.ops.blur3x3_masked(u, act, slope, True).double()).sum()
+    assert abs(float(lhs - rhs)) < (1e-5 if dt == torch.float32 else 2e-2) * (abs(float(lhs)) + 1.0)
 
 
 def _pair(gan, x, w1, b1, w2, b2, fused, code):
