@@ -96,6 +96,10 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
 // rewrites the tile bookkeeping in p when it accepts.
 bool plan_patch(GatherParams& p, const GatherLaunch& l);
 int launch_patch(GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);   // clears p.mask when it applied it
+// Weights-resident persistent kernel for stride-1 gathers over at most 64 input channels on large images (conv_thin.hip);
+// applies the gradient mask itself.
+bool plan_thin(const GatherParams& p, const GatherLaunch& l);
+int launch_thin(GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // Persistent wave-specialised LDS-DMA kernel for mid-size layers (conv_gather_ws.hip): full channel tiles of 64 / 128,
 // 128-pixel tiles, 16-byte aligned output rows, none / ReLU / LeakyReLU epilogues.
 bool plan_ws(const GatherParams& p, const GatherLaunch& l);

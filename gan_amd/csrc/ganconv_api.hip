@@ -427,6 +427,7 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
       return rc;
     }
   }
+  if (dma && patch_kernel_allowed() && plan_thin(p, l)) return launch_thin(p, l, out_dt == GC_F32, stream);
   if (dma && patch_kernel_allowed() && plan_patch(p, l)) return launch_patch(p, l, out_dt == GC_F32, stream);
   if (dma && !scaled && plan_ws(p, l)) {
     const int rc = launch_ws(p, l, out_dt == GC_F32, stream);    // applies grad_mask in its epilogue
