@@ -111,29 +111,51 @@ __global__ __launch_bounds__(kNW * 64, 1) void conv_thin_kernel(const GatherPara
     p_c[j] = px - p_r[j] * PW;
     p_in[j] = px < npatch;
   }
-  auto rect_of = [&](int j, int& n, int& th, int& tw) {
+  // rectangle (sample, row tile, column tile) of a sequence position: cursors that advance by n_seq rectangles with carries
+  struct Rect { int n, th, tw; };
+  auto rect_at = [&](int j) {
     const int i = seq + j * q.n_seq;
-    tw = i % q.tiles_w;
+    Rect r;
+    r.tw = i % q.tiles_w;
     const int rest = i / q.tiles_w;
-    th = rest % q.tiles_h;
-    n = rest / q.tiles_h;
+    r.th = rest % q.tiles_h;
+    r.n = rest / q.tiles_h;
+    return r;
   };
+  const int step_tw = q.n_seq % q.tiles_w, step_rest = q.n_seq / q.tiles_w;
+  const int step_th = step_rest % q.tiles_h, step_n = step_rest / q.tiles_h;
+  auto advance = [&](Rect& r) {
+    r.tw += step_tw;
+    int c = r.tw >= q.tiles_w ? 1 : 0;
+    r.tw -= c * q.tiles_w;
+    r.th += step_th + c;
+    c = r.th >= q.tiles_h ? 1 : 0;
+    r.th -= c * q.tiles_h;
+    r.n += step_n + c;
+  };
+  // per-lane part of a patch load's address: (patch row, patch column, 16-byte chunk) relative to the patch origin
+  int p_lane[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) p_lane[j] = ((p_r[j] * p.IW + p_c[j]) * p.in_cstride + p.in_coff + p_chunk[j] * 8) * 2;
   // chunk (rectangle j, channel half kh) into ring buffer `buf`; live = false: every lane out of range (zeros into a
   // buffer nobody reads, so that the counted waits stay uniform)
-  auto issue_patch = [&](int j, int kh, int buf, bool live) {
-    int n, th, tw;
-    rect_of(j, n, th, tw);
+  auto issue_patch = [&](const Rect& rc, int kh, int buf, bool live) {
     char* pb = patch_base + buf * kPatchBytes;
+    const int ih0 = rc.th * kTH + q.dh_min, iw0 = rc.tw * kTW + q.dw_min;
+    const uint32_t base = (uint32_t)((((size_t)rc.n * p.IH + ih0) * p.IW + iw0) * p.in_cstride) * 2u;     // (may wrap below zero at an edge: masked there)
+    // a rectangle whose patch lies inside the image needs no per-lane bounds checks
+    const bool inside = ih0 >= 0 && iw0 >= 0 && ih0 + q.PH <= p.IH && iw0 + q.PW <= p.IW;
 #pragma unroll
     for (int jj = 0; jj < 6; jj++)
       if (jj < 5 || npi == 6) {
-        const int ih = th * kTH + p_r[jj] + q.dh_min, iw = tw * kTW + p_c[jj] + q.dw_min;
-        const bool ok = live & p_in[jj] & ((unsigned)ih < (unsigned)p.IH) & ((unsigned)iw < (unsigned)p.IW) &
-                        (kh * 32 + p_chunk[jj] * 8 < p.IC);
-        const uint32_t off = (uint32_t)((((size_t)n * p.IH + ih) * p.IW + iw) * p.in_cstride + p.in_coff + p_chunk[jj] * 8) * 2u;
+        bool ok = live & p_in[jj] & (kh * 32 + p_chunk[jj] * 8 < p.IC);
+        if (!inside) {
+          const int ih = ih0 + p_r[jj], iw = iw0 + p_c[jj];
+          ok = ok & ((unsigned)ih < (unsigned)p.IH) & ((unsigned)iw < (unsigned)p.IW);
+        }
         // (the scalar offset stays uniform: an out-of-range lane offset stays out of range with it added)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(pb + (jj * kNW + wave) * 1024), 16, (int)(ok ? off : kOutOfRange),
-                                                 kh * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(pb + (jj * kNW + wave) * 1024), 16,
+                                                 (int)(ok ? base + (uint32_t)p_lane[jj] : kOutOfRange), kh * 64, 0, 0);
       }
   };
 
@@ -162,11 +184,15 @@ __global__ __launch_bounds__(kNW * 64, 1) void conv_thin_kernel(const GatherPara
   };
 
   f32x4 acc[FO][4];
-  auto clear_acc = [&]() {
+  // accumulators start at the bias (accumulator row r of block ob is channel 32 (ob >> 1) + 8 g + 4 (ob & 1) + r), or at zero
+  // when a per-sample scale stands between the sums and the bias
+  auto clear_acc = [&](const float (&bv)[2][8], bool bias_first) {
 #pragma unroll
     for (int i = 0; i < FO; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[i][j][r] = bias_first ? bv[i >> 1][4 * (i & 1) + r] : 0.f;
   };
   // all nine taps of one chunk out of patch buffer pb, straight-line, patch column shift by column shift; the tap that reads
   // patch offset (dr, dc) sits at grid position (dr or 2 - dr, dc or 2 - dc) of the filter slots
@@ -209,9 +235,9 @@ __global__ __launch_bounds__(kNW * 64, 1) void conv_thin_kernel(const GatherPara
   const float ls = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);
   TOut* out = reinterpret_cast<TOut*>(p.out);
 
-  auto store_rect = [&](int j) {
-    int n, th, tw;
-    rect_of(j, n, th, tw);
+  const bool bias_first = p.pre_scale == nullptr;
+  auto store_rect = [&](const Rect& rc) {
+    const int n = rc.n, th = rc.th, tw = rc.tw;
 #pragma unroll
     for (int pg = 0; pg < 4; pg++) {
       const int oh = th * kTH + row0 + pg, ow = tw * kTW + col0 + c16;
@@ -229,10 +255,13 @@ __global__ __launch_bounds__(kNW * 64, 1) void conv_thin_kernel(const GatherPara
 #pragma unroll
           for (int r = 0; r < 4; r++) { v[r] *= s0[r]; v[4 + r] *= s1[r]; }
         }
+        if (!bias_first) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          v[r] += bias_v[m][r];
-          v[r] = fmaxf(v[r], v[r] * ls);
+          for (int r = 0; r < 8; r++) v[r] += bias_v[m][r];
+        }
+        if (ls != 1.f) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r] * ls);
         }
         if (p.post_scale != nullptr) {
           const float* sc = p.post_scale + (size_t)n * p.OC + oc;
@@ -271,11 +300,13 @@ __global__ __launch_bounds__(kNW * 64, 1) void conv_thin_kernel(const GatherPara
 
   // ---- chunks k = 2 j + kh through ring buffer k % 3.  Younger than chunk k's loads when chunk k is waited for: chunk
   // k + 1's loads, and from the second rectangle on the previous rectangle's stores.
-  issue_patch(0, 0, 0, true);
-  issue_patch(0, 1, 1, true);
+  Rect cur = rect_at(0), nxt = cur;
+  issue_patch(cur, 0, 0, true);
+  issue_patch(cur, 1, 1, true);
+  advance(nxt);
   int buf = 0;                                   // ring buffer of the chunk being multiplied
   for (int j = 0; j < nr; j++) {
-    clear_acc();
+    clear_acc(bias_v, bias_first);
 #pragma unroll
     for (int kh = 0; kh < 2; kh++) {
       if (j == 0) {
@@ -286,13 +317,15 @@ __global__ __launch_bounds__(kNW * 64, 1) void conv_thin_kernel(const GatherPara
       __builtin_amdgcn_s_barrier();              // chunk k has landed for every wave; every wave is done with chunk k - 1
       __builtin_amdgcn_sched_barrier(0);
       const int nbuf = buf == 0 ? 2 : buf - 1;   // (k + 2) % 3 = (k - 1) % 3
-      issue_patch(j + 1, kh, nbuf, j + 1 < nr);
+      issue_patch(nxt, kh, nbuf, j + 1 < nr);
       __builtin_amdgcn_sched_barrier(0);
       compute(patch_base + buf * kPatchBytes, kh);
       buf = buf == 2 ? 0 : buf + 1;
       __builtin_amdgcn_sched_barrier(0);
     }
-    store_rect(j);
+    store_rect(cur);
+    cur = nxt;
+    advance(nxt);
     __builtin_amdgcn_sched_barrier(0);
   }
   wait_vmcnt<0>();                               // the zero-filling tail loads target this workgroup's LDS: let them land
