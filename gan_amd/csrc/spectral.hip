@@ -5,8 +5,8 @@
 // HBM-bound: W is read twice per iteration, with 16-byte loads where the row length allows; every sum runs in a fixed
 // order (partial sums per row range, added in order), so the result does not depend on timing.
 //   sn_cols_kernel       part[split][col] = sum over the split's rows of u[row] * W[row][col]
-//   sn_cols_finish       t = sum of the parts, scal[0] = 1 / max(|t|, eps)                       (one workgroup)
-//   sn_rows_kernel       s[row] = scal[0] * <W[row], t>                                          (one wave per row)
+//   sn_cols_finish       t = sum of the parts, scal[4 + b] = block b's share of |t|^2              (16 workgroups per matrix)
+//   sn_rows_kernel       s[row] = <W[row], t> / max(|t|, eps), |t|^2 = the shares added in order   (one wave per row)
 //   sn_rows_finish       u = s / max(|s|, eps), sigma = |s|^2 / max(|s|, eps)                    (one workgroup)
 #include "common.h"
 
@@ -15,6 +15,8 @@ namespace {
 
 constexpr float kNormEps = 1e-12f;      // torch.nn.functional.normalize's default
 constexpr int kMaxSplits = 64;
+constexpr int kFinBlocks = 16;          // workgroups that add a matrix's column partials (one partial square each)
+constexpr int kScalFloats = 4 + kFinBlocks;
 
 __device__ __forceinline__ float block_sum(float v, float* red) {   // red: kThreads / 64 floats of LDS; all threads get the sum
 #pragma unroll
@@ -59,21 +61,38 @@ __global__ __launch_bounds__(kThreads) void sn_cols_kernel(const float* w, const
   sn_cols<VEC>(w, u, part, rows, cols, rows_per_split, blockIdx.x, blockIdx.y);
 }
 
-__device__ __forceinline__ void sn_cols_fin(const float* part, float* t, float* scal, long cols, int splits, float* red) {
+// block `blk` of `nblk` takes the columns blk * kThreads + t, stride nblk * kThreads
+__device__ __forceinline__ void sn_cols_fin(const float* part, float* t, float* scal, long cols, int splits, float* red, int blk, int nblk) {
   float sq = 0.f;
-  for (long c = threadIdx.x; c < cols; c += kThreads) {
-    float s = 0.f;
-    for (int k = 0; k < splits; k++) s += part[(size_t)k * cols + c];
+  for (long c = (long)blk * kThreads + threadIdx.x; c < cols; c += (long)nblk * kThreads) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four loads in flight; the order of the additions is fixed
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      s0 += part[(size_t)k * cols + c];
+      s1 += part[(size_t)(k + 1) * cols + c];
+      s2 += part[(size_t)(k + 2) * cols + c];
+      s3 += part[(size_t)(k + 3) * cols + c];
+    }
+    for (; k < splits; k++) s0 += part[(size_t)k * cols + c];
+    const float s = (s0 + s1) + (s2 + s3);
     t[c] = s;
     sq += s * s;
   }
   sq = block_sum(sq, red);
-  if (threadIdx.x == 0) scal[0] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+  if (threadIdx.x == 0) scal[4 + blk] = sq;
+}
+
+// 1 / max(|t|, eps) from the blocks' shares of |t|^2, added in block order
+__device__ __forceinline__ float sn_inv_norm(const float* scal) {
+  float sq = 0.f;
+#pragma unroll
+  for (int b = 0; b < kFinBlocks; b++) sq += scal[4 + b];
+  return 1.f / fmaxf(sqrtf(sq), kNormEps);
 }
 
 __global__ __launch_bounds__(kThreads) void sn_cols_finish(const float* part, float* t, float* scal, long cols, int splits) {
   __shared__ float red[kThreads / 64];
-  sn_cols_fin(part, t, scal, cols, splits, red);
+  sn_cols_fin(part, t, scal, cols, splits, red, blockIdx.x, kFinBlocks);
 }
 
 // one wave per row
@@ -93,7 +112,7 @@ __device__ __forceinline__ void sn_rows(const float* w, const float* t, const fl
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) s[row] = acc * scal[0];
+  if (lane == 0) s[row] = acc * sn_inv_norm(scal);
 }
 
 template <int VEC>
@@ -136,8 +155,8 @@ __global__ __launch_bounds__(kThreads) void sn_multi_cols_kernel(const gc_spectr
 
 __global__ __launch_bounds__(kThreads) void sn_multi_cols_finish(const gc_spectral_plan* plan, float* ws) {
   __shared__ float red[kThreads / 64];
-  const gc_spectral_plan q = plan[blockIdx.x];
-  sn_cols_fin(ws + q.ws_part, ws + q.ws_t, ws + q.ws_scal, q.cols, q.splits, red);
+  const gc_spectral_plan q = plan[blockIdx.x / kFinBlocks];
+  sn_cols_fin(ws + q.ws_part, ws + q.ws_t, ws + q.ws_scal, q.cols, q.splits, red, blockIdx.x % kFinBlocks, kFinBlocks);
 }
 
 __global__ __launch_bounds__(kThreads) void sn_multi_rows_kernel(const gc_spectral_plan* plan, int n, float* ws) {
@@ -172,9 +191,9 @@ extern "C" {
 
 size_t gc_spectral_norm_workspace_bytes(int32_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return 0;
-  // parts [splits][cols], t [cols], s [rows], one scalar; each piece 16-byte aligned
+  // parts [splits][cols], t [cols], s [rows], the blocks' shares of |t|^2; each piece 16-byte aligned
   const size_t c4 = ((size_t)cols + 3) / 4 * 4, r4 = ((size_t)rows + 3) / 4 * 4;
-  return ((size_t)kMaxSplits * c4 + c4 + r4 + 4) * sizeof(float);
+  return ((size_t)kMaxSplits * c4 + c4 + r4 + kScalFloats) * sizeof(float);
 }
 
 int gc_spectral_norm_power_iteration(const float* w, int32_t rows, int64_t cols, float* u, float* sigma, int32_t n_iterations,
@@ -206,7 +225,7 @@ int gc_spectral_norm_power_iteration(const float* w, int32_t rows, int64_t cols,
       if (vec) hipLaunchKernelGGL(sn_cols_kernel<4>, grid_c, dim3(kThreads), 0, stream, w, u, part, rows, (long)cols, rows_per_split);
       else hipLaunchKernelGGL(sn_cols_kernel<1>, grid_c, dim3(kThreads), 0, stream, w, u, part, rows, (long)cols, rows_per_split);
     }
-    hipLaunchKernelGGL(sn_cols_finish, dim3(1), dim3(kThreads), 0, stream, part, t, scal, (long)cols, splits);
+    hipLaunchKernelGGL(sn_cols_finish, dim3(kFinBlocks), dim3(kThreads), 0, stream, part, t, scal, (long)cols, splits);
     {
       ProfScope ps("gc::sn_rows_kernel", 0.0, stream);
       if (vec) hipLaunchKernelGGL(sn_rows_kernel<4>, dim3(grid_r), dim3(kThreads), 0, stream, w, t, scal, s, rows, (long)cols);
@@ -246,7 +265,7 @@ int gc_spectral_norm_multi_plan(const gc_spectral_job* jobs, int32_t n, gc_spect
     q.ws_part = (int64_t)floats; floats += (size_t)q.splits * c4;
     q.ws_t = (int64_t)floats; floats += c4;
     q.ws_s = (int64_t)floats; floats += r4;
-    q.ws_scal = (int64_t)floats; floats += 4;
+    q.ws_scal = (int64_t)floats; floats += kScalFloats;
   }
   if (col_blocks_total >= (1l << 31) || row_blocks_total >= (1l << 31)) {
     set_error("gc_spectral_norm_multi_plan: too many blocks");
@@ -272,7 +291,7 @@ int gc_spectral_norm_multi_run(const gc_spectral_plan* plan_device, int32_t n, c
       ProfScope ps("gc::sn_multi_cols_kernel", 0.0, stream);
       hipLaunchKernelGGL(sn_multi_cols_kernel, dim3((unsigned)grids[0]), dim3(kThreads), 0, stream, plan_device, n, ws);
     }
-    hipLaunchKernelGGL(sn_multi_cols_finish, dim3((unsigned)n), dim3(kThreads), 0, stream, plan_device, ws);
+    hipLaunchKernelGGL(sn_multi_cols_finish, dim3((unsigned)n * kFinBlocks), dim3(kThreads), 0, stream, plan_device, ws);
     {
       ProfScope ps("gc::sn_multi_rows_kernel", 0.0, stream);
       hipLaunchKernelGGL(sn_multi_rows_kernel, dim3((unsigned)grids[1]), dim3(kThreads), 0, stream, plan_device, n, ws);
