@@ -1621,6 +1621,67 @@ torch.library.register_autograd("ganconv::attention", _attn_backward, setup_cont
 
 
 # ---- 2x2 pooling / 2x nearest replication (an adjoint pair; each is the other's backward) -------------------------
+# ---- the tail of the self-attention block: x + gamma * (the [B, N, C] product read as [B, C, H, W]) --------------------
+@torch.library.custom_op("ganconv::attention_residual", mutates_args=())
+def attention_residual(x: Tensor, mixed: Tensor, gamma: Tensor) -> Tensor:
+    """x + gamma * mixed.reshape(x.shape) for the attention product `mixed` [B, N, C] (contiguous) and the block input x
+    [B, C, H, W] in channels-last memory: the reference reinterprets the product's buffer as [B, C, H, W] without a
+    transpose (BigGAN/model.py:97-105), which is a transposition against channels-last memory; one tiled launch instead of a
+    strided addcmul.  N and C multiples of 64; gamma: one float."""
+    _check_cuda(x, mixed, gamma)
+    B, C, H, W = x.shape
+    N = H * W
+    if tuple(mixed.shape) != (B, N, C) or mixed.dtype != x.dtype:
+        raise RuntimeError(f"ganconv: attention_residual expects the product as [B, N, C] = [{B}, {N}, {C}] in the input's dtype")
+    x, mixed = _nhwc(x), mixed.contiguous()
+    gm = gamma.detach().to(torch.float32).reshape(1).contiguous()
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().gc_attention_residual_fwd(_ptr(x), _ptr(mixed), _ptr(gm), _ptr(out), B, N, C, _dtype_code(x), _stream()),
+               "gc_attention_residual_fwd")
+    return out
+
+
+@attention_residual.register_fake
+def _(x, mixed, gamma):
+    return torch.empty_like(x, memory_format=torch.channels_last)
+
+
+@torch.library.custom_op("ganconv::attention_residual_bwd", mutates_args=())
+def attention_residual_bwd(g: Tensor, mixed: Tensor, gamma: Tensor) -> tuple[Tensor, Tensor]:
+    """(d mixed [B, N, C], d gamma [1]) of attention_residual from the gradient g of its output."""
+    _check_cuda(g, mixed, gamma)
+    B, C, H, W = g.shape
+    N = H * W
+    g = _nhwc(g if g.dtype == mixed.dtype else g.to(mixed.dtype))
+    mixed = mixed.contiguous()
+    gm = gamma.detach().to(torch.float32).reshape(1).contiguous()
+    dm = torch.empty_like(mixed)
+    dgamma = torch.empty(1, dtype=torch.float32, device=g.device)
+    L = _lib.lib()
+    ws = torch.empty(max(L.gc_attention_residual_workspace_bytes(B, N, C), 16), dtype=torch.uint8, device=g.device)
+    _lib.check(L.gc_attention_residual_bwd(_ptr(g), _ptr(mixed), _ptr(gm), _ptr(dm), _ptr(dgamma), _ptr(ws), ws.numel(), B, N, C,
+                                           _dtype_code(g), _stream()), "gc_attention_residual_bwd")
+    return dm, dgamma
+
+
+@attention_residual_bwd.register_fake
+def _(g, mixed, gamma):
+    return torch.empty_like(mixed), mixed.new_empty(1, dtype=torch.float32)
+
+
+def _attn_res_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1], inputs[2])
+
+
+def _attn_res_backward(ctx, g):
+    mixed, gamma = ctx.saved_tensors
+    dm, dgamma = attention_residual_bwd(g, mixed, gamma)
+    return g, dm, dgamma.to(gamma.dtype).reshape(gamma.shape)
+
+
+torch.library.register_autograd("ganconv::attention_residual", _attn_res_backward, setup_context=_attn_res_setup)
+
+
 def _resample(fn_name, x, scale, H, W, shape):
     _check_cuda(x)
     x = _nhwc(x)

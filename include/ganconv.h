@@ -498,6 +498,19 @@ int gc_attention_fwd(const void* k, const void* q, const void* v, void* out, flo
 int gc_attention_bwd(const void* k, const void* q, const void* v, const void* out, const void* dout, const float* lse, void* dk,
                      void* dq, void* dv, float* delta, int32_t B, int32_t N, int32_t d, int32_t C, void* stream);
 
+/* The tail of the self-attention block (BigGAN/model.py:97-105): out = x + gamma * mixed.view(B, C, H, W), where mixed is
+ * the attention product [B, N, C] that the reference reinterprets, WITHOUT a transpose, as a contiguous [B, C, H, W] tensor.
+ * With NHWC activations (x, out, g: [B][N][C]) that is a batched transpose fused with an axpy:
+ *   fwd   out[b][p][c] = x[b][p][c] + gamma[0] * mixed[b][c * N + p]
+ *   bwd   dmixed[b][c * N + p] = gamma[0] * g[b][p][c],  dgamma[0] = sum of g[b][p][c] * mixed[b][c * N + p]   (dx = g)
+ * N and C multiples of 64, one gc_dtype for the tensors, gamma / dgamma float[1] on the device, 16-byte aligned pointers;
+ * the workspace holds one partial of dgamma per 64 x 64 tile, added in a fixed order. */
+int gc_attention_residual_fwd(const void* x, const void* mixed, const float* gamma, void* out, int32_t B, int32_t N, int32_t C, int32_t dtype,
+                              void* stream);
+size_t gc_attention_residual_workspace_bytes(int32_t B, int32_t N, int32_t C);
+int gc_attention_residual_bwd(const void* g, const void* mixed, const float* gamma, void* dmixed, float* dgamma, void* workspace,
+                              size_t workspace_bytes, int32_t B, int32_t N, int32_t C, int32_t dtype, void* stream);
+
 /* Split reductions.  A convolution whose output grid cannot fill the chip (few output pixels x channels, long
  * reduction) is split over several workgroups that add fp32 partial tiles into the zeroed output with atomics; the
  * order of those adds, and so the last bit of the result, varies from run to run.  gc_set_split_reduction(0) turns

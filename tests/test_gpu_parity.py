@@ -1292,6 +1292,32 @@ def test_patch_kernel_exact_on_small_integers(gan, cin, cout, hw, k, s, p, B):
     assert torch.equal(y2, yr)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(3, 64, 8, 8), (2, 128, 16, 24), (1, 64, 64, 64)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_residual_against_the_reference_expression(gan, B, C, H, W, dt):
+    """x + gamma * mixed.view(B, C, H, W) (BigGAN/model.py:97-105: the [B, N, C] product reinterpreted without a transpose) and
+    its three gradients against the tensor expression on the CPU in float64."""
+    g = torch.Generator().manual_seed(C + H)
+    N = H * W
+    x = torch.randn(B, C, H, W, generator=g).to(dt)
+    m = torch.randn(B, N, C, generator=g).to(dt)
+    gamma = torch.tensor([[0.37]])
+    seed = torch.randn(B, C, H, W, generator=g).to(dt)
+    xr, mr, gr = x.double().requires_grad_(True), m.double().requires_grad_(True), gamma.double().requires_grad_(True)
+    want = xr + gr * mr.reshape(B, C, H, W)
+    wx, wm, wg = torch.autograd.grad(want, [xr, mr, gr], seed.double())
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    mg, gg = m.cuda().requires_grad_(True), gamma.cuda().requires_grad_(True)
+    got = gan.ops.attention_residual(xg, mg, gg)
+    assert got.dtype == dt and got.shape == (B, C, H, W)
+    gx, gm, ggam = torch.autograd.grad(got, [xg, mg, gg], seed.cuda().contiguous(memory_format=torch.channels_last))
+    tol = 1e-6 if dt == torch.float32 else 6e-3
+    assert rel(got.float(), want) < tol and rel(gx.float(), wx) < tol and rel(gm.float(), wm) < tol
+    assert ggam.shape == gamma.shape and rel(ggam, wg) < (1e-5 if dt == torch.float32 else 2e-3)
+    again = torch.autograd.grad(gan.ops.attention_residual(xg, mg, gg), [gg], seed.cuda().contiguous(memory_format=torch.channels_last))[0]
+    assert torch.equal(again, ggam)                      # fixed summation order
+
+
 def _random_geometries(n, seed):
     import random
     rnd = random.Random(seed)
