@@ -33,7 +33,7 @@ from .. import ops
 GENERATOR_PLAN = ((16, 16), (16, 8), (8, 4), (4, 2), "attention", (2, 1))                  # BigGAN/model.py:147-154
 CRITIC_PLAN = ((None, 1, True), "attention", (1, 2, True), (2, 4, True), (4, 8, True), (8, 16, True), (16, 16, False))   # :212-220
 
-_opt = {"dtype": None, "fused_attention": False, "fused_norm": True}
+_opt = {"dtype": None, "fused_attention": False, "fused_norm": True, "defer": True}
 
 
 def set_activation_dtype(dtype):
@@ -43,6 +43,11 @@ def set_activation_dtype(dtype):
 
 def set_fused_attention(on):
     _opt["fused_attention"] = bool(on)
+
+
+def set_deferred_activations(on):
+    """Whether the discriminator blocks leave their ReLU derivatives to the consuming data-gradient kernels (default)."""
+    _opt["defer"] = bool(on)
 
 
 def set_fused_norm(on):
@@ -100,13 +105,15 @@ class Conv2d(gnn.Conv2d):
         self.n_iterations, self.norm = n_iterations, norm
         self.register_buffer("U_vector", torch.rand(1, output_channels))
 
-    def forward(self, x, activation=None, out_dtype=None, upsample=False):
-        """upsample: the input is replicated x2 first (BigGAN/model.py:117-119), folded into the 3x3 weight."""
+    def forward(self, x, activation=None, out_dtype=None, upsample=False, defer=False, in_slope=None):
+        """upsample: the input is replicated x2 first (BigGAN/model.py:117-119), folded into the 3x3 weight.  defer / in_slope:
+        the ReLU's derivative is applied by the data-gradient kernel of the one convolution that reads the activated tensor
+        (functional.conv2d's defer_activation_grad / input_activation_slope)."""
         out_dtype = out_dtype if out_dtype is not None else _opt["dtype"]
         if upsample:
             return GF.upsample2x_conv3x3(x, self.weight / _sigma(self), self.bias, activation=activation, out_dtype=out_dtype)
         return GF.conv2d(x, self.weight / _sigma(self), self.bias, self.stride, self.padding, self.dilation, self.groups,
-                         activation=activation, out_dtype=out_dtype)
+                         activation=activation, out_dtype=out_dtype, defer_activation_grad=defer, input_activation_slope=in_slope)
 
 
 class Linear(torch.nn.Linear):
@@ -188,8 +195,22 @@ class GeneratorBlock(torch.nn.Module):
         return h + GF.upsample_nearest2x(self.residual_conv(x))
 
 
+class _ReluDerivativeLater(torch.autograd.Function):
+    """relu(x) whose backward pass hands the gradient through unchanged: the convolution that reads the result (its only
+    reader) is called with in_slope = 0 and applies the ReLU's derivative in its data-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class DiscriminatorBlock(torch.nn.Module):
-    """relu-conv3x3-relu-conv3x3(-pool) plus a 1x1 shortcut."""
+    """relu-conv3x3-relu-conv3x3(-pool) plus a 1x1 shortcut.  On the GPU neither ReLU has a backward sweep of its own: the
+    derivative of the first rides on conv_1's data-gradient kernel, that of the second (conv_1's epilogue) on conv_2's."""
 
     def __init__(self, cin, cout, downsample=True):
         super().__init__()
@@ -199,7 +220,11 @@ class DiscriminatorBlock(torch.nn.Module):
         self.pool = downsample
 
     def forward(self, x):
-        h = self.conv_2(self.conv_1(torch.relu(x), activation="relu"))
+        first = x.is_cuda and _opt["defer"] and x.shape[1] % 4 == 0 and x.requires_grad
+        second = x.is_cuda and _opt["defer"] and self.conv_1.out_channels % 4 == 0
+        a = _ReluDerivativeLater.apply(x) if first else torch.relu(x)
+        h = self.conv_1(a, activation="relu", defer=second, in_slope=0.0 if first else None)
+        h = self.conv_2(h, in_slope=0.0 if second else None)
         if self.pool:
             return GF.avg_pool2x2(h) + self.residual_conv(GF.avg_pool2x2(x))
         return h + self.residual_conv(x)

@@ -132,3 +132,32 @@ def test_stylegan_critic_with_and_without_the_deferral(gan):
     assert ga.keys() == gb.keys()
     worst = max((rel(gb[n], ga[n]), n) for n in ga if float(ga[n].norm()) > 0)
     assert worst[0] < 2e-2, worst
+
+
+def test_biggan_discriminator_blocks_with_and_without_the_deferral(gan):
+    """BigGAN's relu-conv-relu-conv blocks (BigGAN/model.py:180-203): scores and every parameter gradient agree between the
+    form whose ReLU derivatives ride on the data-gradient kernels and the form with their own sweeps."""
+    from gan_amd.harness import biggan as B
+    torch.manual_seed(5)
+    D = B.Discriminator(n_classes=4, ch=8).cuda()
+    x = torch.randn(4, 3, 128, 128, device="cuda")
+    y = torch.randint(0, 4, (4,), device="cuda")
+    out = []
+    try:
+        for fused in (False, True):
+            B.set_deferred_activations(fused)
+            D.zero_grad(set_to_none=True)
+            for m in D.modules():                       # the same power-iteration state in both runs
+                if hasattr(m, "U_vector"):
+                    torch.manual_seed(11)
+                    m.U_vector.copy_(torch.rand_like(m.U_vector))
+            score = D(x, y)
+            torch.relu(1 - score).mean().backward()
+            out.append((score.detach(), {n: p.grad.clone() for n, p in D.named_parameters() if p.grad is not None}))
+    finally:
+        B.set_deferred_activations(True)
+    (sa, ga), (sb, gb) = out
+    assert rel(sb, sa) < 1e-5
+    assert ga.keys() == gb.keys() and len(ga) > 20
+    worst = max((rel(gb[n], ga[n]), n) for n in ga if float(ga[n].norm()) > 0)
+    assert worst[0] < 2e-2, worst
