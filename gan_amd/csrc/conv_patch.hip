@@ -24,6 +24,13 @@
 // rectangle (64 pixels): TO / 4 MFMAs per tap against TO / 16 + 4 fragment reads.
 // Weight rows are permuted inside groups of 32 (oc_of_row) so that a lane's two MFMA blocks of a group hold 8
 // consecutive channels of a pixel: one 16-byte store per (pixel, 8 channels) in bf16.
+//
+// S2D: the forward pass of a 4x4 / stride 2 / padding 1 convolution (the down-sampling layers of the critics and of the
+// U-Net encoder) as the 2x2-tap stride-1 convolution it is on the space-to-depth image: output pixel (y, x), filter tap
+// (2 tr + dy, 2 ts + dx) reads input pixel (2 (y + tr) - 1 + dy, 2 (x + ts) - 1 + dx), i.e. pixel (y + tr, x + ts) of the
+// image of 2x2 blocks whose 4 C channels are (dy, dx, c).  Nothing is rearranged in memory: a "chunk" of that image is a
+// (dy, dx, 32 channels) triple, its patch (9 x 33 block pixels) is gathered with a pixel stride of two rows / columns, and
+// its weights are the taps (2 tr + dy, 2 ts + dx) of the ordinary packed image.  The multiply loop is the same.
 #include <stdio.h>
 
 #include "conv_gather.h"
@@ -53,7 +60,7 @@ __device__ __forceinline__ int oc_of_row(int row) {
   return (row & ~31) + 8 * g + 4 * f + e;
 }
 
-template <typename TOut, int TO, bool MASK>
+template <typename TOut, int TO, bool MASK, bool S2D = false>
 __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherParams p) {
   constexpr int FO = TO / 16;              // MFMA blocks of output channels
   constexpr int WJ = TO / 64;              // weight DMA instructions per wave and step
@@ -86,13 +93,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
   const int th_ = rest % tiles_h;
   const int n = rest / tiles_h;
   const int tap_begin = p.tt.cls_tap_start[cls], tap_end = p.tt.cls_tap_start[cls + 1];
-  const int T = tap_end - tap_begin;
+  int T = tap_end - tap_begin;
   int dh_min = 127, dh_max = -128, dw_min = 127, dw_max = -128;
-  for (int e = tap_begin; e < tap_end; e++) {
-    const int v = __builtin_amdgcn_readfirstlane(tap_lds[e]);
-    const int dh = (int)(int8_t)(v & 0xff), dw = (int)(int8_t)((v >> 8) & 0xff);
-    dh_min = min(dh_min, dh); dh_max = max(dh_max, dh);
-    dw_min = min(dw_min, dw); dw_max = max(dw_max, dw);
+  if (S2D) {
+    T = 4; dh_min = dw_min = 0; dh_max = dw_max = 1;       // 2 x 2 block taps
+  } else {
+    for (int e = tap_begin; e < tap_end; e++) {
+      const int v = __builtin_amdgcn_readfirstlane(tap_lds[e]);
+      const int dh = (int)(int8_t)(v & 0xff), dw = (int)(int8_t)((v >> 8) & 0xff);
+      dh_min = min(dh_min, dh); dh_max = max(dh_max, dh);
+      dw_min = min(dw_min, dw); dw_max = max(dw_max, dw);
+    }
   }
   const int PH = kTH + dh_max - dh_min, PW = kTW + dw_max - dw_min;
   const int npatch = PH * PW;
@@ -101,7 +112,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
   // step waits for a table read.
   const int nw = dw_max - dw_min + 1;
   int to0, dto_r = 0, dto_s = 0, wt0, dwt_r = 0, dwt_s = 0;
-  {
+  if (S2D) {
+    to0 = 0; dto_r = PW; dto_s = 1;
+    wt0 = 0; dwt_r = 8; dwt_s = 2;                         // filter tap (2 tr + dy) * 4 + 2 ts + dx; (dy, dx) comes with the chunk
+  } else {
     auto tap_at = [&](int i, int& to, int& wt) {
       const int v = __builtin_amdgcn_readfirstlane(tap_lds[tap_begin + i]);
       to = ((int)(int8_t)(v & 0xff) - dh_min) * PW + ((int)(int8_t)((v >> 8) & 0xff) - dw_min);
@@ -127,10 +141,22 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
     const int pos = lane & 3;
     const int chunk = pos ^ ((px >> 1) & 3);
     const int pr = px / PW, pc = px - pr * PW;
-    const int ih = th_ * kTH + pr + dh_min, iw = tw_ * kTW + pc + dw_min;
-    const bool ok = (px < npatch) & ((unsigned)ih < (unsigned)p.IH) & ((unsigned)iw < (unsigned)p.IW);
-    a_chunk[j] = ok ? chunk * 8 : (1 << 30);     // a masked lane fails the channel check of every chunk
-    a_off[j] = (uint32_t)((((size_t)n * p.IH + (ok ? ih : 0)) * p.IW + (ok ? iw : 0)) * p.in_cstride + p.in_coff + chunk * 8) * 2u;
+    if (S2D) {
+      // block pixel (by, bx): the offset is that of its sub-pixel (dy, dx) = (1, 1), input pixel (2 by, 2 bx) (non-negative;
+      // the other three lie one row / column in front of it); bits 3 .. 6 say which of the four lie inside the image
+      const int ih = 2 * (th_ * kTH + pr), iw = 2 * (tw_ * kTW + pc);
+      int okb = 0;
+#pragma unroll
+      for (int d = 0; d < 4; d++)
+        okb |= ((px < npatch) & ((unsigned)(ih - 1 + (d >> 1)) < (unsigned)p.IH) & ((unsigned)(iw - 1 + (d & 1)) < (unsigned)p.IW)) ? (8 << d) : 0;
+      a_chunk[j] = chunk * 8 + (okb << 4);               // bits 0 .. 6: channel offset of the 16-byte piece, bits 7 .. 10: validity
+      a_off[j] = (uint32_t)((((size_t)n * p.IH + ih) * p.IW + iw) * p.in_cstride + p.in_coff + chunk * 8) * 2u;
+    } else {
+      const int ih = th_ * kTH + pr + dh_min, iw = tw_ * kTW + pc + dw_min;
+      const bool ok = (px < npatch) & ((unsigned)ih < (unsigned)p.IH) & ((unsigned)iw < (unsigned)p.IW);
+      a_chunk[j] = ok ? chunk * 8 : (1 << 30);     // a masked lane fails the channel check of every chunk
+      a_off[j] = (uint32_t)((((size_t)n * p.IH + (ok ? ih : 0)) * p.IW + (ok ? iw : 0)) * p.in_cstride + p.in_coff + chunk * 8) * 2u;
+    }
   }
   uint32_t w_voff[WJ];
 #pragma unroll
@@ -140,11 +166,25 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
     w_voff[j] = oc < p.OC ? (uint32_t)(((size_t)oc * p.row_pitch + (pos ^ ((row >> 1) & 3)) * 8) * 2) : kOutOfRange;
   }
 
-  const int nchunks = p.ICp / kCK;
+  const int nch = p.ICp / kCK;                             // 32-channel chunks of the input
+  const int nchunks = S2D ? 4 * nch : nch;                 // S2D: chunk = (dy, dx, 32 channels), the channel chunk running fastest
   const int nsteps = nchunks * T;
 
   auto issue_patch = [&](int c) {
     char* pb = patch_base + (c & 1) * kPatchBytes;
+    if (S2D) {
+      const int d = c / nch, c0 = (c - d * nch) * kCK;
+      // sub-pixel (dy, dx) lies (1 - dy) rows and (1 - dx) columns in front of the lane's anchor
+      const uint32_t back = (uint32_t)(((1 - (d >> 1)) * p.IW + (1 - (d & 1))) * p.in_cstride) * 2u;
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+        if (j < 5 || npi == 6) {
+          const bool ok = ((a_chunk[j] >> (7 + d)) & 1) && (c0 + (a_chunk[j] & 127)) < p.IC;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(pb + (j * kNW + wave) * 1024), 16,
+                                                   (int)(ok ? a_off[j] - back : kOutOfRange), c0 * 2, 0, 0);
+        }
+      return;
+    }
     const int c0 = c * kCK;
 #pragma unroll
     for (int j = 0; j < 6; j++)
@@ -154,7 +194,13 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
   };
   // weights of step (chunk c, tap ti): [TO oc][32 ch]; steps past the last one load zeros (uniform wait counts)
   auto issue_w = [&](int slot, int c, int tr, int ts, bool live) {
-    const uint32_t soff = (uint32_t)(((wt0 + tr * dwt_r + ts * dwt_s) * p.ICp + c * kCK) * 2);
+    uint32_t soff;
+    if (S2D) {
+      const int d = c / nch, c0 = (c - d * nch) * kCK;
+      soff = (uint32_t)((((d >> 1) * 4 + (d & 1) + tr * dwt_r + ts * dwt_s) * p.ICp + c0) * 2);
+    } else {
+      soff = (uint32_t)(((wt0 + tr * dwt_r + ts * dwt_s) * p.ICp + c * kCK) * 2);
+    }
 #pragma unroll
     for (int j = 0; j < WJ; j++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(w_base + slot * kWBytes + (wave * WJ + j) * 1024), 16,
@@ -339,13 +385,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
   }
 }
 
-template <typename TOut, int TO, bool MASK>
+template <typename TOut, int TO, bool MASK, bool S2D = false>
 int launch_one(const GatherParams& p, double flops, hipStream_t stream) {
   constexpr int kSmem = smem_bytes(TO);
-  auto kern = conv_patch_kernel<TOut, TO, MASK>;
+  auto kern = conv_patch_kernel<TOut, TO, MASK, S2D>;
   if (ensure_dynamic_smem(reinterpret_cast<const void*>(kern), kSmem) != GC_OK) return GC_HIP_ERROR;
   char name[96];
-  snprintf(name, sizeof(name), "gc::conv_patch_kernel<%s, %d, %s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, MASK ? "true" : "false");
+  snprintf(name, sizeof(name), "gc::conv_patch_kernel<%s, %d, %s%s>", sizeof(TOut) == 4 ? "float" : "unsigned short", TO, MASK ? "true" : "false",
+           S2D ? ", strided" : "");
   ProfScope ps(name, flops, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)p.n_pix_tiles * (unsigned)p.n_oc_tiles), dim3(kNW * 64), kSmem, stream, p);
   return check_hip(hipGetLastError(), "conv_patch launch");
@@ -369,10 +416,31 @@ int patch_to(const GatherParams& p) {
 // tensors below 2 GiB, no reduction split.
 bool plan_patch(GatherParams& p, const GatherLaunch& l) {
   const int to = patch_to(p);
-  if (!l.in_bf16 || l.mode != kVecLoads || p.a != 1 || to == 0 || p.ICp % kCK != 0) return false;
+  if (!l.in_bf16 || l.mode != kVecLoads || (p.a != 1 && p.a != 2) || to == 0 || p.ICp % kCK != 0) return false;
   if (p.ch_sum != nullptr || p.ch_sumsq != nullptr || p.out_bf16 != nullptr) return false;
   long tiles = 0;
   int starts[kMaxClasses + 1];
+  if (p.a == 2) {
+    // the strided mode: a 4x4 / stride 2 / padding 1 forward convolution with its taps in filter order
+    static const bool off = getenv("GC_PATCH_NO_STRIDED") != nullptr;
+    if (off || p.b != 1 || p.tt.n_classes != 1 || p.tt.cls_tap_start[1] - p.tt.cls_tap_start[0] != 16) return false;
+    const int t0 = p.tt.cls_tap_start[0];
+    for (int e = 0; e < 16; e++)
+      if (p.tt.dh[t0 + e] != e / 4 - 1 || p.tt.dw[t0 + e] != e % 4 - 1 || p.tt.wtap[t0 + e] != e) return false;
+    const int oh = p.tt.cls_oh[0], ow = p.tt.cls_ow[0];
+    if (oh % kTH != 0 || ow % kTW != 0 || p.tt.cls_ph[0] != 0 || p.tt.cls_pw[0] != 0) return false;
+    // a lane's anchor pixel (2 by, 2 bx) may lie one row and one column past the image: its 32-bit offset must not wrap
+    if (p.in_bytes + ((int64_t)p.IW + 2) * p.in_cstride * 2 >= (1ll << 31)) return false;
+    tiles = (long)p.N * (oh / kTH) * (ow / kTW);
+    const int n_oc_tiles = (p.OC + to - 1) / to;
+    if (tiles * n_oc_tiles < 512 || tiles * n_oc_tiles >= (1l << 31)) return false;
+    p.tt.cls_tile_start[0] = 0;
+    for (int c = 1; c <= kMaxClasses; c++) p.tt.cls_tile_start[c] = (int)tiles;
+    p.n_pix_tiles = (int)tiles;
+    p.n_oc_tiles = n_oc_tiles;
+    p.cls_interleave = 0;
+    return true;
+  }
   for (int c = 0; c < p.tt.n_classes; c++) {
     const int t0 = p.tt.cls_tap_start[c], t1 = p.tt.cls_tap_start[c + 1];
     if (t1 - t0 < 4) return false;       // the wait counts assume that a chunk's patch has three steps to land
@@ -412,6 +480,10 @@ bool plan_patch(GatherParams& p, const GatherLaunch& l) {
 // Applies p.mask itself (and clears it) when the 16-byte store path holds for every lane; otherwise the caller's sweep does.
 int launch_patch(GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
   if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
+  if (p.a == 2) {                        // strided mode; a mask, if any, stays with the caller's sweep
+    if (patch_to(p) == 128) return out_f32 ? launch_one<float, 128, false, true>(p, l.flops, stream) : launch_one<uint16_t, 128, false, true>(p, l.flops, stream);
+    return out_f32 ? launch_one<float, 64, false, true>(p, l.flops, stream) : launch_one<uint16_t, 64, false, true>(p, l.flops, stream);
+  }
   const bool mask = p.mask != nullptr && p.out_vec8 && p.OC % 8 == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 15u) == 0;
   int rc;
   if (patch_to(p) == 128) rc = out_f32 ? launch_mask<float, 128>(p, l.flops, mask, stream) : launch_mask<uint16_t, 128>(p, l.flops, mask, stream);
