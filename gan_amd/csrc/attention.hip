@@ -31,7 +31,7 @@ struct AttnParams {
   const uint16_t *k, *q, *v, *o, *dout;
   uint16_t *out, *dk, *dq, *dv;
   float *lse, *delta;
-  int N, d, C;
+  int B, N, d, C;
 };
 
 constexpr int kBlk = 64;      // positions staged per step
@@ -62,13 +62,40 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int r0, i
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
-__device__ __forceinline__ float xor_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  return fmaxf(v, __shfl_xor(v, 32));
+// exp(x) for a pair of scores already in units of log 2: two v_exp_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kLog2e = 1.44269504088896340736f;
+__device__ __forceinline__ f32x2 exp2_pair(f32x2 t) { return f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])}; }
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ bf16x8 ones8() {
+  const u32x4 o = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  return __builtin_bit_cast(bf16x8, o);
 }
-__device__ __forceinline__ float xor_sum(float v) {
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
+// Exchanges across the wave's four 16-lane rows in the vector unit (v_permlane32_swap / v_permlane16_swap: with both
+// operands the same register, one result holds the own half / row and the other the partner's), not through the LDS crossbar.
+__device__ __forceinline__ float xor_max(float v) {
+  typedef unsigned int u32pair __attribute__((ext_vector_type(2)));
+  u32pair r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, v), __builtin_bit_cast(unsigned int, v), false, false);
+  v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned int, v), __builtin_bit_cast(unsigned int, v), false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+// Which (sample, tile of 128 positions) a workgroup owns.  Workgroup b runs on XCD b % 8, and every workgroup of a sample walks
+// that sample's whole value / key tensors (0.5 - 1 MiB): the workgroups of one sample are given to ONE XCD, so that its L2
+// (4 MiB) holds the two to four samples its CUs are working on; dealt round-robin, every L2 would see all 16 - 32 samples
+// in flight and miss.  Samples beyond the last multiple of eight are dealt in order.
+__device__ __forceinline__ void sample_and_tile(int B, int tiles, int& sample, int& tile) {
+  const int b = blockIdx.x, grouped = (B & ~7) * tiles;
+  if (b < grouped) {
+    const int r = b >> 3;
+    sample = (r / tiles) * 8 + (b & 7);
+    tile = r % tiles;
+  } else {
+    const int r = b - grouped;
+    sample = (B & ~7) + r / tiles;
+    tile = r % tiles;
+  }
 }
 
 // Stages 64 rows of a C-wide tensor and of a d-wide tensor (plus, optionally, 64 entries of two fp32 vectors) through
@@ -94,8 +121,8 @@ struct Stager {
     if (tid < 2 * kBlk && (tid & 1) * 8 < d) n = *reinterpret_cast<const u32x4*>(narrow + (row0 + (tid >> 1)) * d + (tid & 1) * 8);
     if (VEC) {
       f = 0.f;
-      if (tid >= 128 && tid < 192) f = va[row0 + tid - 128];
-      if (tid >= 192) f = vb[row0 + tid - 192];
+      if (tid >= 128 && tid < 192) f = -va[row0 + tid - 128];   // negated: the consumers start their accumulators from them
+      if (tid >= 192) f = -vb[row0 + tid - 192];
     }
   }
   __device__ __forceinline__ void stash(char* stage, int tid) const {
@@ -116,8 +143,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnParams 
   constexpr int NCB = C / 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * St::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const size_t base = (size_t)blockIdx.y * p.N;
-  const int i0 = blockIdx.x * 128 + wave * 32;
+  int sample, tile;
+  sample_and_tile(p.B, p.N / 128, sample, tile);
+  const size_t base = (size_t)sample * p.N;
+  const int i0 = tile * 128 + wave * 32;
   const uint16_t* Q = p.q + base * p.d;
   const uint16_t* V = p.v + base * C;
 
@@ -130,7 +159,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnParams 
   for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) acc[cb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  float m[2] = {-INFINITY, -INFINITY};
+  f32x4 accl[2] = {splat4(0.f), splat4(0.f)};        // sum_j p_ij, the same in every row of the block
+  const bf16x8 ones = ones8();
 
   St st;
   st.fetch(V, Q, nullptr, nullptr, 0, p.d, tid);
@@ -146,33 +177,33 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnParams 
     f32x4 s[4][2];
 #pragma unroll
     for (int jb = 0; jb < 4; jb++) {
-      const bf16x8 qa = g < 2 ? *reinterpret_cast<const bf16x8*>(qs + (jb * 16 + c16) * kNarrow + g * 16) : zero8();
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qs + (jb * 16 + c16) * kNarrow + (g & 1) * 16);   // g >= 2: any finite data, the other operand is zero there
 #pragma unroll
       for (int ib = 0; ib < 2; ib++)
         s[jb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfrag[ib], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) {
-      float mx = s[0][ib][0];
+      float mx = m[ib];                    // three-operand maxima: two scores per instruction
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) mx = fmaxf(mx, s[jb][ib][e]);
-      mx = xor_max(mx);
-      const float mn = fmaxf(m[ib], mx);
-      const float alpha = __expf(m[ib] - mn);
+      for (int jb = 0; jb < 4; jb++) {
+        mx = fmaxf(fmaxf(s[jb][ib][0], s[jb][ib][1]), mx);
+        mx = fmaxf(fmaxf(s[jb][ib][2], s[jb][ib][3]), mx);
+      }
+      const float mn = xor_max(mx);
+      const float alpha = __builtin_amdgcn_exp2f((m[ib] - mn) * kLog2e);
       m[ib] = mn;
-      float rs = 0.f;
+      // exp(s - mn) = exp2(s log2 e - mn log2 e): one multiply-add per score in front of the exponential; the row sums come
+      // from the matrix cores (a block of ones beside V^T), which add the probabilities as the product uses them
+      const f32x2 nb = {-mn * kLog2e, -mn * kLog2e}, sc = {kLog2e, kLog2e};
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const float pv = __expf(s[jb][ib][e] - mn);
-          s[jb][ib][e] = pv;
-          rs += pv;
-        }
-      l[ib] = l[ib] * alpha + rs;
+      for (int jb = 0; jb < 4; jb++) {
+        const f32x2 lo = exp2_pair(f32x2{s[jb][ib][0], s[jb][ib][1]} * sc + nb);
+        const f32x2 hi = exp2_pair(f32x2{s[jb][ib][2], s[jb][ib][3]} * sc + nb);
+        s[jb][ib] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
       if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {   // the running maximum rarely moves after the first blocks
+        accl[ib] *= alpha;
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) acc[cb][ib] *= alpha;
       }
@@ -190,13 +221,17 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnParams 
 #pragma unroll
         for (int ib = 0; ib < 2; ib++) acc[cb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qq][ib], acc[cb][ib], 0, 0, 0);
       }
+#pragma unroll
+    for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) accl[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qq][ib], accl[ib], 0, 0, 0);
     if (more) st.stash(smem + ((blk + 1) & 1) * St::STAGE, tid);
     __syncthreads();
   }
 
 #pragma unroll
   for (int ib = 0; ib < 2; ib++) {
-    const float ls = xor_sum(l[ib]);
+    const float ls = accl[ib][0];
     const float inv = 1.f / ls;
     const size_t row = base + i0 + ib * 16 + c16;
 #pragma unroll
@@ -228,13 +263,15 @@ __global__ __launch_bounds__(kThreads) void attn_delta_kernel(const uint16_t* o,
 
 // Owner: 128 columns j (32 per wave); walks the rows i in blocks of 64.  Produces dV and dQ.
 template <int C>
-__global__ __launch_bounds__(kThreads) void attn_bwd_dqv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dqv_kernel(const AttnParams p) {
   typedef Stager<C, true> St;
   constexpr int NCB = C / 16, NKS = C / 32;
   __shared__ __attribute__((aligned(16))) char smem[2 * St::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const size_t base = (size_t)blockIdx.y * p.N;
-  const int j0 = blockIdx.x * 128 + wave * 32;
+  int sample, tile;
+  sample_and_tile(p.B, p.N / 128, sample, tile);
+  const size_t base = (size_t)sample * p.N;
+  const int j0 = tile * 128 + wave * 32;
   const uint16_t* K = p.k + base * p.d;
   const uint16_t* dO = p.dout + base * C;
   const float* lse = p.lse + base;
@@ -271,24 +308,25 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dqv_kernel(const AttnParams
     f32x4 pm[4][2], ds[4][2];
 #pragma unroll
     for (int ib = 0; ib < 4; ib++) {
-      const bf16x8 ka = g < 2 ? *reinterpret_cast<const bf16x8*>(ks_ + (ib * 16 + c16) * kNarrow + g * 16) : zero8();
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(ks_ + (ib * 16 + c16) * kNarrow + (g & 1) * 16);  // g >= 2: any finite data, the other operand is zero there
       bf16x8 oa[NKS];
 #pragma unroll
       for (int ks = 0; ks < NKS; ks++) oa[ks] = *reinterpret_cast<const bf16x8*>(os + (ib * 16 + c16) * St::WROW + ks * 64 + g * 16);
-      const f32x4 li = *reinterpret_cast<const f32x4*>(ls + ib * 16 + 4 * g);
-      const f32x4 di = *reinterpret_cast<const f32x4*>(ls + kBlk + ib * 16 + 4 * g);
+      // -lse_i and -delta_i in the accumulator layout (row 4 g + e): the products start from them, so s - lse and
+      // dP - delta come out of the matrix cores
+      const f32x4 nli = *reinterpret_cast<const f32x4*>(ls + ib * 16 + 4 * g);
+      const f32x4 ndi = *reinterpret_cast<const f32x4*>(ls + kBlk + ib * 16 + 4 * g);
+      const f32x2 sc = {kLog2e, kLog2e};
 #pragma unroll
       for (int jb = 0; jb < 2; jb++) {
-        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qfrag[jb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qfrag[jb], nli, 0, 0, 0);
+        f32x4 dp = ndi;
 #pragma unroll
         for (int ks = 0; ks < NKS; ks++) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[ks], vfrag[jb][ks], dp, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const float pv = __expf(s[e] - li[e]);
-          pm[ib][jb][e] = pv;
-          ds[ib][jb][e] = pv * (dp[e] - di[e]);
-        }
+        const f32x2 p0 = exp2_pair(f32x2{s[0], s[1]} * sc), p1 = exp2_pair(f32x2{s[2], s[3]} * sc);
+        const f32x2 d0 = p0 * f32x2{dp[0], dp[1]}, d1 = p1 * f32x2{dp[2], dp[3]};
+        pm[ib][jb] = f32x4{p0[0], p0[1], p1[0], p1[1]};
+        ds[ib][jb] = f32x4{d0[0], d0[1], d1[0], d1[1]};
       }
     }
 #pragma unroll
@@ -324,13 +362,15 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dqv_kernel(const AttnParams
 
 // Owner: 128 rows i (32 per wave); walks the columns j in blocks of 64.  Produces dK.
 template <int C>
-__global__ __launch_bounds__(kThreads) void attn_bwd_dk_kernel(const AttnParams p) {
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dk_kernel(const AttnParams p) {
   typedef Stager<C, false> St;
   constexpr int NKS = C / 32;
   __shared__ __attribute__((aligned(16))) char smem[2 * St::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const size_t base = (size_t)blockIdx.y * p.N;
-  const int i0 = blockIdx.x * 128 + wave * 32;
+  int sample, tile;
+  sample_and_tile(p.B, p.N / 128, sample, tile);
+  const size_t base = (size_t)sample * p.N;
+  const int i0 = tile * 128 + wave * 32;
   const uint16_t* Q = p.q + base * p.d;
   const uint16_t* V = p.v + base * C;
 
@@ -342,8 +382,8 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dk_kernel(const AttnParams 
     kfrag[ib] = row_frag(p.k + base * p.d, i, p.d, 8 * g);
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) ofrag[ib][ks] = row_frag(p.dout + base * C, i, C, ks * 32 + 8 * g);
-    li[ib] = p.lse[base + i];
-    di[ib] = p.delta[base + i];
+    li[ib] = -p.lse[base + i];           // negated: the products below start from them
+    di[ib] = -p.delta[base + i];
   }
   f32x4 adk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
@@ -361,18 +401,19 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dk_kernel(const AttnParams 
     f32x4 ds[4][2];
 #pragma unroll
     for (int jb = 0; jb < 4; jb++) {
-      const bf16x8 qa = g < 2 ? *reinterpret_cast<const bf16x8*>(qs + (jb * 16 + c16) * kNarrow + g * 16) : zero8();
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qs + (jb * 16 + c16) * kNarrow + (g & 1) * 16);   // g >= 2: any finite data, the other operand is zero there
       bf16x8 va[NKS];
 #pragma unroll
       for (int ks = 0; ks < NKS; ks++) va[ks] = *reinterpret_cast<const bf16x8*>(vs + (jb * 16 + c16) * St::WROW + ks * 64 + g * 16);
 #pragma unroll
       for (int ib = 0; ib < 2; ib++) {
-        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfrag[ib], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfrag[ib], splat4(li[ib]), 0, 0, 0);     // s - lse_i
+        f32x4 dp = splat4(di[ib]);                                                                          // dP - delta_i
 #pragma unroll
         for (int ks = 0; ks < NKS; ks++) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[ks], ofrag[ib][ks], dp, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; e++) ds[jb][ib][e] = __expf(s[e] - li[ib]) * (dp[e] - di[ib]);
+        const f32x2 sc = {kLog2e, kLog2e};
+        const f32x2 d0 = exp2_pair(f32x2{s[0], s[1]} * sc) * f32x2{dp[0], dp[1]}, d1 = exp2_pair(f32x2{s[2], s[3]} * sc) * f32x2{dp[2], dp[3]};
+        ds[jb][ib] = f32x4{d0[0], d0[1], d1[0], d1[1]};
       }
     }
 #pragma unroll
@@ -391,8 +432,8 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dk_kernel(const AttnParams 
 }
 
 int check_shape(int64_t B, int32_t N, int32_t d, int32_t C, const void* const* ptrs, int n) {
-  if (B <= 0 || B > 65535 || N <= 0 || N % 128 != 0 || (d != 8 && d != 16) || (C != 64 && C != 128)) {
-    set_error("attention: supported are N %% 128 == 0, d in {8, 16}, C in {64, 128}, B <= 65535 (got B=%lld N=%d d=%d C=%d)", (long long)B, N, d, C);
+  if (B <= 0 || (int64_t)B * (N / 128) >= (1ll << 31) || N <= 0 || N % 128 != 0 || (d != 8 && d != 16) || (C != 64 && C != 128)) {
+    set_error("attention: supported are N %% 128 == 0, d in {8, 16}, C in {64, 128}, B * N / 128 < 2^31 (got B=%lld N=%d d=%d C=%d)", (long long)B, N, d, C);
     return GC_UNSUPPORTED_GEOMETRY;
   }
   for (int i = 0; i < n; i++)
@@ -414,10 +455,10 @@ extern "C" int gc_attention_fwd(const void* k, const void* q, const void* v, voi
   if (int e = check_shape(B, N, d, C, ptrs, 5)) return e;
   AttnParams p{};
   p.k = (const uint16_t*)k; p.q = (const uint16_t*)q; p.v = (const uint16_t*)v; p.out = (uint16_t*)out; p.lse = lse;
-  p.N = N; p.d = d; p.C = C;
+  p.B = B; p.N = N; p.d = d; p.C = C;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps("gc::attn_fwd_kernel", 2.0 * B * N * (double)N * (d + C), s);
-  const dim3 grid(N / 128, B);
+  const dim3 grid((unsigned)(N / 128) * (unsigned)B);
   if (C == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(kThreads), 0, s, p);
   else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(kThreads), 0, s, p);
   return check_hip(hipGetLastError(), "attn_fwd launch");
@@ -430,12 +471,12 @@ extern "C" int gc_attention_bwd(const void* k, const void* q, const void* v, con
   AttnParams p{};
   p.k = (const uint16_t*)k; p.q = (const uint16_t*)q; p.v = (const uint16_t*)v; p.o = (const uint16_t*)out; p.dout = (const uint16_t*)dout;
   p.dk = (uint16_t*)dk; p.dq = (uint16_t*)dq; p.dv = (uint16_t*)dv; p.lse = const_cast<float*>(lse); p.delta = delta;
-  p.N = N; p.d = d; p.C = C;
+  p.B = B; p.N = N; p.d = d; p.C = C;
   hipStream_t s = (hipStream_t)stream;
   const size_t rows = (size_t)B * N;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 16 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p.o, p.dout, delta, rows, C);
   if (check_hip(hipGetLastError(), "attn_delta launch")) return GC_HIP_ERROR;
-  const dim3 grid(N / 128, B);
+  const dim3 grid((unsigned)(N / 128) * (unsigned)B);
   {
     ProfScope ps("gc::attn_bwd_dqv_kernel", 2.0 * B * N * (double)N * (2 * d + 2 * C), s);
     if (C == 128) hipLaunchKernelGGL(attn_bwd_dqv_kernel<128>, grid, dim3(kThreads), 0, s, p);

@@ -1189,7 +1189,9 @@ def test_attention_against_unfused_product(gan, B, N, d, C):
     sr = torch.bmm(kr, qr.transpose(1, 2))
     outr = torch.bmm(torch.softmax(sr, dim=-1), vr)
     dkr, dqr, dvr = torch.autograd.grad(outr, (kr, qr, vr), go.cpu().double())
-    assert rel(lse, torch.logsumexp(sr, dim=-1)) < 1e-5
+    # lse is the logarithm of the sum of the probabilities AS THE SECOND PRODUCT USES THEM (rounded to bf16, added by the matrix
+    # cores): the output's weights then sum to one exactly; against the exact sum that is 2^-9 / sqrt(N) relative
+    assert rel(lse, torch.logsumexp(sr, dim=-1)) < 1e-4
     assert rel(out.float(), outr) < 6e-3
     assert rel(dv.float(), dvr) < 6e-3
     assert rel(dk.float(), dkr) < 1.5e-2
