@@ -51,5 +51,10 @@ def test_second_order_rounds_the_incoming_vector():
     gx, = torch.autograd.grad(y, x, gy, create_graph=True)
     u = torch.randn_like(gx)
     g_gy, g_w = torch.autograd.grad(gx, (gy, w), u)
-    assert torch.equal(g_gy, F.conv2d(r(u), r(w), None, 1, 1))
-    assert torch.equal(g_w, torch.nn.grad.conv2d_weight(r(u), w.shape, r(gy.detach()), 1, 1))
+    # The host library may add the products of these two in another order than the explicit formula does (one fp32
+    # rounding step, 1e-6); an operand left unrounded would show at 1e-2.
+    torch.testing.assert_close(g_gy, F.conv2d(r(u), r(w), None, 1, 1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g_w, torch.nn.grad.conv2d_weight(r(u), w.shape, r(gy.detach()), 1, 1),
+                               rtol=1e-5, atol=1e-5)
+    unrounded = torch.nn.grad.conv2d_weight(u, w.shape, gy.detach(), 1, 1)
+    assert (g_w - unrounded).abs().max() > 1e-3
