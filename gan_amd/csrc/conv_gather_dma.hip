@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
   // A wave alone on its SIMD issues one vector instruction every 4-5 cycles, so this part is written for instruction
   // count: full tiles with aligned rows (the common case) take a branch-free path, two 16-row blocks per 16-byte store.
   const int g = lane >> 4;
-  const bool stats = p.ch_sum != nullptr;
+  const bool stats = p.ch_sum != nullptr || p.stat_rows != nullptr;
   TOut* out = reinterpret_cast<TOut*>(p.out);
   const int oc_w = oc0 + wo * (TO / C::WO);          // first channel of this wave's rows
   const bool linear = p.tt.n_classes == 1 && p.b == 1;   // forward pass: output pixel index == GEMM column index
@@ -392,8 +392,13 @@ __global__ __launch_bounds__(NW * 64 * (WS ? 2 : 1)) void conv_gather_dma_kernel
         }
         const int oc = oc0 + oc_of_row(wo * (TO / C::WO) + i * 16 + g * 4) + r;
         if ((lane & 15) == 0 && oc < p.OC) {
-          atomicAdd(p.ch_sum + oc, s);
-          if (p.ch_sumsq != nullptr) atomicAdd(p.ch_sumsq + oc, q);
+          if (p.stat_rows != nullptr) {      // this wave's pixels of this tile are one row of the partial table
+            const size_t row = (size_t)pix_tile * C::WP + wp_;
+            *reinterpret_cast<float2*>(p.stat_rows + (row * (size_t)p.OC + oc) * 2) = float2{s, q};
+          } else {
+            atomicAdd(p.ch_sum + oc, s);
+            if (p.ch_sumsq != nullptr) atomicAdd(p.ch_sumsq + oc, q);
+          }
         }
       }
   }
@@ -413,8 +418,15 @@ static int launch_dma_one(const GatherParams& p, double flops, hipStream_t strea
   return check_hip(hipGetLastError(), "conv_gather_dma launch");
 }
 
-int launch_gather_dma(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t s) {
-  if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
+int launch_gather_dma(const GatherParams& p0, const GatherLaunch& l, bool out_f32, hipStream_t s) {
+  if (p0.n_pix_tiles == 0 || p0.n_oc_tiles == 0) return GC_OK;
+  GatherParams p = p0;
+  if (p.stat_rows != nullptr) {     // one row per consumer wave's pixel share of a tile; no rows when they do not fit the caller's table
+    const int nw = (l.to == 256 || l.tp == 256) ? 8 : 4;
+    const long rows = (long)p.n_pix_tiles * (nw / 2);
+    if (rows <= p.stat_cap) *p.stat_written = (int32_t)rows;
+    else p.stat_rows = nullptr;
+  }
   if (l.to == 256 && l.tp == 256) return out_f32 ? launch_dma_one<float, 256, 256, 2, 8>(p, l.flops, s) : launch_dma_one<uint16_t, 256, 256, 2, 8>(p, l.flops, s);
   if (l.to == 128 && l.tp == 256) return out_f32 ? launch_dma_one<float, 128, 256, 3, 8>(p, l.flops, s) : launch_dma_one<uint16_t, 128, 256, 3, 8>(p, l.flops, s);
   // At most one workgroup per CU: nothing else hides the load latency, so spend the idle LDS on a deeper ring.

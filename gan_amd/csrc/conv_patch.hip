@@ -301,6 +301,65 @@ __global__ __launch_bounds__(kNW * 64, 2) void conv_patch_kernel(const GatherPar
   }
   wait_vmcnt<0>();                       // the zero-filling tail loads target this workgroup's LDS: let them land
 
+  // ---- statistics rows (a BatchNorm behind this convolution): per 32-channel group the four pixel groups in turn, so that
+  // only 16 sums are live beside the accumulators; a row of the table is this wave's 64 pixels, summed over the 16 lanes
+  // that share a channel.  The planner grants rows only with 16-byte stores, whole rectangles and no mask.
+  if (!MASK && p.stat_rows != nullptr) {
+    TOut* out = reinterpret_cast<TOut*>(p.out);
+    const float ls = p.act == GC_ACT_NONE ? 1.f : (p.act == GC_ACT_RELU ? 0.f : p.slope);
+    const bool lean = p.act == GC_ACT_NONE || p.act == GC_ACT_RELU || p.act == GC_ACT_LRELU;
+    const size_t row = (size_t)pix_tile * kNW + wave;
+#pragma unroll
+    for (int m = 0; m < FO / 2; m++) {
+      const int oc = oc0 + 32 * m + 8 * g;
+      if (oc + 7 >= p.OC) continue;        // (OC is a multiple of 8 here: the lane's eight channels lie inside or outside)
+      f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (p.bias != nullptr) { b0 = *reinterpret_cast<const f32x4*>(p.bias + oc); b1 = *reinterpret_cast<const f32x4*>(p.bias + oc + 4); }
+      float ssum[8], ssq[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) ssum[r] = ssq[r] = 0.f;
+#pragma unroll
+      for (int pg = 0; pg < 4; pg++) {
+        const int oh = th_ * kTH + 2 * wave + (pg >> 1), ow = tw_ * kTW + (pg & 1) * 16 + c16;
+        const size_t pix = ((size_t)n * p.OH + (oh * p.b + p.tt.cls_ph[cls])) * p.OW + (ow * p.b + p.tt.cls_pw[cls]);
+        TOut* dst = out + pix * p.out_cstride + p.out_coff;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { v[r] = acc[2 * m][pg][r] + b0[r]; v[4 + r] = acc[2 * m + 1][pg][r] + b1[r]; }
+        if (lean) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r] * ls);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; r++) v[r] = apply_act(v[r], p.act, p.slope);
+        }
+        if (sizeof(TOut) == 4) {
+          *reinterpret_cast<f32x4*>(dst + oc) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst + oc + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          const u32x2 lo = cvt_bf16x4(f32x4{v[0], v[1], v[2], v[3]}), hi = cvt_bf16x4(f32x4{v[4], v[5], v[6], v[7]});
+          *reinterpret_cast<u32x4*>(dst + oc) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          const f32x4 w0 = widen_bf16x4(lo), w1 = widen_bf16x4(hi);      // statistics of the stored values
+#pragma unroll
+          for (int r = 0; r < 4; r++) { v[r] = w0[r]; v[4 + r] = w1[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) { ssum[r] += v[r]; ssq[r] += v[r] * v[r]; }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        float sm = ssum[r], sq = ssq[r];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          sm += __shfl_xor(sm, d, 64);
+          sq += __shfl_xor(sq, d, 64);
+        }
+        if (c16 == 0) *reinterpret_cast<float2*>(p.stat_rows + (row * (size_t)p.OC + oc + r) * 2) = float2{sm, sq};
+      }
+    }
+    return;
+  }
+
   // ---- epilogue: per (pixel group, group of 32 channels) a lane owns 8 consecutive channels of one pixel
   TOut* out = reinterpret_cast<TOut*>(p.out);
   const bool vec8 = p.out_vec8 != 0;
@@ -480,6 +539,12 @@ bool plan_patch(GatherParams& p, const GatherLaunch& l) {
 // Applies p.mask itself (and clears it) when the 16-byte store path holds for every lane; otherwise the caller's sweep does.
 int launch_patch(GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
   if (p.n_pix_tiles == 0 || p.n_oc_tiles == 0) return GC_OK;
+  if (p.stat_rows != nullptr) {          // one row per wave (64 pixels of a rectangle); no rows when the table is too small
+    const long rows = (long)p.n_pix_tiles * kNW;
+    const bool ok = p.mask == nullptr && p.out_vec8 && p.OC % 8 == 0 && p.pre_scale == nullptr && p.post_scale == nullptr && rows <= p.stat_cap;
+    if (ok) *p.stat_written = (int32_t)rows;
+    else p.stat_rows = nullptr;
+  }
   if (p.a == 2) {                        // strided mode; a mask, if any, stays with the caller's sweep
     if (patch_to(p) == 128) return out_f32 ? launch_one<float, 128, false, true>(p, l.flops, stream) : launch_one<uint16_t, 128, false, true>(p, l.flops, stream);
     return out_f32 ? launch_one<float, 64, false, true>(p, l.flops, stream) : launch_one<uint16_t, 64, false, true>(p, l.flops, stream);

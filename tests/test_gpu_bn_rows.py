@@ -56,12 +56,23 @@ CASES = [   # producer, Cin, Cout, N, H, storage of the activation
     ("conv", 64, 128, 16, 32, torch.float32),
     ("convT_first", 100, 512, 256, 1, torch.bfloat16),
     ("conv", 6, 64, 4, 64, torch.float32),
+    # the patch-resident kernel (8 x 32 rectangles: a row of the table per wave), plain, strided and over the four classes
+    # of a transposed convolution; large tiles of the LDS-DMA kernel
+    ("conv_s1", 128, 128, 32, 64, torch.bfloat16, "gc::conv_patch_kernel<unsigned short, 128, false>"),
+    ("conv_s1", 64, 64, 32, 64, torch.bfloat16, "gc::conv_patch_kernel<unsigned short, 64, false>"),
+    ("conv", 64, 128, 32, 128, torch.bfloat16, "gc::conv_patch_kernel<unsigned short, 128, false, strided>"),
+    ("convT", 128, 64, 32, 32, torch.bfloat16, "gc::conv_patch_kernel<unsigned short, 64, false>"),
+    ("convT", 256, 128, 32, 32, torch.bfloat16, "gc::conv_patch_kernel<unsigned short, 128, false>"),
+    ("conv_s1", 64, 72, 32, 64, torch.bfloat16, "gc::conv_patch_kernel<unsigned short, 64, false>"),      # a partial channel tile
+    ("conv", 256, 512, 64, 32, torch.bfloat16, None),
+    ("conv_s1", 512, 512, 32, 32, torch.bfloat16, None),
 ]
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_batchnorm_from_conv_rows_matches_own_sweep(gan, case):
-    kind, cin, cout, N, H, dt = case
+    kind, cin, cout, N, H, dt = case[:6]
+    expect_kernel = case[6] if len(case) > 6 else None
     net = _pair(gan, kind, cin, cout, dt)
     x = torch.randn(N, cin, H, H, device="cuda")
     if cin % 8 == 0:
@@ -72,6 +83,7 @@ def test_batchnorm_from_conv_rows_matches_own_sweep(gan, case):
     from_rows = {"gc::bn_rows_partial_kernel", "gc::bn_finalize_kernel<3>"}       # (few rows: the finalizing kernel reads them itself)
     assert "gc::bn_partial_kernel<0>" in names0 and not (from_rows & names0)
     assert (from_rows & names1) and "gc::bn_partial_kernel<0>" not in names1, sorted(names1)
+    assert expect_kernel is None or expect_kernel in names1, sorted(names1)
     tol = 2e-5 if dt == torch.float32 else 4e-3         # the statistics agree to rounding; bf16 storage rounds the output
     assert rel(y1, y0) < tol
     assert rel(gx1, gx0) < tol * 5
