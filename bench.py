@@ -121,6 +121,27 @@ def families(device, steps=8, only=None):
     return out
 
 
+_RESULT_FD = None
+
+
+def _claim_stdout():
+    """Keeps the process's standard output for the one JSON line: file descriptor 1 is pointed at standard error for
+    everything else (RCCL prints a version banner to standard output when its first communicator is created)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_RESULT_FD, (line + "\n").encode())
+
+
 def family_main(a, rank, local_rank, world):
     """bench.py --family NAME [--gpus N]: the training step of one of the other model families as the benchmarked step.  One
     rank: the step replayed as one HIP graph.  N ranks (torch.distributed.run): every rank runs the step eagerly on its own
@@ -178,8 +199,12 @@ def family_main(a, rank, local_rank, world):
         if dom:
             roofline = {"bound": "mfma", "kernel": dom["dominant_kernel"], "achieved": dom["dominant_kernel_tflops"], "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None, "launches": dom["dominant_kernel_launches"],
-                        "avg_launch_us": dom["dominant_kernel_avg_us"], "step_tflops": dom["step_tflops"]}
-        print(json.dumps({
+                        "avg_launch_us": dom["dominant_kernel_avg_us"], "step_tflops": dom["step_tflops"],
+                        "hbm_gb_s": _family_traffic(a.family, per),
+                        "all_kernels": {k: {"launches": v["launches"], "avg_us": 1e3 * v["total_ms"] / max(v["launches"], 1),
+                                            "tflops": v["flops"] / (v["total_ms"] * 1e-3) / 1e12 if v["total_ms"] > 0 else 0.0}
+                                        for k, v in prof.items()}}
+        _emit(json.dumps({
             "metric": "G+D train img/s", "value": world * step.batch * a.steps / dt, "unit": "img/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * per, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
@@ -187,7 +212,7 @@ def family_main(a, rank, local_rank, world):
                        "family": a.family, "global_batch": world * step.batch, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "gradient_all_reduce": "bucketed, started from autograd hooks during the last backward pass of a phase" if distributed else None,
                        "losses": losses, "losses_finite": all(x == x and abs(x) != float("inf") for x in losses)},
-            "roofline": roofline}), flush=True)
+            "roofline": roofline}))
     if distributed:
         dist.destroy_process_group()
 
@@ -229,6 +254,7 @@ def main():
             raise SystemExit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     torch.cuda.set_device(local_rank)
+    _claim_stdout()
     if a.family is not None:
         return family_main(a, rank, local_rank, world)
     import torch.distributed as dist
@@ -339,7 +365,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(threads)
             except Exception as e:  # the GPU number stands on its own
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
 

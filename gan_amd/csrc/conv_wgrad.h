@@ -19,6 +19,7 @@ struct WgradParams {
   int32_t y_elem;        // register-staged kernel, vector instantiation: the gy side still needs element loads (odd Cout)
   int32_t x_f32;         // 1: x is fp32 while gy is bf16 (the image-layer kernel rounds it in registers; nothing else takes the mix)
   int32_t image;         // 1: geometry of the image-layer kernel (conv_wgrad_image.hip); splits start on its 128-pixel rectangles
+  int32_t score;         // 1: planned for the one-output-channel kernel (conv_wgrad_score.hip): a split is a run of k_per_split image rows
   int32_t thin;          // 1: Cin <= 32; the tile's columns run over (tap, channel) jointly, channel padded to ICp
   int32_t ICp, icp_log2, ncols;   // thin mode: padded channels per tap, its log2, T * ICp
   int32_t n_tap_groups, tpt, cw_log2;   // LDS-DMA kernel: a 128-column tile holds tpt taps of (1 << cw_log2) channels
@@ -90,6 +91,8 @@ int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t s
 bool plan_wgrad_rows(WgradParams& p, const WgradLaunch& l, int n_seg, const int32_t* Ns);
 size_t wgrad_rows_workspace_cap();    // 0, or the calling thread's bound on the partial sums of the row-streaming plan
 int launch_wgrad_rows(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
+bool plan_wgrad_score(WgradParams& p, const WgradLaunch& l, bool operands_aligned);
+int launch_wgrad_score(const WgradParams& p, const WgradLaunch& l, hipStream_t stream);
 int launch_wgrad_reduce(const WgradReduceParams& p, hipStream_t stream);
 int launch_colsum(const void* gy, float* gb, int K, int C, int cstride, int coff, bool bf16, hipStream_t stream);
 

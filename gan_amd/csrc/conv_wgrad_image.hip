@@ -1,9 +1,11 @@
-// Weight gradient of the critics' first layer: Conv2d(<= 4 channels -> up to 64, kernel 4, stride 2, padding 1) on
-// 64-pixel-wide images (reference BasicGANs/models.py:52-56,77), bf16 operands.  3 MFLOP per sample against 270 KB of
+// Weight gradient of the critics' and the U-Net's first layer: Conv2d(<= 4 channels -> up to 64, kernel 4, stride 2,
+// padding 1) on images whose output width is a multiple of 32 (reference BasicGANs/models.py:52-56,77: 64-pixel-wide
+// images; Pix2Pix/models.py:8-20: 256-pixel-wide ones), bf16 operands.  3 MFLOP per sample against 270 KB of
 // gy and image: memory-bound, so gy and the image are each read once and the per-pixel instruction count is kept low
 // (the general thin-input kernel gathers every (tap, channel) element of its x tile with a 2-byte load of its own).
 //
-// A workgroup walks the rectangles (4 output rows x 32 = one 128-pixel run of the reduction index) of its split.  Per
+// A workgroup walks the rectangles (4 output rows x 32 columns = 128 values of the reduction index; units are numbered
+// sample-major, then rows of rectangles, then columns, and a split is a run of units) of its split.  Per
 // rectangle it stages, as the forward kernel of this layer does, the 10 x 66 input patch as channel-padded bf16 -- the 4
 // taps x 4 channels of one filter row are then 32 contiguous bytes per output pixel, so the x operand of an MFMA whose
 // reduction runs over 32 pixels is two transposing LDS reads straight from the patch, no im2col tile -- and the 128 x 64
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
   const TX* x = reinterpret_cast<const TX*>(rg.x);
   const uint16_t* gy = reinterpret_cast<const uint16_t*>(rg.gy);
   const int u0 = rg.kb0 / kUnit, u1 = rg.kend > rg.kb0 ? (rg.kend + kUnit - 1) / kUnit : u0;
-  const int units_per_sample = p.Ho / kTH;
+  const int tiles_w = p.Wo / kTW;
+  const int units_per_sample = (p.Ho / kTH) * tiles_w;
   const int ychunks = p.Cout / 8;                    // 16-byte chunks of a gy pixel
 
   // ---- what this thread loads per rectangle: 4 chunks of gy, up to 3 patch pixels.  The image values wait in registers as
@@ -59,19 +62,20 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
     ppc[i] = e - ppr[i] * kPW;
   }
   auto load_unit = [&](int u) {
-    const int n = u / units_per_sample, th = u - n * units_per_sample;
-    const size_t k0 = (size_t)u * kUnit;
+    const int n = u / units_per_sample, rem = u - n * units_per_sample, th = rem / tiles_w, tw = rem - th * tiles_w;
+    const size_t k0 = ((size_t)n * p.Ho + (size_t)th * kTH) * p.Wo + (size_t)tw * kTW;      // the rectangle's first output pixel
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int idx = t + i * kThreads, row = idx >> 3, ch = idx & 7;
+      const int idx = t + i * kThreads, row = idx >> 3, ch = idx & 7;       // row: pixel of the rectangle, 32 per output row
       yreg[i] = u32x4{0u, 0u, 0u, 0u};
-      if (ch < ychunks) yreg[i] = *reinterpret_cast<const u32x4*>(gy + (k0 + row) * p.y_cstride + p.y_coff + ch * 8);
+      if (ch < ychunks)
+        yreg[i] = *reinterpret_cast<const u32x4*>(gy + (k0 + (size_t)(row >> 5) * p.Wo + (row & 31)) * p.y_cstride + p.y_coff + ch * 8);
     }
     const TX* img = x + (size_t)n * p.H * p.W * p.Cin;
-    const int ih0 = 2 * kTH * th - 1;
+    const int ih0 = 2 * kTH * th - 1, iw0 = 2 * kTW * tw - 1;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const int ih = ih0 + ppr[i], iw = ppc[i] - 1;
+      const int ih = ih0 + ppr[i], iw = iw0 + ppc[i];
 #pragma unroll
       for (int c = 0; c < 4; c++) xraw[i][c] = (TX)0;
       if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
 
 }  // namespace
 
-// bf16 operands, dense image of at most 4 channels, 4 x 4 / stride 2 / padding 1, 32 output columns, output rows in
+// bf16 operands, dense image of at most 4 channels, 4 x 4 / stride 2 / padding 1, output columns in 32s, output rows in
 // fours, 16 / 32 / 48 / 64 output channels with 16-byte aligned gy pixels; splits that start on a rectangle.
 bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l) {
   if (!p.image || !l.bf16 || l.x3 || !l.aligned) return false;
@@ -179,7 +183,7 @@ bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l) {
 }
 
 bool wgrad_image_geometry(const WgradParams& p) {
-  return p.thin && p.Cin <= 4 && p.kh == 4 && p.kw == 4 && p.sh == 2 && p.sw == 2 && p.ph == 1 && p.pw == 1 && p.Wo == kTW &&
+  return p.thin && p.Cin <= 4 && p.kh == 4 && p.kw == 4 && p.sh == 2 && p.sw == 2 && p.ph == 1 && p.pw == 1 && p.Wo % kTW == 0 &&
          p.Ho % kTH == 0 && p.H == 2 * p.Ho && p.W == 2 * p.Wo && p.Cout % 16 == 0 && p.Cout <= 64 && p.x_cstride == p.Cin &&
          p.x_coff == 0 && (long)p.H * p.W * p.Cin < (1l << 31);
 }

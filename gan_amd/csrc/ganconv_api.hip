@@ -744,7 +744,7 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
   if (validate(d) != GC_OK) return 0;
   WgradParams p; WgradLaunch l;
   wgrad_setup(d, p, l, true);
-  plan_wgrad_rows(p, l, 1, &d->N);
+  if (!plan_wgrad_rows(p, l, 1, &d->N)) plan_wgrad_score(p, l, true);
   size_t need = wgrad_need(d, p);
   if (l.dma) {
     wgrad_setup(d, p, l, false);
@@ -789,6 +789,7 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
   wgrad_setup(d, p, l, al);
   const bool rows = plan_wgrad_rows(p, l, n_seg, Ns);
   if (!rows && n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
+  const bool score = !rows && n_seg == 1 && d->x_dtype == d->y_dtype && plan_wgrad_score(p, l, al);
   const size_t need = wgrad_need(d, p);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("%s: workspace of %zu bytes given, %zu needed", who, workspace_bytes, need);
@@ -824,6 +825,7 @@ static int wgrad_run(const gc_conv_desc* d, int32_t n_seg, const void* const* xs
   const bool bias_fused = gbias != nullptr && (rows || l.dma) && d->N > 0;
   if (bias_fused) p.bias_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + wgrad_weight_part_bytes(d, p));
   if (rows) rc = launch_wgrad_rows(p, l, (hipStream_t)stream);
+  else if (score) rc = launch_wgrad_score(p, l, (hipStream_t)stream);
   else rc = l.dma ? launch_wgrad_dma(p, l, (hipStream_t)stream) : launch_wgrad(p, l, (hipStream_t)stream);
   if (rc != GC_OK) return rc;
   WgradReduceParams r;
@@ -881,7 +883,10 @@ size_t gc_wgrad_multi_workspace_bytes(const gc_conv_desc* d, int32_t n_seg, cons
   for (int dma = 0; dma < 2; dma++) {      // the call knows the alignment, the query covers both plans
     WgradParams p; WgradLaunch l;
     wgrad_setup(&t, p, l, dma != 0);
-    if (!plan_wgrad_rows(p, l, n_seg, Ns) && n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
+    if (!plan_wgrad_rows(p, l, n_seg, Ns)) {
+      if (n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
+      else plan_wgrad_score(p, l, dma != 0);
+    }
     const size_t b = wgrad_need(&t, p);
     if (b > need) need = b;
   }

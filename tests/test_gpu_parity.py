@@ -1737,15 +1737,16 @@ def test_split_reduction_of_small_outputs_is_exact_on_small_integers(gan, case):
     assert torch.equal(y, y2)
 
 
-@pytest.mark.parametrize("cin,cout,N", [(3, 64, 8), (1, 16, 5), (4, 48, 3), (3, 32, 16)])
-def test_image_layer_weight_gradient_is_exact_on_small_integers(gan, cin, cout, N):
-    """The weight-gradient kernel of the critics' first layer (<= 4 channels -> <= 64, 4 x 4 / stride 2 / padding 1, 64-pixel
-    wide images, bf16 operands): on small integers every sum is exact, so it must equal torch's CPU gradient bit for bit,
-    alone and as two segments of one launch."""
+@pytest.mark.parametrize("cin,cout,N,H,W", [(3, 64, 8, 64, 64), (1, 16, 5, 64, 64), (4, 48, 3, 64, 64), (3, 32, 16, 64, 64),
+                                            (3, 64, 5, 256, 256), (3, 64, 6, 24, 128), (2, 16, 7, 8, 192)])
+def test_image_layer_weight_gradient_is_exact_on_small_integers(gan, cin, cout, N, H, W):
+    """The weight-gradient kernel of the critics' and the U-Net's first layer (<= 4 channels -> <= 64, 4 x 4 / stride 2 /
+    padding 1, output widths in 32s and heights in fours, bf16 operands): on small integers every sum is exact, so it must
+    equal torch's CPU gradient bit for bit, alone and as two segments of one launch."""
     from gan_amd import ops, _lib
     g = torch.Generator().manual_seed(23 + cin)
-    x = torch.randint(-2, 3, (N, cin, 64, 64), generator=g).float()
-    gy = torch.randint(-2, 3, (N, cout, 32, 32), generator=g).float()
+    x = torch.randint(-2, 3, (N, cin, H, W), generator=g).float()
+    gy = torch.randint(-2, 3, (N, cout, H // 2, W // 2), generator=g).float()
     xr = x.double().requires_grad_(False)
     w = torch.zeros(cout, cin, 4, 4, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv2d(xr, w, None, 2, 1).backward(gy.double())
@@ -1771,6 +1772,33 @@ def test_image_layer_weight_gradient_is_exact_on_small_integers(gan, cin, cout, 
     _lib.profile_enable(False)
     assert "gc::conv_wgrad_image_kernel" in names and not any("copy" in n for n in names), sorted(names)
     assert torch.equal(gw2.double().cpu(), w.grad)
+
+
+@pytest.mark.parametrize("N,cin,H,W,k,pad", [(3, 512, 31, 31, 4, 1), (37, 512, 4, 4, 4, 0), (5, 128, 16, 24, 3, 1), (2, 640, 9, 7, 4, 2),
+                                            (4, 256, 12, 12, 2, 0), (600, 512, 4, 4, 4, 0)])
+def test_score_layer_weight_gradient_is_exact_on_small_integers(gan, N, cin, H, W, k, pad):
+    """The weight-gradient kernel for one output channel and a small stride-1 filter (the PatchGAN's and the critics' score
+    layers): x is read once, pixel by pixel.  On small integers every sum is exact: bit for bit torch's CPU gradient, with
+    the bias gradient beside it, and the same bits on a second call."""
+    from gan_amd import ops, _lib
+    g = torch.Generator().manual_seed(41 + cin + H)
+    x = torch.randint(-2, 3, (N, cin, H, W), generator=g).float()
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    gy = torch.randint(-2, 3, (N, 1, Ho, Wo), generator=g).float()
+    w = torch.zeros(1, cin, k, k, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), w, None, 1, pad).backward(gy.double())
+    xb = x.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gb = gy.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    _lib.profile_enable(True)
+    gw = ops.conv_wgrad(xb, gb, k, k, 1, pad, _lib.GC_PREC_BF16)
+    torch.cuda.synchronize()
+    names = set(_lib.profile_collect())
+    _lib.profile_enable(False)
+    assert "gc::conv_wgrad_score_kernel" in names, sorted(names)
+    assert torch.equal(gw.double().cpu(), w.grad)
+    gw2, gbias = ops.conv_wgrad_bias(xb, gb, k, k, 1, pad, _lib.GC_PREC_BF16)
+    assert torch.equal(gw2, gw)
+    assert torch.equal(gbias.double().cpu(), gy.double().sum((0, 2, 3)))
 
 
 @pytest.mark.parametrize("cin,cout,hw,dt", [(512, 1, 4, torch.bfloat16), (512, 1, 4, torch.float32), (128, 3, 2, torch.bfloat16),
