@@ -21,7 +21,8 @@ namespace {
 
 constexpr int kTH = 4, kTW = 32, kUnit = kTH * kTW;      // output rectangle = 128 consecutive values of the reduction index
 constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
-constexpr int kPatchBytes = kPH * kPW * 8, kGyBytes = kUnit * 128;
+constexpr int kGyBytes = kUnit * 128;
+constexpr int patch_bytes(int icp) { return kPH * kPW * 2 * icp; }
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -36,8 +37,12 @@ __device__ __forceinline__ bf16x8 read_tr(const char* a0, int second_offset) {
 }
 
 // TX: storage type of the image (uint16_t = bf16, float: rounded to bf16 on the way into the patch)
-template <typename TX>
+// ICP: channels of a patch pixel (4, or 8 for 5 to 8 input channels -- the PatchGAN's image pair, Pix2Pix/models.py:225-232: the
+// 4 taps x 8 channels of a filter row are then two blocks of 16 columns, twice the MFMAs and accumulators)
+template <typename TX, int ICP>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradParams p) {
+  constexpr int kPatchBytes = patch_bytes(ICP);
+  constexpr int NH = ICP / 4;                          // 16-column blocks per filter row
   __shared__ __attribute__((aligned(16))) char smem[2 * (kPatchBytes + kGyBytes)];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int split = blockIdx.x;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
   // loaded and are rounded to bf16 on their way into LDS, after the multiplications of the rectangle before: a conversion
   // next to its load would put a wait for that load in front of the next load, three memory latencies in a row per rectangle.
   u32x4 yreg[4];
-  TX xraw[3][4];
+  TX xraw[3][ICP];
   int ppr[3], ppc[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -77,13 +82,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
     for (int i = 0; i < 3; i++) {
       const int ih = ih0 + ppr[i], iw = iw0 + ppc[i];
 #pragma unroll
-      for (int c = 0; c < 4; c++) xraw[i][c] = (TX)0;
+      for (int c = 0; c < ICP; c++) xraw[i][c] = (TX)0;
       if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
         const TX* src = img + (uint32_t)((ih * p.W + iw) * p.Cin);
         xraw[i][0] = src[0];
-        if (p.Cin > 1) xraw[i][1] = src[1];
-        if (p.Cin > 2) xraw[i][2] = src[2];
-        if (p.Cin > 3) xraw[i][3] = src[3];
+#pragma unroll
+        for (int c = 1; c < ICP; c++)
+          if (p.Cin > c) xraw[i][c] = src[c];
       }
     }
   };
@@ -98,16 +103,21 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
     auto bits = [](TX v) -> uint32_t { return sizeof(TX) == 2 ? (uint32_t)v : (uint32_t)float_to_bf16_bits((float)v); };
 #pragma unroll
     for (int i = 0; i < 3; i++)
-      if (t + i * kThreads < kPH * kPW)
-        *reinterpret_cast<u32x2*>(pb + (t + i * kThreads) * 8) =
-            u32x2{bits(xraw[i][0]) | (bits(xraw[i][1]) << 16), bits(xraw[i][2]) | (bits(xraw[i][3]) << 16)};
+      if (t + i * kThreads < kPH * kPW) {
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+          *reinterpret_cast<u32x2*>(pb + (t + i * kThreads) * (2 * ICP) + 8 * h) =
+              u32x2{bits(xraw[i][4 * h]) | (bits(xraw[i][4 * h + 1]) << 16), bits(xraw[i][4 * h + 2]) | (bits(xraw[i][4 * h + 3]) << 16)};
+      }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][4][NH];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) acc[i][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int h = 0; h < NH; h++) acc[i][r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // transposing read: lane (g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3) addresses row 8g + q (and + 4), columns
   // 4pp .. 4pp + 3 of a 16-column block and receives, for column lane & 15, the rows 8g .. 8g + 7
@@ -125,57 +135,69 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
     if (more) load_unit(u + 1);
     const char* pb = smem + buf * (kPatchBytes + kGyBytes);
     const char* yb = pb + kPatchBytes;
-    bf16x8 a[4], b[4];
+    bf16x8 a[4], b[4][NH];
     const int yrow = wave * kTW + k0;
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (i < co_blocks) a[i] = read_tr(yb + yrow * 128 + ((i ^ gy_swz(k0)) << 5) + pp8, 4 * 128);
+    // output pixel k of the row meets the patch pixels 2k .. 2k + 3 of filter row r: 4 taps x ICP channels, contiguous
 #pragma unroll
-    for (int r = 0; r < 4; r++) b[r] = read_tr(pb + ((2 * wave + r) * kPW + 2 * k0) * 8 + pp8, 4 * 16);
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int h = 0; h < NH; h++) b[r][h] = read_tr(pb + ((2 * wave + r) * kPW + 2 * k0) * (2 * ICP) + 32 * h + pp8, 4 * 4 * ICP);
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (i < co_blocks)
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[i][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[r], acc[i][r], 0, 0, 0);
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int h = 0; h < NH; h++) acc[i][r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[r][h], acc[i][r][h], 0, 0, 0);
     if (more) store_unit(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- the four waves' tiles -> one: waves 2, 3 hand theirs to waves 0, 1, then wave 1 to wave 0
+  // ---- the four waves' tiles -> one: waves 2, 3 hand theirs to waves 0, 1, then wave 1 to wave 0 (one column block at a time)
   float* red = reinterpret_cast<float*>(smem);          // two slots of 16 fragments x 64 lanes x 4 floats (16 KB each)
-  auto slot_io = [&](int slot, bool write) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+  for (int h = 0; h < NH; h++) {
+    auto slot_io = [&](int slot, bool write) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        f32x4* q = reinterpret_cast<f32x4*>(red + ((size_t)slot * 16 + i * 4 + r) * 256 + lane * 4);
-        if (write) *q = acc[i][r];
-        else acc[i][r] += *q;
-      }
-  };
-  if (wave >= 2) slot_io(wave - 2, true);
-  __syncthreads();
-  if (wave < 2) slot_io(wave, false);
-  __syncthreads();
-  if (wave == 1) slot_io(0, true);
-  __syncthreads();
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          f32x4* q = reinterpret_cast<f32x4*>(red + ((size_t)slot * 16 + i * 4 + r) * 256 + lane * 4);
+          if (write) *q = acc[i][r][h];
+          else acc[i][r][h] += *q;
+        }
+    };
+    if (h > 0) __syncthreads();                           // the slots of the block before have been read
+    if (wave >= 2) slot_io(wave - 2, true);
+    __syncthreads();
+    if (wave < 2) slot_io(wave, false);
+    __syncthreads();
+    if (wave == 1) slot_io(0, true);
+    __syncthreads();
+    if (wave == 0) slot_io(0, false);
+  }
   if (wave != 0) return;
-  slot_io(0, false);
-  float* part = p.part + (size_t)split * p.Cout * 64;
+  // [split][Cout][tap][ICP]: column (lane & 15) of block h of filter row r is tap 4 r + (16 h + column) / ICP, channel column % ICP
+  float* part = p.part + (size_t)split * p.Cout * (16 * ICP);
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int co = i * 16 + (lane >> 4) * 4 + e;
-        if (co < p.Cout) part[(size_t)co * 64 + r * 16 + (lane & 15)] = acc[i][r][e];
-      }
+      for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int co = i * 16 + (lane >> 4) * 4 + e;
+          if (co < p.Cout) part[(size_t)co * (16 * ICP) + r * (4 * ICP) + h * 16 + (lane & 15)] = acc[i][r][h][e];
+        }
 }
 
 }  // namespace
 
-// bf16 operands, dense image of at most 4 channels, 4 x 4 / stride 2 / padding 1, output columns in 32s, output rows in
+// bf16 operands, dense image of at most 8 channels, 4 x 4 / stride 2 / padding 1, output columns in 32s, output rows in
 // fours, 16 / 32 / 48 / 64 output channels with 16-byte aligned gy pixels; splits that start on a rectangle.
 bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l) {
   if (!p.image || !l.bf16 || l.x3 || !l.aligned) return false;
@@ -183,7 +205,7 @@ bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l) {
 }
 
 bool wgrad_image_geometry(const WgradParams& p) {
-  return p.thin && p.Cin <= 4 && p.kh == 4 && p.kw == 4 && p.sh == 2 && p.sw == 2 && p.ph == 1 && p.pw == 1 && p.Wo % kTW == 0 &&
+  return p.thin && p.Cin <= 8 && p.kh == 4 && p.kw == 4 && p.sh == 2 && p.sw == 2 && p.ph == 1 && p.pw == 1 && p.Wo % kTW == 0 &&
          p.Ho % kTH == 0 && p.H == 2 * p.Ho && p.W == 2 * p.Wo && p.Cout % 16 == 0 && p.Cout <= 64 && p.x_cstride == p.Cin &&
          p.x_coff == 0 && (long)p.H * p.W * p.Cin < (1l << 31);
 }
@@ -191,8 +213,14 @@ bool wgrad_image_geometry(const WgradParams& p) {
 int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t stream) {
   if (p.K <= 0 || p.splits <= 0) return GC_OK;
   ProfScope ps("gc::conv_wgrad_image_kernel", l.flops, stream);
-  if (p.x_f32) hipLaunchKernelGGL(conv_wgrad_image_kernel<float>, dim3((unsigned)p.splits), dim3(kThreads), 0, stream, p);
-  else hipLaunchKernelGGL(conv_wgrad_image_kernel<uint16_t>, dim3((unsigned)p.splits), dim3(kThreads), 0, stream, p);
+  const dim3 grid((unsigned)p.splits), block(kThreads);
+  if (p.ICp == 8) {
+    if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 8>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 8>), grid, block, 0, stream, p);
+  } else {
+    if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 4>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 4>), grid, block, 0, stream, p);
+  }
   return check_hip(hipGetLastError(), "conv_wgrad_image launch");
 }
 

@@ -726,7 +726,7 @@ def _image_layer(x, gy, geom, precision):
         return False
     kh, kw, stride, padding = geom
     (_, Cin, H, W), (_, Cout, Ho, Wo) = x.shape, gy.shape
-    return (Cin <= 4 and kh == 4 and kw == 4 and stride == 2 and padding == 1 and Wo % 32 == 0 and Ho % 4 == 0 and H == 2 * Ho and W == 2 * Wo
+    return (Cin <= 8 and kh == 4 and kw == 4 and stride == 2 and padding == 1 and Wo % 32 == 0 and Ho % 4 == 0 and H == 2 * Ho and W == 2 * Wo
             and Cout % 16 == 0 and Cout <= 64)
 
 

@@ -1738,9 +1738,10 @@ def test_split_reduction_of_small_outputs_is_exact_on_small_integers(gan, case):
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W", [(3, 64, 8, 64, 64), (1, 16, 5, 64, 64), (4, 48, 3, 64, 64), (3, 32, 16, 64, 64),
-                                            (3, 64, 5, 256, 256), (3, 64, 6, 24, 128), (2, 16, 7, 8, 192)])
+                                            (3, 64, 5, 256, 256), (3, 64, 6, 24, 128), (2, 16, 7, 8, 192),
+                                            (6, 64, 5, 256, 256), (8, 48, 6, 64, 64), (5, 16, 7, 8, 192), (7, 32, 3, 64, 64)])
 def test_image_layer_weight_gradient_is_exact_on_small_integers(gan, cin, cout, N, H, W):
-    """The weight-gradient kernel of the critics' and the U-Net's first layer (<= 4 channels -> <= 64, 4 x 4 / stride 2 /
+    """The weight-gradient kernel of the critics' and the U-Net's first layer (<= 8 channels -> <= 64, 4 x 4 / stride 2 /
     padding 1, output widths in 32s and heights in fours, bf16 operands): on small integers every sum is exact, so it must
     equal torch's CPU gradient bit for bit, alone and as two segments of one launch."""
     from gan_amd import ops, _lib
