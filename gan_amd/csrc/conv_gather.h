@@ -91,6 +91,9 @@ int launch_point(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
 // the gradient mask itself.
 bool plan_outer(const GatherParams& p, const GatherLaunch& l);
 int launch_outer(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
+// One input channel, many output channels, one class of up to 16 taps (the data gradient of a sliding-window score layer).
+bool plan_spread(const GatherParams& p, const GatherLaunch& l);
+int launch_spread(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 // Patch-resident kernel (stride-1 gathers with >= 4 taps per class on large images, see conv_patch.hip); plan_patch
 // rewrites the tile bookkeeping in p when it accepts.

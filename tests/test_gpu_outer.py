@@ -88,3 +88,31 @@ def test_patch_score_map_on_the_few_channel_kernel(gan, cin, cout, hw, N):
     y, names = _names(gan, lambda: gan.functional.conv2d(xg, w.cuda(), b.cuda(), 1, 1, out_dtype=torch.float32))
     assert any("conv_scatter_kernel" in n for n in names), sorted(names)
     assert torch.equal(y.double().cpu(), want)
+
+
+@pytest.mark.parametrize("cin,H,W,k,pad,N,dt", [(512, 31, 31, 4, 1, 5, torch.bfloat16), (512, 31, 31, 4, 1, 3, torch.float32),
+                                                (64, 16, 24, 3, 1, 4, torch.bfloat16), (640, 9, 7, 4, 2, 2, torch.bfloat16),
+                                                (128, 12, 12, 2, 0, 3, torch.bfloat16)])
+def test_sliding_score_layer_data_gradient(gan, cin, H, W, k, pad, N, dt):
+    """The data gradient of a score layer that slides over the map (the PatchGAN's Conv2d(512 -> 1, kernel 4, stride 1,
+    padding 1), Pix2Pix/models.py:238): one input channel spread over many output channels (gc::conv_spread_kernel).  Small
+    integers: every sum is exact, so the result equals torch's CPU gradient bit for bit."""
+    g = torch.Generator().manual_seed(63 + cin)
+    x = torch.randint(-2, 3, (N, cin, H, W), generator=g).float()
+    w = torch.randint(-1, 2, (1, cin, k, k), generator=g).float()
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    gy = torch.randint(-3, 4, (N, 1, Ho, Wo), generator=g).float()
+    xr = x.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w.double(), None, 1, pad).backward(gy.double())
+    xg = x.cuda().to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = gan.functional.conv2d(xg, w.cuda(), None, 1, pad, out_dtype=torch.float32)
+    (gx,), names = _names(gan, lambda: torch.autograd.grad(y, (xg,), gy.cuda()))
+    assert "gc::conv_spread_kernel" in names, sorted(names)
+    assert gx.dtype == dt and torch.equal(gx.double().cpu(), xr.grad)
+    # the same kernel as the forward pass of a transposed convolution of a one-channel map, with bias and LeakyReLU
+    b = torch.randint(-2, 3, (cin,), generator=g).float()
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv_transpose2d(gy.double(), w.double(), b.double(), 1, pad), 0.25)
+    (out,), names = _names(gan, lambda: (gan.functional.conv_transpose2d(gy.cuda().contiguous(memory_format=torch.channels_last), w.cuda(), b.cuda(), 1, pad,
+                                                                          activation="leaky_relu", negative_slope=0.25, out_dtype=torch.float32),))
+    assert "gc::conv_spread_kernel" in names, sorted(names)
+    assert torch.equal(out.double().cpu(), want)
