@@ -19,14 +19,15 @@ namespace {
 constexpr int kTW = 16;               // class-local output rectangle of a workgroup: TH (8, or 4 where the halo of a 4 x 4
                                      // filter makes the patch of 8 rows too large) x 16
 constexpr int kMaxPatch = 192;       // patch pixels (rows of the staged input tile)
-constexpr int kMaxRows = 64;         // (tap, oc) pairs
+constexpr int kMaxRows = 96;         // (tap, oc) pairs (64 in the MR = 4 build, 96 in the MR = 6 one: 16 taps x 6 channels)
 constexpr int kPStride = 196;        // floats per row of P: 4 * 196 = 16 (mod 64) keeps the fragment stores conflict-free
 
 __device__ __forceinline__ int sswz(int row) { return (row >> 1) & 7; }
 
 }  // namespace
 
-template <typename TIn, typename TOut, int TH>
+// MR: 16-row fragments of (tap, channel) pairs the build holds (4: up to 64 pairs, 6: up to 96)
+template <typename TIn, typename TOut, int TH, int MR = 4>
 __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherParams p) {
   constexpr int kTH = TH;
   constexpr int EPC = 16 / (int)sizeof(TIn);          // elements per 16-byte source chunk
@@ -54,9 +55,9 @@ __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherPara
   if (t < kMaxTaps) tap_e[t] = ((int)p.tt.dh[t] & 0xff) | (((int)p.tt.dw[t] & 0xff) << 8) | ((int)p.tt.wtap[t] << 16);
   if (t <= kMaxClasses) cls_start[t] = p.tt.cls_tap_start[t];
 
-  f32x4 acc[4][3];
+  f32x4 acc[MR][3];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MR; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherPara
       reg[i] = u32x4{0u, 0u, 0u, 0u};
       if (ok) reg[i] = *reinterpret_cast<const u32x4*>(in + (((size_t)n * p.IH + ih) * p.IW + iw) * p.in_cstride + p.in_coff + c);
     }
-    u32x4 wreg[2];
+    u32x4 wreg[MR / 2];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < MR / 2; i++) {
       const int idx = t + kThreads * i;
       const int row = idx >> 3, ch = idx & 7;
       wreg[i] = u32x4{0u, 0u, 0u, 0u};
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherPara
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < MR / 2; i++) {
       const int idx = t + kThreads * i;
       const int row = idx >> 3, ch = idx & 7;
       *reinterpret_cast<u32x4*>(wts + row * 128 + ((ch ^ sswz(row)) << 4)) = wreg[i];
@@ -108,9 +109,9 @@ __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherPara
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const int kc = ks * 4 + (lane >> 4);
-      bf16x8 a[4], b[3];
+      bf16x8 a[MR], b[3];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < MR; i++) {
         const int row = i * 16 + (lane & 15);
         a[i] = *reinterpret_cast<const bf16x8*>(wts + row * 128 + ((kc ^ sswz(row)) << 4));
       }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherPara
         b[j] = *reinterpret_cast<const bf16x8*>(xin + row * 128 + ((kc ^ sswz(row)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < MR; i++)
         if (i < RF)
 #pragma unroll
           for (int j = 0; j < 3; j++)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void conv_scatter_kernel(const GatherPara
   }
   __syncthreads();   // all fragment reads done: P may overwrite the tiles
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MR; i++)
     if (i < RF)
 #pragma unroll
       for (int j = 0; j < 3; j++)
@@ -200,7 +201,10 @@ static int launch_scatter_one(const GatherParams& p, double flops, hipStream_t s
   const int rows16 = (p.T * p.OC + 15) / 16 * 16;
   int smem = rows16 * kPStride * 4;
   if (smem < (kMaxPatch + kMaxRows) * 128) smem = (kMaxPatch + kMaxRows) * 128;
-  auto kern = p.sc_th == 8 ? conv_scatter_kernel<TIn, TOut, 8> : conv_scatter_kernel<TIn, TOut, 4>;
+  const bool wide = rows16 > 64;
+  auto kern = wide ? (p.sc_th == 8 ? conv_scatter_kernel<TIn, TOut, 8, 6> : conv_scatter_kernel<TIn, TOut, 4, 6>)
+                   : (p.sc_th == 8 ? conv_scatter_kernel<TIn, TOut, 8, 4> : conv_scatter_kernel<TIn, TOut, 4, 4>);
+  if (smem > 64 * 1024 && ensure_dynamic_smem(reinterpret_cast<const void*>(kern), smem) != GC_OK) return GC_HIP_ERROR;
   char name[96];
   snprintf(name, sizeof(name), "gc::conv_scatter_kernel<%s, %s>", sizeof(TIn) == 4 ? "float" : "unsigned short",
            sizeof(TOut) == 4 ? "float" : "unsigned short");

@@ -75,7 +75,7 @@ def test_transposed_convolution_of_one_value_per_sample(gan, stride, pad, k):
     assert y.shape == want.shape and torch.equal(y.double().cpu(), want)
 
 
-@pytest.mark.parametrize("cin,cout,hw,N", [(512, 1, 31, 8), (256, 2, 24, 3), (64, 3, 33, 2)])
+@pytest.mark.parametrize("cin,cout,hw,N", [(512, 1, 31, 8), (256, 2, 24, 3), (64, 3, 33, 2), (128, 6, 20, 3), (64, 5, 33, 2)])
 def test_patch_score_map_on_the_few_channel_kernel(gan, cin, cout, hw, N):
     """The last layer of the PatchGAN discriminator, Conv2d(512 -> 1, kernel 4, stride 1, padding 1) on 31 x 31 maps
     (Pix2Pix/models.py:221-243): the halo of a 4 x 4 filter needs the few-output-channel kernel's 4-row rectangles."""
@@ -116,3 +116,21 @@ def test_sliding_score_layer_data_gradient(gan, cin, H, W, k, pad, N, dt):
                                                                           activation="leaky_relu", negative_slope=0.25, out_dtype=torch.float32),))
     assert "gc::conv_spread_kernel" in names, sorted(names)
     assert torch.equal(out.double().cpu(), want)
+
+
+@pytest.mark.parametrize("cimg,cmid,hw,N,dt", [(6, 64, 64, 3, torch.bfloat16), (3, 64, 64, 2, torch.bfloat16), (6, 128, 32, 2, torch.float32)])
+def test_image_pair_data_gradient_on_the_few_channel_kernel(gan, cimg, cmid, hw, N, dt):
+    """The data gradient of the PatchGAN's first layer, Conv2d(6 -> 64, kernel 4, stride 2, padding 1) on the image pair
+    (Pix2Pix/models.py:225-232): 16 taps x 6 channels = 96 (tap, channel) pairs on the few-output-channel kernel.  Small
+    integers: bit for bit torch's CPU gradient."""
+    g = torch.Generator().manual_seed(65 + cimg)
+    x = torch.randint(-2, 3, (N, cimg, hw, hw), generator=g).float()
+    w = torch.randint(-1, 2, (cmid, cimg, 4, 4), generator=g).float()
+    gy = torch.randint(-2, 3, (N, cmid, hw // 2, hw // 2), generator=g).float()
+    xr = x.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, w.double(), None, 2, 1).backward(gy.double())
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = gan.functional.conv2d(xg, w.cuda(), None, 2, 1, out_dtype=dt)
+    (gx,), names = _names(gan, lambda: torch.autograd.grad(y, (xg,), gy.cuda().to(dt)))
+    assert any("conv_scatter_kernel" in n for n in names), sorted(names)
+    assert torch.equal(gx.double().cpu(), xr.grad)
