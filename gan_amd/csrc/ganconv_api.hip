@@ -745,8 +745,14 @@ size_t gc_wgrad_workspace_bytes(const gc_conv_desc* d) {
   if (validate(d) != GC_OK) return 0;
   WgradParams p; WgradLaunch l;
   wgrad_setup(d, p, l, true);
-  if (!plan_wgrad_rows(p, l, 1, &d->N)) plan_wgrad_score(p, l, true);
   size_t need = wgrad_need(d, p);
+  {   // the plans that replace the tiled one when their geometry (and the call's alignment) holds
+    WgradParams q = p;
+    if (plan_wgrad_rows(q, l, 1, &d->N) || plan_wgrad_score(q, l, true)) {
+      const size_t other = wgrad_need(d, q);
+      if (other > need) need = other;
+    }
+  }
   if (l.dma) {
     wgrad_setup(d, p, l, false);
     const size_t other = wgrad_need(d, p);
@@ -884,12 +890,11 @@ size_t gc_wgrad_multi_workspace_bytes(const gc_conv_desc* d, int32_t n_seg, cons
   for (int dma = 0; dma < 2; dma++) {      // the call knows the alignment, the query covers both plans
     WgradParams p; WgradLaunch l;
     wgrad_setup(&t, p, l, dma != 0);
-    if (!plan_wgrad_rows(p, l, n_seg, Ns)) {
-      if (n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
-      else plan_wgrad_score(p, l, dma != 0);
-    }
-    const size_t b = wgrad_need(&t, p);
+    WgradParams q = p;
+    if (!plan_wgrad_rows(p, l, n_seg, Ns) && n_seg > 1) wgrad_split_segments(p, n_seg, Ns, d->Ho * d->Wo);
+    size_t b = wgrad_need(&t, p);
     if (b > need) need = b;
+    if (n_seg == 1 && plan_wgrad_score(q, l, dma != 0) && (b = wgrad_need(&t, q)) > need) need = b;
   }
   return need;
 }
