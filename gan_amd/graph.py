@@ -23,7 +23,7 @@ from . import ops
 
 
 class GraphedStep:
-    def __init__(self, step, warmup=2):
+    def __init__(self, step, warmup=2, keep_weight_images=True):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -33,7 +33,11 @@ class GraphedStep:
         torch.cuda.synchronize()
         # Packed weight images and bf16 operand copies made during the warm-up must not be found by the recording: their
         # producer kernels would be missing from the graph and replays would keep reading the values of this moment.
-        ops.clear_weight_cache()
+        # Exception: a step whose optimizers refresh every cached image right after they move the weights
+        # (Adam.repack_after_step; the step says so): the images of the warm-up are current when the recording starts and the
+        # recorded refresh launches keep them current in every replay, so the per-layer pack launches stay out of the graph.
+        if not (keep_weight_images and getattr(step, "weight_images_refreshed_in_step", False)):
+            ops.clear_weight_cache()
         ops.clear_cast_cache()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), ops.capturing_on():

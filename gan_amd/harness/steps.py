@@ -42,6 +42,9 @@ class TrainStep:
         self.red_D = reducer_factory(self.net_D) if reducer_factory is not None else None
         self.red_G = reducer_factory(self.net_G) if reducer_factory is not None else None
         self.after = after or (lambda which: None)     # what follows a phase's gradients (BigGAN: orthogonal regularisation)
+        # Both optimizers refresh the packed weight images of their network right after their step (one launch per network):
+        # a recording of the step may then keep the images of the warm-up, which every replay finds current.
+        self.weight_images_refreshed_in_step = all(getattr(o, "_nets", None) for o in opts)
 
     def _run(self, red, opt, phase, which):
         if red is not None:
@@ -74,8 +77,8 @@ def dcgan(device, batch=128, reducer_factory=None, data_seed=None):
     D = basic_gans.Discriminator(3, 64, 64, is_wgan=False, activation_dtype=torch.bfloat16).to(device)
     G.apply(basic_gans.weights_init)
     D.apply(basic_gans.weights_init)
-    oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    oD = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999)).repack_after_step(G)
+    oD = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999)).repack_after_step(D)
     _reseed(data_seed)
     real = (torch.rand(batch, 3, 64, 64, device=device) * 2 - 1).contiguous(memory_format=torch.channels_last)
     z = torch.randn(batch, 100, 1, 1, device=device)
@@ -98,8 +101,8 @@ def pix2pix_unet(device, batch=8, ch=64, size=256, reducer_factory=None, data_se
     pix2pix.set_activation_dtype(torch.bfloat16)
     pix2pix.set_fused_norm(True)
     G, D = pix2pix.Generator(ch=ch).to(device), pix2pix.Discriminator(ch=ch).to(device)
-    oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    oD = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999)).repack_after_step(G)
+    oD = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999)).repack_after_step(D)
     _reseed(data_seed)
     real = torch.rand(batch, 3, size, size, device=device) * 2 - 1
     label = torch.rand(batch, 3, size, size, device=device)
@@ -131,7 +134,8 @@ def stylegan_v1(device, batch=32, pg=6, reducer_factory=None, data_seed=None):
     oG = optim.Adam([{"params": list(G.synthesis_network.parameters())},
                      {"params": list(G.mapping_network.parameters()), "lr": lr * 0.01}], lr=lr, betas=(0.0, 0.9))
     oG.average_into(averaged_G, G, 0.999)
-    oD = optim.Adam(D.parameters(), lr=lr, betas=(0.0, 0.9))
+    oG.repack_after_step(G)
+    oD = optim.Adam(D.parameters(), lr=lr, betas=(0.0, 0.9)).repack_after_step(D)
     _reseed(data_seed)
     real = torch.rand(batch, 3, res, res, device=device) * 2 - 1
     zs = torch.randn(4, batch, 512, device=device)

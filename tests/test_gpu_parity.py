@@ -1396,9 +1396,12 @@ def test_largest_tiles_against_torch(gan, cin, cout, hw, k, s, p):
     assert rel(y.float(), yr) < 4e-3 and rel(gx.float(), gxr) < 4e-3 and rel(gw, gwr) < 2e-3
 
 
-def test_graphed_step_matches_eager_steps(gan):
+@pytest.mark.parametrize("repack", [False, True])
+def test_graphed_step_matches_eager_steps(gan, repack):
     """gan_amd.GraphedStep on a full Pix2Pix step (both phases, both fused-Adam updates; U-Net and PatchGAN at width 8):
-    three replays with fresh inputs copied into the static tensors must give the losses of three eager steps."""
+    three replays with fresh inputs copied into the static tensors must give the losses of three eager steps.  repack: the
+    optimizers refresh the packed weight images after their step and the recording keeps the images of the warm-up (no
+    per-layer pack launch inside the graph)."""
     from gan_amd.harness import pix2pix as P
     B, ch = 2, 8
     gen = torch.Generator().manual_seed(11)
@@ -1409,6 +1412,8 @@ def test_graphed_step_matches_eager_steps(gan):
         torch.manual_seed(12)
         G, D = P.Generator(ch=ch).cuda(), P.Discriminator(ch=ch).cuda()
         oG = gan.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999)); oD = gan.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        if repack:
+            oG.repack_after_step(G); oD.repack_after_step(D)
         real, label = torch.empty(B, 3, 256, 256, device="cuda"), torch.empty(B, 3, 256, 256, device="cuda")
 
         def step():
@@ -1421,6 +1426,7 @@ def test_graphed_step_matches_eager_steps(gan):
 
         def feed(i):
             real.copy_(batches[i][0]); label.copy_(batches[i][1])
+        step.weight_images_refreshed_in_step = repack
         return step, feed
 
     gan.set_split_reduction(False)
