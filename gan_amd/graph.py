@@ -38,6 +38,8 @@ class GraphedStep:
         # recorded refresh launches keep them current in every replay, so the per-layer pack launches stay out of the graph.
         if not (keep_weight_images and getattr(step, "weight_images_refreshed_in_step", False)):
             ops.clear_weight_cache()
+        else:
+            ops.weight_images_settled()      # (synchronised above: no wait nodes for the warm-up's packs inside the graph)
         ops.clear_cast_cache()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), ops.capturing_on():

@@ -484,7 +484,7 @@ def _dma_ok(t, ic, oc, precision):
 
 class _Image:
     """A cached packed weight image and what it was made from / on."""
-    __slots__ = ("ptr", "version", "shape", "buf", "desc", "wref", "stream", "event", "alpha")
+    __slots__ = ("ptr", "version", "shape", "buf", "desc", "wref", "stream", "event", "alpha", "recorded", "done")
 
     def mark_packed(self, w):
         """Called right after a pack launch on the current stream."""
@@ -493,12 +493,15 @@ class _Image:
         self.stream = st.cuda_stream
         self.event = torch.cuda.Event()
         self.event.record(st)
+        self.recorded = torch.cuda.is_current_stream_capturing()      # the event is a node of a graph being recorded
+        self.done = False
 
     def ready(self, w):
         """Makes the current stream wait for the pack if that ran on another stream (two chains of one training phase on
-        two streams share the images)."""
+        two streams share the images).  A pack that ran eagerly and is known to have finished (weight_images_settled) needs
+        no wait (inside a recording the wait would become an event node of its own per use)."""
         st = torch.cuda.current_stream(w.device)
-        if st.cuda_stream != self.stream:
+        if st.cuda_stream != self.stream and not self.done:
             st.wait_event(self.event)
         return self.buf
 
@@ -537,6 +540,16 @@ def _packed(desc, w, pass_, wkey, alpha=1.0):
             ent.mark_packed(w)
             _wcache.setdefault(wkey, {})[ik] = ent
         return buf
+
+
+def weight_images_settled():
+    """Call after a device synchronisation: every cached image that was packed eagerly has finished, so later uses on
+    other streams skip the wait for its pack (GraphedStep does this in front of a recording that keeps the images)."""
+    with _lock:
+        for images in _wcache.values():
+            for ent in images.values():
+                if not ent.recorded:
+                    ent.done = True
 
 
 def repack(wkeys):
