@@ -162,7 +162,7 @@ def _real_fake_loss(d_both, B):
     return d_real.detach(), d_fake.detach(), d_fake - d_real, None
 
 
-def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
+def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake, pair=None):
     """The independent parts of a critic iteration on streams of their own: the gradient-penalty pass beside the real +
     fake pass (or beside the real pass and the fake pass, `split_real_fake`).  The mid-size layers of these networks
     leave a good part of the GPU idle on their own; two chains in flight at once measured 11 % less time per training
@@ -192,7 +192,9 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
         return grads_of(d_fake, None), d_fake.detach()
 
     def both_chain():
-        d_real, d_fake, out, seed = _real_fake_loss(net_D(torch.cat([real, fake])), B)
+        # pair: real || generated as one tensor that already exists (the data side wrote `real` into its first half, the
+        # generator its images into the second): no concatenation launch
+        d_real, d_fake, out, seed = _real_fake_loss(net_D(pair if pair is not None else torch.cat([real, fake])), B)
         return grads_of(out, seed), (d_real, d_fake)
 
     rf_chains = [real_chain, fake_chain] if split_real_fake else [both_chain]
@@ -273,7 +275,7 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake):
 
 
 def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_backward=None, batch_real_fake=False,
-                      two_streams=False, fake=None):
+                      two_streams=False, fake=None, pair=None):
     """Backward passes accumulate into net_D's gradients: real batch (with the 0.001 drift term), fake batch,
     gradient penalty (double backward).  `on_last_backward` is called right before the last one (a data-parallel
     gradient reducer arms its hooks there).  Returns (D_x, D_G_z1, penalty) as tensors.
@@ -288,9 +290,9 @@ def wgan_critic_phase(net_G, net_D, real, z, epsilon, c_lambda=10.0, on_last_bac
     if two_streams and real.is_cuda:
         if on_last_backward is not None:
             raise RuntimeError("two_streams computes the gradients explicitly: no hook-driven reducer")
-        return _critic_streams(net_D, real, fake, epsilon, c_lambda, not batch_real_fake)
+        return _critic_streams(net_D, real, fake, epsilon, c_lambda, not batch_real_fake, pair)
     if batch_real_fake:
-        d_real, d_fake, out, seed = _real_fake_loss(net_D(torch.cat([real, fake])), real.shape[0])
+        d_real, d_fake, out, seed = _real_fake_loss(net_D(pair if pair is not None else torch.cat([real, fake])), real.shape[0])
         torch.autograd.backward(out, seed)
     else:
         d_real = net_D(real).view(-1)
@@ -393,6 +395,12 @@ class WganGpTrainer:
         self.real = torch.zeros(batch, 3, resolution, resolution, device=self.device).contiguous(memory_format=cl)
         self.z = torch.zeros(disc_repeats + 1, batch, z_dim, 1, 1, device=self.device)
         self.eps = torch.zeros(disc_repeats, batch, 1, 1, 1, device=self.device)
+        # real || generated batches of the critic iterations: `real` sits in the first half (set_inputs), the generator's
+        # forward passes that run ahead write their images into the second half (ops.output_into)
+        self.pairs = None
+        if batch_real_fake and two_streams and self.device.type == "cuda":
+            self.pairs = [torch.zeros(2 * batch, 3, resolution, resolution, device=self.device).contiguous(memory_format=cl)
+                          for _ in range(disc_repeats)]
         self.red_D = reducer_factory(self.net_D) if reducer_factory else None
         self.red_G = reducer_factory(self.net_G) if reducer_factory else None
         self.graph = None
@@ -400,6 +408,8 @@ class WganGpTrainer:
 
     def set_inputs(self, real, zs, eps):
         self.real.copy_(real)
+        for p in self.pairs or []:
+            p[:self.B].copy_(self.real)
         self.z.copy_(torch.stack(list(zs)))
         self.eps.copy_(eps)
 
@@ -420,7 +430,11 @@ class WganGpTrainer:
         fakes = []
         with torch.cuda.stream(st):
             for it in range(self.reps):
-                f = self.net_G(self.z[it]).detach()
+                if self.pairs is not None:
+                    with gops.output_into(self.pairs[it][self.B:]):
+                        f = self.net_G(self.z[it]).detach()
+                else:
+                    f = self.net_G(self.z[it]).detach()
                 ev = torch.cuda.Event()
                 ev.record(st)
                 fakes.append((f, ev))
@@ -439,6 +453,12 @@ class WganGpTrainer:
         if wait:
             torch.cuda.current_stream(self.device).wait_event(ev)
         return f
+
+    def _pair(self, it, fake):
+        """The real || generated tensor of critic iteration `it` if the generator's images landed in its second half."""
+        if self.pairs is None or fake is None or fake.data_ptr() != self.pairs[it][self.B:].data_ptr():
+            return None
+        return self.pairs[it]
 
     def _generator_phase(self, arm, fake=None):
         """The generator phase of the cycle.  The critic's weight gradients of this pass -- added to the critic's
@@ -459,9 +479,10 @@ class WganGpTrainer:
         for it in range(self.reps):
             self._zero(self.net_D, self.red_D)
             arm = self.red_D.arm if self.red_D is not None else None
+            fake = self._fake(fakes, it)
             d_x, d_g_z1, gp = wgan_critic_phase(self.net_G, self.net_D, self.real, self.z[it], self.eps[it], self.c_lambda,
                                                 None if self.two_streams else arm, self.batch_real_fake, self.two_streams,
-                                                self._fake(fakes, it))
+                                                fake, self._pair(it, fake))
             if self.red_D is not None:
                 self.red_D.finish()
             self.opt_D.step()
@@ -534,8 +555,9 @@ class WganGpTrainer:
                 if it == 0 and self.two_streams:        # (the images stay allocated in the graphs' pool until their graph is recorded)
                     fakes = self._fakes_ahead()
                 # the first graph holds all generator passes and ends after them: later graphs find the images ready
+                fake = self._fake(fakes, it, wait=(it == 0))
                 out = wgan_critic_phase(self.net_G, self.net_D, self.real, self.z[it], self.eps[it], self.c_lambda, None,
-                                        self.batch_real_fake, self.two_streams, self._fake(fakes, it, wait=(it == 0)))
+                                        self.batch_real_fake, self.two_streams, fake, self._pair(it, fake))
                 if it == 0 and self.two_streams:
                     torch.cuda.current_stream(self.device).wait_stream(_side_stream(self.device, "generator"))
                 return out

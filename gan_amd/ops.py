@@ -667,6 +667,38 @@ def _(x, w, bias, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=
                        dtype=_out_dtype(x, out_dtype))
 
 
+# A caller may offer the memory a convolution's result should be written to (the generator's images straight into the second
+# half of the critic's real || generated batch: no concatenation launch).  The next forward-of-a-transposed-convolution /
+# data-gradient launch whose result has exactly the offered tensor's shape, dtype and NHWC layout takes it.
+_offered_outputs = []
+
+
+class output_into:
+    """with output_into(buf): the launch inside whose result matches `buf` (shape, dtype, dense NHWC) writes into it and
+    returns it instead of a fresh tensor.  An offer nobody took is withdrawn at exit."""
+
+    def __init__(self, buf):
+        self.buf = buf
+
+    def __enter__(self):
+        _offered_outputs.append(self.buf)
+        return self
+
+    def __exit__(self, *exc):
+        for i, b in enumerate(_offered_outputs):
+            if b is self.buf:
+                del _offered_outputs[i]
+                break
+        return False
+
+
+def _result_tensor(shape, dtype, device):
+    for i, b in enumerate(_offered_outputs):
+        if tuple(b.shape) == tuple(shape) and b.dtype == dtype and b.device == device and b.is_contiguous(memory_format=torch.channels_last):
+            return _offered_outputs.pop(i)
+    return torch.empty(shape, dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
 def _dgrad_launch(gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, out_dtype, alpha, mask=None, mask_slope=0.0):
     _check_cuda(gy, w, bias, mask)
     N, Cout, Ho, Wo = gy.shape
@@ -678,7 +710,10 @@ def _dgrad_launch(gy, w, bias, H, W, stride, padding, precision, wkey, act, slop
     gy = _nhwc(gy)
     want = _out_dtype(gy, out_dtype)
     narrow = mask is None and _small_output_in_f32(N * Cin * H * W, want, act)
-    gx = torch.empty((N, Cin, H, W), dtype=torch.float32 if narrow else want, device=gy.device, memory_format=torch.channels_last)
+    if narrow:
+        gx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+    else:
+        gx = _result_tensor((N, Cin, H, W), want, gy.device)
     if _dma_ok(gy, Cout, Cin, precision):
         gy = _to_bf16(gy)
     d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(gx), precision, _dtype_code(gy))
