@@ -83,6 +83,7 @@ int launch_scatter(const GatherParams& p, const GatherLaunch& l, bool out_f32, h
 bool plan_dot(const GatherParams& p, const GatherLaunch& l);
 int launch_dot(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream);
 bool plan_image(const GatherParams& p, const GatherLaunch& l);
+bool image_applies_mask(const GatherParams& p);      // launch_image multiplies by the gradient mask itself
 // 1 x 1 convolution of an image of at most 4 channels (StyleGAN's from-RGB layers), see conv_point.hip; leaves a gradient
 // mask to the caller.
 bool plan_point(const GatherParams& p, const GatherLaunch& l);

@@ -24,7 +24,9 @@ constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 // multiplied and stored (two patch buffers, the raw floats wait in registers).
 // NB: 16-channel blocks the kernel is built for (4: up to 64 output channels; 8: up to 128, at twice the registers)
 // ICP: channels of a patch pixel (4, or 8 for 5 to 8 input channels -- the PatchGAN's image pair: a filter row per MFMA)
-template <typename TOut, bool LEAN, int NB, int ICP>
+// MASK: the stored value is multiplied by the derivative of the ReLU / LeakyReLU whose output is p.mask (gc_epilogue.grad_mask:
+// the second-order pass of the critic's first layer, whose result the next layer's masked data gradient would otherwise sweep)
+template <typename TOut, bool LEAN, int NB, int ICP, bool MASK = false>
 __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p, int units, int units_per_wg) {
   constexpr int NKS = ICP / 2;        // reduction steps of 32: 16 taps x ICP channels
   __shared__ __attribute__((aligned(16))) uint16_t patch[2][kPH * kPW * ICP];
@@ -141,6 +143,22 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
         if (ob >= nb) continue;
         if (ob + 1 < nb) {          // a pair of blocks: 8 consecutive channels
           const size_t o = o0 + 32 * (ob >> 1) + 8 * g;
+          if (MASK) {
+            f32x4 m0, m1;
+            if (sizeof(TOut) == 4) {
+              m0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask) + o);
+              m1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask) + o + 4);
+            } else {
+              const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.mask) + o);
+              m0 = widen_bf16x4(u32x2{q[0], q[1]});
+              m1 = widen_bf16x4(u32x2{q[2], q[3]});
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              v[ob][e] = m0[e] > 0.f ? v[ob][e] : v[ob][e] * p.mask_slope;
+              v[ob + 1][e] = m1[e] > 0.f ? v[ob + 1][e] : v[ob + 1][e] * p.mask_slope;
+            }
+          }
           if (sizeof(TOut) == 4) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v[ob];
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o + 4) = v[ob + 1];
@@ -150,6 +168,13 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
           }
         } else {
           const size_t o = o0 + 16 * ob + 4 * g;
+          if (MASK) {
+            f32x4 m0;
+            if (sizeof(TOut) == 4) m0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mask) + o);
+            else m0 = widen_bf16x4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.mask) + o));
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[ob][e] = m0[e] > 0.f ? v[ob][e] : v[ob][e] * p.mask_slope;
+          }
           if (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v[ob];
           else *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + o) = cvt_bf16x4(v[ob]);
         }
@@ -182,6 +207,12 @@ bool plan_image(const GatherParams& p, const GatherLaunch& l) {
   return (long)p.N * (p.OH / kTH) * (p.OW / kTW) < (1l << 31);
 }
 
+// Whether launch_image applies p.mask itself (the caller then clears it): 4-channel patch pixels, up to 64 output channels,
+// a 16-byte aligned mask (it shares the output's layout).
+bool image_applies_mask(const GatherParams& p) {
+  return p.mask != nullptr && p.ICp == 4 && p.OC <= 64 && p.act == GC_ACT_NONE && (reinterpret_cast<uintptr_t>(p.mask) & 15u) == 0;
+}
+
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
   const long units_l = (long)p.N * (p.OH / kTH) * (p.OW / kTW);
   if (units_l == 0) return GC_OK;
@@ -196,7 +227,10 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
   const dim3 grid(blocks);
 #define GC_IMAGE_LAUNCH8(T_, L_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, 4, 8>), grid, dim3(kThreads), 0, stream, p, units, per)
 #define GC_IMAGE_LAUNCH(T_, L_, NB_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, NB_, 4>), grid, dim3(kThreads), 0, stream, p, units, per)
-  if (p.ICp == 8) {
+  if (image_applies_mask(p)) {
+    if (out_f32) hipLaunchKernelGGL((conv_image_kernel<float, true, 4, 4, true>), grid, dim3(kThreads), 0, stream, p, units, per);
+    else hipLaunchKernelGGL((conv_image_kernel<uint16_t, true, 4, 4, true>), grid, dim3(kThreads), 0, stream, p, units, per);
+  } else if (p.ICp == 8) {
     if (out_f32) { if (lean) GC_IMAGE_LAUNCH8(float, true); else GC_IMAGE_LAUNCH8(float, false); }
     else { if (lean) GC_IMAGE_LAUNCH8(uint16_t, true); else GC_IMAGE_LAUNCH8(uint16_t, false); }
   } else if (p.OC <= 64) {

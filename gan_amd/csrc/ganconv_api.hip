@@ -390,7 +390,12 @@ static int run_gather_unmasked(GatherParams& p, GatherLaunch& l, int out_dt, hip
     return rc;
   }
   if (plan_spread(p, l)) return launch_spread(p, l, out_dt == GC_F32, stream);
-  if (plan_image(p, l)) return launch_image(p, l, out_dt == GC_F32, stream);
+  if (plan_image(p, l)) {
+    const bool masked = image_applies_mask(p);
+    const int rc = launch_image(p, l, out_dt == GC_F32, stream);
+    if (masked) p.mask = nullptr;
+    return rc;
+  }
   if (plan_point(p, l)) return launch_point(p, l, out_dt == GC_F32, stream);
   if (p.out_bf16 == nullptr && plan_scatter(p, l)) return launch_scatter(p, l, out_dt == GC_F32, stream);
   }

@@ -767,6 +767,43 @@ def _(gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0, out
     return gy.new_empty((gy.shape[0], w.shape[1], H, W), dtype=_out_dtype(gy, out_dtype))
 
 
+@torch.library.custom_op("ganconv::conv_fprop_masked", mutates_args=())
+def conv_fprop_masked(x: Tensor, w: Tensor, mask: Tensor, mask_slope: float, stride: int, padding: int, precision: int, wkey: int,
+                      out_dtype: int = -1, alpha: float = 1.0) -> Tensor:
+    """conv2d(x, alpha * w) * (mask > 0 ? 1 : mask_slope): a forward convolution whose result is multiplied, in the kernel's
+    output stage, by the derivative of the ReLU / LeakyReLU whose output is `mask` (gc_epilogue.grad_mask).  The second-order
+    pass of a convolution whose activation's derivative is deferred to its consumer: the gradient with respect to the masked
+    data gradient, handed on already masked (see the hand-over described at fuse_second_order_mask)."""
+    _check_cuda(x, w, mask)
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = w.shape
+    if Cin_w != Cin:
+        raise RuntimeError(f"ganconv: weight expects {Cin_w} input channels, input has {Cin}")
+    Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
+    x = _nhwc(x)
+    want = _out_dtype(x, out_dtype)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=want, device=x.device, memory_format=torch.channels_last)
+    if tuple(mask.shape) != tuple(y.shape):
+        raise RuntimeError(f"ganconv: the activated tensor {tuple(mask.shape)} does not have the result's shape {tuple(y.shape)}")
+    mask = _nhwc(mask)
+    if mask.dtype != y.dtype:
+        mask = mask.to(y.dtype)
+    if _dma_ok(x, Cin, Cout, precision):
+        x = _to_bf16(x)
+    d = _desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, padding, _dtype_code(x), precision, _dtype_code(y))
+    wp = _packed(d, w, _lib.GC_PASS_FPROP, wkey, alpha)
+    ep = Epilogue()
+    ep.act, ep.slope, ep.grad_mask = _lib.GC_ACT_NONE, mask_slope, mask.data_ptr()
+    _lib.check(_lib.lib().gc_conv2d_fprop(ctypes.byref(d), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wp.data_ptr()),
+                                          ctypes.c_void_p(y.data_ptr()), ctypes.byref(ep), _stream()), "gc_conv2d_fprop")
+    return y
+
+
+@conv_fprop_masked.register_fake
+def _(x, w, mask, mask_slope, stride, padding, precision, wkey, out_dtype=-1, alpha=1.0):
+    return x.new_empty(mask.shape, dtype=_out_dtype(x, out_dtype))
+
+
 def _image_layer(x, gy, geom, precision):
     """fp32 image, bf16 gradient, in the geometry of the image layer's weight-gradient kernel (conv_wgrad_image.hip),
     which rounds the image to bf16 in registers: no bf16 copy of the image is needed."""
@@ -1017,6 +1054,44 @@ def _wanted(ctx, i):
         return True
 
 
+# Second-order pass through a deferred activation derivative (the gradient penalty's double backward through the critic's
+# first LeakyReLU, BasicGANs/models.py:78).  First order: layer 2 returns G = m * dgrad(gy2, w2) (conv_dgrad_masked, m the
+# derivative of layer 1's activation) and layer 1 computes dgrad(G, w1).  Second order: layer 1's node returns
+# t = fprop(u, w1) as the gradient with respect to G, and conv_dgrad_masked's node needs m * t.  Instead of a sweep there,
+# layer 1's node produces m * t in its kernel's output stage (conv_fprop_masked).  The two nodes agree on it as follows:
+# conv_dgrad_masked registers its result G (by address, with a weak reference) together with (m, slope, token); the
+# convolution whose backward formula receives exactly that tensor as its incoming gradient passes (m, slope, token) to its
+# conv_dgrad node; in the second-order pass that node multiplies by m and notes the tensor it returned under the token; the
+# conv_dgrad_masked node skips its own multiplication only when the tensor it receives is that one, and raises if a
+# premasked tensor reached it changed (a second reader of G would make autograd add its gradient to the premasked one).
+fuse_second_order_mask = os.environ.get("GC_NO_SECOND_ORDER_MASK") is None      # (the variable: an A/B switch for measurements)
+_premask_offers = {}      # address of G -> (weak reference to G, m, slope, token)
+_premask_done = {}        # token -> weak reference to the premasked tensor the conv_dgrad node returned
+_premask_pending = [None]
+_premask_token = [0]
+
+
+def _premask_offer(out, mask, slope):
+    _premask_token[0] += 1
+    while len(_premask_offers) >= 16:
+        _premask_offers.pop(next(iter(_premask_offers)))
+    while len(_premask_done) >= 16:
+        _premask_done.pop(next(iter(_premask_done)))
+    _premask_offers[out.data_ptr()] = (weakref.ref(out), mask, float(slope), _premask_token[0])
+    return _premask_token[0]
+
+
+def _premask_for(gy):
+    """(mask, slope, token) when `gy` is the registered result of a conv_dgrad_masked call, else None."""
+    ent = _premask_offers.pop(gy.data_ptr(), None) if (fuse_second_order_mask and _premask_offers) else None
+    if ent is None:
+        return None
+    g = ent[0]()
+    if g is None or g.data_ptr() != gy.data_ptr() or g.shape != gy.shape or g.dtype != gy.dtype or g._version != gy._version:
+        return None
+    return ent[1:]
+
+
 def _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_x, need_w, x_act_slope=-1.0, need_b=False):
     """(gx, gw, gb) of y = conv(x, alpha * w) + b from gy: the data-gradient and weight-gradient launches (the weight gradient
     goes to an active weight_gradient_sink instead when one accepts it; with backward overlap on, it runs on the side
@@ -1026,7 +1101,11 @@ def _input_weight_grads(x, w, gy, stride, padding, precision, wkey, alpha, need_
     def dgrad():
         if x_act_slope >= 0.0:
             return conv_dgrad_masked(gy, w, x, x_act_slope, stride, padding, precision, wkey, _code_of(x.dtype), alpha)
-        return conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
+        _premask_pending[0] = _premask_for(gy) if gy.requires_grad else None      # (picked up by the conv_dgrad node's setup)
+        try:
+            return conv_dgrad(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, wkey, 0, 0.0, _code_of(x.dtype), alpha)
+        finally:
+            _premask_pending[0] = None
 
     def wgrad():
         if need_b:
@@ -1095,6 +1174,7 @@ def _dgrad_setup(ctx, inputs, output):
     else:
         ctx.save_for_backward(gy, w)
     ctx.cfg = (stride, padding, precision, wkey, bias is not None, act, slope, alpha)
+    ctx.premask, _premask_pending[0] = (_premask_pending[0] if act == 0 else None), None
 
 
 def _dgrad_backward(ctx, u):
@@ -1110,17 +1190,27 @@ def _dgrad_backward(ctx, u):
     else:
         gy, w = ctx.saved_tensors
     g_gy = g_w = None
+
+    def fprop_of_u():
+        premask = getattr(ctx, "premask", None)
+        if premask is None:
+            return conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
+        mask, mask_slope, token = premask       # gy is a masked data gradient: its gradient leaves already masked
+        t = conv_fprop_masked(u, w, mask, mask_slope, stride, padding, precision, wkey, _code_of(gy.dtype), alpha)
+        _premask_done[token] = weakref.ref(t)
+        return t
+
     if need_w and _wgrad_to_sink(w, u, gy, stride, padding, precision, alpha):
         need_w = False
     if _overlap and need_gy and need_w and u.is_cuda:
         with _SideLaunch(u.device) as side:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha)
-        g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
+        g_gy = fprop_of_u()
         side.join()
         g_w = g_w.to(w.dtype)
     else:
         if need_gy:
-            g_gy = conv_fprop(u, w, None, stride, padding, precision, wkey, 0, 0.0, _code_of(gy.dtype), alpha)
+            g_gy = fprop_of_u()
         if need_w:
             g_w = conv_wgrad(u, gy, w.shape[2], w.shape[3], stride, padding, precision, alpha).to(w.dtype)
     if need_b and g_b is None:
@@ -1136,6 +1226,7 @@ def _dgrad_masked_setup(ctx, inputs, output):
     ctx.edges = _edges(gy, w)
     ctx.save_for_backward(gy, w, x)
     ctx.cfg = (x_act_slope, stride, padding, precision, wkey, alpha)
+    ctx.token = _premask_offer(output, x, x_act_slope) if fuse_second_order_mask else 0
 
 
 def _dgrad_masked_backward(ctx, u):
@@ -1144,7 +1235,15 @@ def _dgrad_masked_backward(ctx, u):
     x_act_slope, stride, padding, precision, wkey, alpha = ctx.cfg
     gy, w, x = ctx.saved_tensors
     need_gy, need_w = _wanted(ctx, 0), _wanted(ctx, 1)
-    u = _act_backward(u, x, _lib.GC_ACT_LRELU if x_act_slope != 0.0 else _lib.GC_ACT_RELU, x_act_slope)
+    done = _premask_done.pop(ctx.token, None) if getattr(ctx, "token", 0) else None
+    if done is not None:          # the node that produced u multiplied it by the activation's derivative already
+        t = done()
+        if t is None or t.data_ptr() != u.data_ptr() or t.shape != u.shape:
+            raise RuntimeError("ganconv: a gradient that left its kernel already multiplied by the deferred activation derivative "
+                               "reached conv_dgrad_masked changed (a second reader of the masked data gradient?); set "
+                               "gan_amd.ops.fuse_second_order_mask = False for this graph")
+    else:
+        u = _act_backward(u, x, _lib.GC_ACT_LRELU if x_act_slope != 0.0 else _lib.GC_ACT_RELU, x_act_slope)
     g_gy = g_w = None
     if need_w and _wgrad_to_sink(w, u, gy, stride, padding, precision, alpha):
         need_w = False
@@ -1156,6 +1255,25 @@ def _dgrad_masked_backward(ctx, u):
 
 
 torch.library.register_autograd("ganconv::conv_dgrad_masked", _dgrad_masked_backward, setup_context=_dgrad_masked_setup)
+
+
+def _fprop_masked_setup(ctx, inputs, output):
+    x, w, mask, mask_slope, stride, padding, precision, wkey, _, alpha = inputs
+    ctx.edges = _edges(x, w)
+    ctx.save_for_backward(x, w, mask)
+    ctx.cfg = (mask_slope, stride, padding, precision, wkey, alpha)
+
+
+def _fprop_masked_backward(ctx, g):
+    """Linear in x and in w for a fixed mask: g passes through the same mask, then through the convolution's adjoints."""
+    mask_slope, stride, padding, precision, wkey, alpha = ctx.cfg
+    x, w, mask = ctx.saved_tensors
+    g = _act_backward(g, mask, _lib.GC_ACT_LRELU if mask_slope != 0.0 else _lib.GC_ACT_RELU, mask_slope)
+    gx, gw, _ = _input_weight_grads(x, w, g, stride, padding, precision, wkey, alpha, _wanted(ctx, 0), _wanted(ctx, 1))
+    return gx, gw, None, None, None, None, None, None, None, None
+
+
+torch.library.register_autograd("ganconv::conv_fprop_masked", _fprop_masked_backward, setup_context=_fprop_masked_setup)
 
 
 def _wgrad_setup(ctx, inputs, output):

@@ -161,3 +161,44 @@ def test_biggan_discriminator_blocks_with_and_without_the_deferral(gan):
     assert ga.keys() == gb.keys() and len(ga) > 20
     worst = max((rel(gb[n], ga[n]), n) for n in ga if float(ga[n].norm()) > 0)
     assert worst[0] < 2e-2, worst
+
+
+@pytest.mark.parametrize("cin,dt", [(3, torch.bfloat16), (3, torch.float32), (64, torch.bfloat16)])
+def test_second_order_mask_leaves_with_the_producing_kernel(gan, cin, dt):
+    """conv + LeakyReLU (derivative deferred) -> conv, under a gradient penalty's double backward (the critic's first two layers,
+    BasicGANs/models.py:77-79): the second-order pass needs (derivative of the activation) x (forward convolution of the incoming
+    vector).  With ops.fuse_second_order_mask the forward convolution's kernel applies that factor in its output stage and the
+    consumer skips its sweep: same gradients to rounding, one elementwise launch less."""
+    from torch.profiler import ProfilerActivity, profile
+    F = gan.functional
+    g = torch.Generator().manual_seed(13)
+    N, H, C1, C2 = 8, 64, 64, 128
+    x = (torch.randn(N, cin, H, H, generator=g)).cuda().contiguous(memory_format=torch.channels_last)
+    if cin % 8 == 0:
+        x = x.to(dt)
+    w1 = (torch.randn(C1, cin, 4, 4, generator=g) / (4 * cin ** 0.5)).cuda()
+    w2 = (torch.randn(C2, C1, 4, 4, generator=g) / 32).cuda()
+    seed = torch.randn(N, C2, H // 4, H // 4, generator=g).to(dt).cuda()
+    res = []
+    was = gan.ops.fuse_second_order_mask
+    try:
+        for fuse in (False, True):
+            gan.ops.fuse_second_order_mask = fuse
+            xx, a, b = (t.clone().requires_grad_(True) for t in (x, w1, w2))
+            h = F.conv2d(xx, a, None, 2, 1, activation="leaky_relu", negative_slope=0.2, out_dtype=dt, defer_activation_grad=True)
+            y = F.conv2d(h, b, None, 2, 1, out_dtype=dt, input_activation_slope=0.2)
+            gx, = torch.autograd.grad((y * seed).sum(), xx, create_graph=True)
+            penalty = (gx.float().flatten(1).norm(dim=1) - 1).square().mean()
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                second = torch.autograd.grad(penalty, (a, b))
+                torch.cuda.synchronize()
+            sweeps = sum("leaky_relu_backward" in e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+            res.append((gx.detach(), second, sweeps))
+    finally:
+        gan.ops.fuse_second_order_mask = was
+    (gxa, sa, na), (gxb, sb, nb) = res
+    assert torch.equal(gxa, gxb)                      # the first-order pass is untouched
+    assert na >= 1 and nb == na - 1, (na, nb)
+    tol = 2e-5 if (dt == torch.float32 and cin == 3) else 1.5e-2
+    for p, q, name in zip(sb, sa, ("w1", "w2")):
+        assert rel(p, q) < tol, f"second-order gradient by {name}: {rel(p, q)}"
