@@ -175,6 +175,8 @@ def _critic_streams(net_D, real, fake, epsilon, c_lambda, split_real_fake, pair=
     def grads_of(out, seed):
         """d out / d params as autograd returns them; inside the sink the convolution weights come back as None (their
         gradients are collected by the sink)."""
+        if seed is None and out.is_cuda:            # (a cached one instead of the fill launch autograd would make per call)
+            seed = _ones_like(out)
         with gops.parameter_gradients_only():      # (no data gradient for the mixed images, a leaf that requires grad)
             return torch.autograd.grad(out, params, grad_outputs=seed, allow_unused=weight_gradient_sink)
 
@@ -315,7 +317,7 @@ def wgan_generator_phase(net_G, net_D, z, on_last_backward=None, fake=None):
     g_error = -d_fake.mean()
     if on_last_backward is not None:
         on_last_backward()
-    g_error.backward()
+    g_error.backward(_ones_like(g_error) if g_error.is_cuda else None)
     return g_error.detach()
 
 
