@@ -717,6 +717,16 @@ int gc_cond_batchnorm_act_fwd(const void* x, void* y, const float* gamma, const 
                     workspace_bytes, (int64_t)N * HW, C, dtype, eps, momentum, act, slope, training, stream, N);
 }
 
+int gc_cond_batchnorm_act_fwd_rows(const void* x, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                                   const float* stat_rows, int32_t n_rows, void* workspace, size_t workspace_bytes, int32_t N, int32_t HW,
+                                   int32_t C, int32_t dtype, float eps, float momentum, int32_t act, float slope, void* stream) {
+  if (N <= 0 || HW <= 0) { set_error("batchnorm: conditional mode needs N > 0 and HW > 0"); return GC_BAD_ARGUMENT; }
+  if (stat_rows == nullptr || n_rows <= 0 || misaligned(stat_rows, 7)) { set_error("batchnorm: rows of statistics expected"); return GC_BAD_ARGUMENT; }
+  return bn_forward(x, y, nullptr, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, save_var, workspace,
+                    workspace_bytes, (int64_t)N * HW, C, dtype, eps, momentum, act, slope, 1, stream, N, stat_rows, n_rows);
+}
+
 static int bn_backward(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
                        const float* save_rstd, void* gx, void* gx_bf16, float* ggamma, float* gbeta, void* workspace,
                        size_t workspace_bytes, int64_t P, int32_t C, int32_t dtype, int32_t act, float slope, void* stream, int32_t nsamp,

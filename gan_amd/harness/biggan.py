@@ -22,6 +22,8 @@ set_fused_attention(True) computes softmax(K Q) V with ops.attention, which neve
 weights.  Phases: hinge loss of BasicGANs/loss_functions.py:79-99, step order and orthogonal regularisation of
 BigGAN/train.py:115-127, 187-226.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as TF
 
@@ -189,7 +191,9 @@ class GeneratorBlock(torch.nn.Module):
         self.residual_conv = Conv2d(cin, cout, 1)
 
     def forward(self, x, y):
-        h = self.conv_1(self.batch_norm_1(x, y), upsample=True)
+        # (the up-sampling convolution writes the statistics rows the conditional BatchNorm behind it reads: no sweep of its own)
+        with ops.channel_statistics_request() if (self.training and _opt["fused_norm"] and x.is_cuda) else contextlib.nullcontext():
+            h = self.conv_1(self.batch_norm_1(x, y), upsample=True)
         h = self.conv_2(self.batch_norm_2(h, y))
         # (a 1x1 convolution commutes with the replication: it runs on the small image)
         return h + GF.upsample_nearest2x(self.residual_conv(x))

@@ -256,6 +256,13 @@ int gc_cond_batchnorm_act_fwd(const void* x, void* y, const float* gamma, const 
                               int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var, void* workspace,
                               size_t workspace_bytes, int32_t N, int32_t HW, int32_t C, int32_t dtype, float eps, float momentum,
                               int32_t act, float slope, int32_t training, void* stream);
+/* gc_cond_batchnorm_act_fwd in training mode with the batch statistics taken from the rows the convolution in front wrote
+ * (gc_epilogue.stat_rows), as gc_batchnorm_act_fwd_rows does for the plain form: BigGAN/model.py:100-133, the second
+ * conditional BatchNorm of a generator block behind its up-sampling convolution. */
+int gc_cond_batchnorm_act_fwd_rows(const void* x, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* save_var,
+                                   const float* stat_rows, int32_t n_rows, void* workspace, size_t workspace_bytes, int32_t N, int32_t HW,
+                                   int32_t C, int32_t dtype, float eps, float momentum, int32_t act, float slope, void* stream);
 int gc_cond_batchnorm_act_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* save_mean,
                               const float* save_rstd, void* gx, float* ggamma, float* gbeta, void* workspace, size_t workspace_bytes,
                               int32_t N, int32_t HW, int32_t C, int32_t dtype, int32_t act, float slope, void* stream);

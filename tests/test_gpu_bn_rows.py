@@ -124,3 +124,31 @@ def test_statistics_rows_through_the_c_abi(gan):
     yf = y.double().permute(0, 2, 3, 1).reshape(-1, 128)
     assert rel(rows[:, :, 0].sum(0), yf.sum(0)) < 1e-6
     assert rel(rows[:, :, 1].sum(0), yf.square().sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("kind,cin,cout,N,H", [("up", 128, 64, 32, 32), ("s1", 128, 128, 32, 64), ("up", 256, 128, 16, 16)])
+def test_conditional_batchnorm_from_conv_rows_matches_own_sweep(gan, kind, cin, cout, N, H):
+    """BigGAN's generator block (BigGAN/model.py:100-133): up-sampling 3x3 convolution -> conditional BatchNorm + ReLU with a
+    gain and shift per sample.  With the statistics rows of the convolution the BatchNorm launches no sweep of its own and
+    gives the same output, running statistics and saved statistics to rounding."""
+    from gan_amd import ops, functional as GF
+    torch.manual_seed(17)
+    x = (torch.randn(N, cin, H, H, device="cuda") * 2 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)
+    b = torch.randn(cout, device="cuda") * 0.1
+    gain, shift = torch.randn(N, cout, device="cuda") * 0.3 + 1, torch.randn(N, cout, device="cuda") * 0.2
+    res = []
+    for rows in (False, True):
+        rm, rv, nbt = torch.full((cout,), 0.5, device="cuda"), torch.full((cout,), 0.5, device="cuda"), torch.zeros((), dtype=torch.long, device="cuda")
+        gan._lib.profile_enable(True)
+        with (ops.channel_statistics_request() if rows else torch.no_grad()):
+            h = GF.upsample2x_conv3x3(x, w, b) if kind == "up" else GF.conv2d(x, w, b, 1, 1)
+        y = ops.batchnorm_act_train(h, gain, shift, rm, rv, nbt, 0.1, 1e-5, 1, 0.0)
+        torch.cuda.synchronize()
+        names = set(gan._lib.profile_collect())
+        gan._lib.profile_enable(False)
+        res.append((y, rm, rv, nbt, names))
+    (y0, rm0, rv0, n0, names0), (y1, rm1, rv1, n1, names1) = res
+    assert "gc::bn_partial_kernel<0>" in names0
+    assert "gc::bn_partial_kernel<0>" not in names1 and ({"gc::bn_rows_partial_kernel", "gc::bn_finalize_kernel<3>"} & names1), sorted(names1)
+    assert rel(y1, y0) < 4e-3 and rel(rm1, rm0) < 1e-5 and rel(rv1, rv0) < 1e-5 and int(n1) == int(n0) == 1
