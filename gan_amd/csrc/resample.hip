@@ -35,8 +35,9 @@ struct Vec8 {
 };
 
 // y[n, h, w, :] = scale * sum of x[n, 2h + {0,1}, 2w + {0,1}, :];  H, W: extents of y
+// `addend` (null, or a tensor of y's shape): y = scale * pool(x) + addend, the residual sum of a block in the same sweep
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pool2x2_kernel(const T* x, T* y, size_t total, int H, int W, int C8, float scale) {
+__global__ __launch_bounds__(kThreads) void pool2x2_kernel(const T* x, T* y, size_t total, int H, int W, int C8, float scale, const T* addend) {
   for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
     const int c = (int)(e % C8);
     const size_t pix = e / C8;
@@ -49,13 +50,18 @@ __global__ __launch_bounds__(kThreads) void pool2x2_kernel(const T* x, T* y, siz
     Vec8<T> o;
     o.a = ((v0.a + v1.a) + (v2.a + v3.a)) * scale;
     o.b = ((v0.b + v1.b) + (v2.b + v3.b)) * scale;
+    if (addend != nullptr) {
+      const Vec8<T> r = Vec8<T>::load(addend + e * 8);
+      o.a += r.a;
+      o.b += r.b;
+    }
     o.store(y + e * 8);
   }
 }
 
 // y[n, 2h + a, 2w + b, :] = scale * x[n, h, w, :];  H, W: extents of x.  One thread per input element, four stores.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void replicate2x_kernel(const T* x, T* y, size_t total, int H, int W, int C8, float scale) {
+__global__ __launch_bounds__(kThreads) void replicate2x_kernel(const T* x, T* y, size_t total, int H, int W, int C8, float scale, const T* addend) {
   for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
     const int c = (int)(e % C8);
     const size_t pix = e / C8;
@@ -66,6 +72,17 @@ __global__ __launch_bounds__(kThreads) void replicate2x_kernel(const T* x, T* y,
     v.b *= scale;
     const size_t dst = ((nh * 2) * (2 * (size_t)W) + 2 * w) * C8 + c;
     const size_t rowp = 2 * (size_t)W * C8;
+    if (addend != nullptr) {          // y = scale * replicate(x) + addend (addend has y's shape)
+      const size_t offs[4] = {dst, dst + C8, dst + rowp, dst + rowp + C8};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        Vec8<T> r = Vec8<T>::load(addend + offs[q] * 8);
+        r.a += v.a;
+        r.b += v.b;
+        r.store(y + offs[q] * 8);
+      }
+      continue;
+    }
     v.store(y + dst * 8);
     v.store(y + (dst + C8) * 8);
     v.store(y + (dst + rowp) * 8);
@@ -172,26 +189,50 @@ extern "C" int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32
   return reflect_launch(true, gy, gx, N, H, W, C, pad, dtype, stream);
 }
 
-extern "C" int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream) {
+static int pool_launch(const void* x, const void* addend, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale,
+                       void* stream) {
   if (int e = check_args(x, y, N, Ho, Wo, C, dtype)) return e;
+  if ((reinterpret_cast<uintptr_t>(addend) & 15) != 0) { set_error("resample: the addend must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
   const size_t total = (size_t)N * Ho * Wo * (C / 8);
   if (total == 0) return GC_OK;
-  ProfScope ps("gc::pool2x2_kernel", 0.0, (hipStream_t)stream);
+  ProfScope ps(addend != nullptr ? "gc::pool2x2_kernel<add>" : "gc::pool2x2_kernel", 0.0, (hipStream_t)stream);
   if (dtype == GC_F32)
-    hipLaunchKernelGGL(pool2x2_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, total, Ho, Wo, C / 8, scale);
+    hipLaunchKernelGGL(pool2x2_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, total, Ho, Wo, C / 8, scale, (const float*)addend);
   else
-    hipLaunchKernelGGL(pool2x2_kernel<uint16_t>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, total, Ho, Wo, C / 8, scale);
+    hipLaunchKernelGGL(pool2x2_kernel<uint16_t>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, total, Ho, Wo, C / 8, scale, (const uint16_t*)addend);
   return check_hip(hipGetLastError(), "pool2x2 launch");
 }
 
-extern "C" int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream) {
+static int replicate_launch(const void* x, const void* addend, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale,
+                            void* stream) {
   if (int e = check_args(x, y, N, H, W, C, dtype)) return e;
+  if ((reinterpret_cast<uintptr_t>(addend) & 15) != 0) { set_error("resample: the addend must be 16-byte aligned"); return GC_BAD_ARGUMENT; }
   const size_t total = (size_t)N * H * W * (C / 8);
   if (total == 0) return GC_OK;
-  ProfScope ps("gc::replicate2x_kernel", 0.0, (hipStream_t)stream);
+  ProfScope ps(addend != nullptr ? "gc::replicate2x_kernel<add>" : "gc::replicate2x_kernel", 0.0, (hipStream_t)stream);
   if (dtype == GC_F32)
-    hipLaunchKernelGGL(replicate2x_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, total, H, W, C / 8, scale);
+    hipLaunchKernelGGL(replicate2x_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, (float*)y, total, H, W, C / 8, scale, (const float*)addend);
   else
-    hipLaunchKernelGGL(replicate2x_kernel<uint16_t>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, total, H, W, C / 8, scale);
+    hipLaunchKernelGGL(replicate2x_kernel<uint16_t>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, total, H, W, C / 8, scale, (const uint16_t*)addend);
   return check_hip(hipGetLastError(), "replicate2x launch");
+}
+
+extern "C" int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream) {
+  return pool_launch(x, nullptr, y, N, Ho, Wo, C, dtype, scale, stream);
+}
+
+extern "C" int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream) {
+  return replicate_launch(x, nullptr, y, N, H, W, C, dtype, scale, stream);
+}
+
+extern "C" int gc_pool2x2_add(const void* x, const void* addend, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale,
+                              void* stream) {
+  if (addend == nullptr) { set_error("resample: null addend"); return GC_BAD_ARGUMENT; }
+  return pool_launch(x, addend, y, N, Ho, Wo, C, dtype, scale, stream);
+}
+
+extern "C" int gc_replicate2x_add(const void* x, const void* addend, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                  float scale, void* stream) {
+  if (addend == nullptr) { set_error("resample: null addend"); return GC_BAD_ARGUMENT; }
+  return replicate_launch(x, addend, y, N, H, W, C, dtype, scale, stream);
 }

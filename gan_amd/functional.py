@@ -9,6 +9,8 @@ Same argument meaning as torch.nn.functional (ints or pairs).  Geometry the MI35
 (dilation > 1, groups > 1, anisotropic stride/padding, string padding) raises RuntimeError -- there is no
 fallback to another backend.
 """
+import os
+
 import torch
 
 from . import ops
@@ -175,3 +177,21 @@ def upsample_nearest2x(input):
     if input.shape[1] % 8:
         return torch.nn.functional.interpolate(input, scale_factor=2, mode="nearest")
     return ops.replicate2x(input, 1.0)
+
+
+_FUSED_SUMS = os.environ.get("GC_NO_RESAMPLE_ADD") is None
+
+
+def avg_pool2x2_add(input, addend):
+    """avg_pool2x2(input) + addend as one sweep where the fused kernel applies (otherwise the plain pair)."""
+    if (not _FUSED_SUMS or input.shape[1] % 8 or input.shape[2] % 2 or input.shape[3] % 2 or addend.dtype != input.dtype
+            or not input.is_cuda):
+        return avg_pool2x2(input) + addend
+    return ops.pool2x2_add(input, addend, 0.25)
+
+
+def upsample_nearest2x_add(input, addend):
+    """upsample_nearest2x(input) + addend as one sweep where the fused kernel applies (otherwise the plain pair)."""
+    if not _FUSED_SUMS or input.shape[1] % 8 or addend.dtype != input.dtype or not input.is_cuda:
+        return upsample_nearest2x(input) + addend
+    return ops.replicate2x_add(input, addend, 1.0)

@@ -196,7 +196,7 @@ class GeneratorBlock(torch.nn.Module):
             h = self.conv_1(self.batch_norm_1(x, y), upsample=True)
         h = self.conv_2(self.batch_norm_2(h, y))
         # (a 1x1 convolution commutes with the replication: it runs on the small image)
-        return h + GF.upsample_nearest2x(self.residual_conv(x))
+        return GF.upsample_nearest2x_add(self.residual_conv(x), h)       # h + the up-sampled shortcut, one sweep
 
 
 class _ReluDerivativeLater(torch.autograd.Function):
@@ -230,7 +230,7 @@ class DiscriminatorBlock(torch.nn.Module):
         h = self.conv_1(a, activation="relu", defer=second, in_slope=0.0 if first else None)
         h = self.conv_2(h, in_slope=0.0 if second else None)
         if self.pool:
-            return GF.avg_pool2x2(h) + self.residual_conv(GF.avg_pool2x2(x))
+            return GF.avg_pool2x2_add(h, self.residual_conv(GF.avg_pool2x2(x)))      # pooled h + shortcut, one sweep
         return h + self.residual_conv(x)
 
 

@@ -1893,8 +1893,55 @@ def _(x, scale):
     return x.new_empty(N, C, 2 * H, 2 * W)
 
 
+def _resample_add(fn_name, x, addend, scale, H, W):
+    _check_cuda(x, addend)
+    x, addend = _nhwc(x), _nhwc(addend)
+    if addend.dtype != x.dtype:
+        raise RuntimeError("ganconv: the addend must have the input's dtype")
+    N, C = x.shape[0], x.shape[1]
+    y = torch.empty_like(addend, memory_format=torch.channels_last)
+    _lib.check(getattr(_lib.lib(), fn_name)(_ptr(x), _ptr(addend), _ptr(y), N, H, W, C, _dtype_code(x), scale, _stream()), fn_name)
+    return y
+
+
+@torch.library.custom_op("ganconv::pool2x2_add", mutates_args=())
+def pool2x2_add(x: Tensor, addend: Tensor, scale: float) -> Tensor:
+    """scale * (sum over 2x2 blocks of x) + addend in one sweep (a residual block's sum behind its pooling)."""
+    N, C, H, W = x.shape
+    if H % 2 or W % 2 or tuple(addend.shape) != (N, C, H // 2, W // 2):
+        raise RuntimeError("ganconv: pool2x2_add needs even extents and an addend of the pooled shape")
+    return _resample_add("gc_pool2x2_add", x, addend, scale, H // 2, W // 2)
+
+
+@pool2x2_add.register_fake
+def _(x, addend, scale):
+    return torch.empty_like(addend)
+
+
+@torch.library.custom_op("ganconv::replicate2x_add", mutates_args=())
+def replicate2x_add(x: Tensor, addend: Tensor, scale: float) -> Tensor:
+    """scale * (every pixel of x repeated 2x2) + addend in one sweep (a residual block's sum behind its up-sampled shortcut)."""
+    N, C, H, W = x.shape
+    if tuple(addend.shape) != (N, C, 2 * H, 2 * W):
+        raise RuntimeError("ganconv: replicate2x_add needs an addend of the up-sampled shape")
+    return _resample_add("gc_replicate2x_add", x, addend, scale, H, W)
+
+
+@replicate2x_add.register_fake
+def _(x, addend, scale):
+    return torch.empty_like(addend)
+
+
 def _scale_ctx(ctx, inputs, output):
     ctx.scale = inputs[1]
+
+
+def _scale_add_ctx(ctx, inputs, output):
+    ctx.scale = inputs[2]
+
+
+torch.library.register_autograd("ganconv::pool2x2_add", lambda ctx, g: (replicate2x(g, ctx.scale), g, None), setup_context=_scale_add_ctx)
+torch.library.register_autograd("ganconv::replicate2x_add", lambda ctx, g: (pool2x2(g, ctx.scale), g, None), setup_context=_scale_add_ctx)
 
 
 torch.library.register_autograd("ganconv::pool2x2", lambda ctx, g: (replicate2x(g, ctx.scale), None), setup_context=_scale_ctx)

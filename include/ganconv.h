@@ -353,6 +353,13 @@ int gc_reflect_pad_adjoint(const void* gy, void* gx, int32_t N, int32_t H, int32
  * aten::upsample_nearest2d(_backward) at BigGAN/model.py:117,188 and StyleGAN/model.py:247,440. */
 int gc_pool2x2(const void* x, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale, void* stream);
 int gc_replicate2x(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale, void* stream);
+/* The same sweeps with the residual sum of a block in them (BigGAN/model.py:131-133 `h + residual`, :196-200 after the
+ * pooling): y = scale * pool(x) + addend  and  y = scale * replicate(x) + addend, `addend` of y's shape and dtype; one
+ * rounding of the sum instead of two. */
+int gc_pool2x2_add(const void* x, const void* addend, void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, float scale,
+                   void* stream);
+int gc_replicate2x_add(const void* x, const void* addend, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, float scale,
+                       void* stream);
 
 /* Channel concatenation of two NHWC tensors of one gc_dtype fused with the (Leaky)ReLU behind it, and its adjoint:
  *   gc_act_concat_fwd   y[p, 0..Ca) = act(a[p, :]), y[p, Ca..Ca+Cb) = act(b[p, :]),  act(v) = v > 0 ? v : slope * v
