@@ -104,8 +104,10 @@ def pix2pix_unet(device, batch=8, ch=64, size=256, reducer_factory=None, data_se
     oG = optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999)).repack_after_step(G)
     oD = optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999)).repack_after_step(D)
     _reseed(data_seed)
-    real = torch.rand(batch, 3, size, size, device=device) * 2 - 1
-    label = torch.rand(batch, 3, size, size, device=device)
+    # (channels-last, as gan_amd.data.ImageBatcher hands its batches over: the pair the critic reads is then built in the
+    #  convolutions' own layout)
+    real = (torch.rand(batch, 3, size, size, device=device) * 2 - 1).contiguous(memory_format=torch.channels_last)
+    label = torch.rand(batch, 3, size, size, device=device).contiguous(memory_format=torch.channels_last)
 
     def phase_D(arm):
         return (pix2pix.discriminator_phase(G, D, real, label, on_last_backward=arm),)
@@ -137,7 +139,7 @@ def stylegan_v1(device, batch=32, pg=6, reducer_factory=None, data_seed=None):
     oG.repack_after_step(G)
     oD = optim.Adam(D.parameters(), lr=lr, betas=(0.0, 0.9)).repack_after_step(D)
     _reseed(data_seed)
-    real = torch.rand(batch, 3, res, res, device=device) * 2 - 1
+    real = (torch.rand(batch, 3, res, res, device=device) * 2 - 1).contiguous(memory_format=torch.channels_last)
     zs = torch.randn(4, batch, 512, device=device)
     eps = torch.rand(batch, 1, 1, 1, device=device)
     cross = min(3, pg)
@@ -169,7 +171,7 @@ def biggan_128(device, batch=256, ch=64, n_classes=10, reducer_factory=None, dat
     oG.average_into(averaged_G, G, 0.9999)                                # BigGAN/train.py:83
     oD = optim.Adam(D.parameters(), lr=5e-5, betas=(0.0, 0.999))
     _reseed(data_seed)
-    real = torch.rand(batch, 3, 128, 128, device=device) * 2 - 1
+    real = (torch.rand(batch, 3, 128, 128, device=device) * 2 - 1).contiguous(memory_format=torch.channels_last)
     z1, z2 = torch.rand(batch, 120, device=device), torch.rand(batch, 120, device=device)      # torch.rand: BigGAN/train.py:182
     lab = torch.randint(0, n_classes, (3, batch), device=device)
 
