@@ -20,7 +20,7 @@ EXPORTS = (
     "gc_version", "gc_last_error", "gc_packed_weight_bytes", "gc_pack_weight", "gc_conv2d_fprop", "gc_conv2d_dgrad",
     "gc_wgrad_workspace_bytes", "gc_workspace_bytes", "gc_fused_upsample_weight", "gc_conv2d_wgrad", "gc_wgrad_sums_bias", "gc_conv2d_wgrad_noalloc", "gc_noalloc_scratch", "gc_dwblur3x3", "gc_dwblur3x3_masked", "gc_profile_enable", "gc_profile_collect",
     "gc_instnorm_act_fwd", "gc_instnorm_act_bwd", "gc_instnorm_act_bwd_bwd",
-    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_fwd_rows", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_channel_sum_workspace_bytes", "gc_channel_sum", "gc_act_backward_channel_sum", "gc_batchnorm_stats", "gc_batchnorm_act_bwd_sums", "gc_batchnorm_act_bwd_apply", "gc_adam_step", "gc_adam_ema_step", "gc_set_split_reduction", "gc_set_patch_kernel", "gc_pack_weights", "gc_attention_fwd", "gc_attention_bwd", "gc_attention_residual_fwd", "gc_attention_residual_workspace_bytes", "gc_attention_residual_bwd", "gc_pool2x2", "gc_replicate2x", "gc_pool2x2_add", "gc_replicate2x_add", "gc_reflect_pad", "gc_reflect_pad_adjoint",
+    "gc_batchnorm_workspace_bytes", "gc_batchnorm_act_fwd", "gc_batchnorm_act_fwd_rows", "gc_batchnorm_act_bwd", "gc_batchnorm_update_running", "gc_channel_sum_workspace_bytes", "gc_channel_sum", "gc_act_backward_channel_sum", "gc_batchnorm_stats", "gc_batchnorm_act_bwd_sums", "gc_batchnorm_act_bwd_apply", "gc_adam_step", "gc_adam_ema_step", "gc_set_split_reduction", "gc_set_patch_kernel", "gc_pack_weights", "gc_pack_weights_div", "gc_attention_fwd", "gc_attention_bwd", "gc_attention_residual_fwd", "gc_attention_residual_workspace_bytes", "gc_attention_residual_bwd", "gc_pool2x2", "gc_replicate2x", "gc_pool2x2_add", "gc_replicate2x_add", "gc_reflect_pad", "gc_reflect_pad_adjoint",
     "gc_cond_batchnorm_workspace_bytes", "gc_cond_batchnorm_act_fwd", "gc_cond_batchnorm_act_fwd_rows", "gc_cond_batchnorm_act_bwd", "gc_noise_lrelu_adain_workspace_bytes", "gc_noise_lrelu_adain_fwd", "gc_noise_lrelu_adain_bwd",
     "gc_wgrad_multi_workspace_bytes", "gc_conv2d_wgrad_multi",
     "gc_channel_scale", "gc_rowdot_workspace_bytes", "gc_rowdot", "gc_modulated_act_backward_workspace_bytes",
@@ -60,6 +60,7 @@ def lib():
     L.gc_set_split_reduction.argtypes = [ctypes.c_int]
     L.gc_set_patch_kernel.argtypes = [ctypes.c_int]
     L.gc_pack_weights.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    L.gc_pack_weights_div.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.gc_noise_lrelu_adain_workspace_bytes.argtypes = [i32, i32, i32]
     L.gc_noise_lrelu_adain_workspace_bytes.restype = ctypes.c_size_t
     L.gc_noise_lrelu_adain_fwd.argtypes = [vp] * 9 + [ctypes.c_size_t] + [i32] * 4 + [ctypes.c_float, ctypes.c_float, vp]

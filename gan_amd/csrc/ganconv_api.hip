@@ -98,6 +98,7 @@ struct PackJob {
   int64_t s_co, s_ci, s_r, s_s;
   int32_t rows, cols, colp, pitch, kh, kw, transpose, planes;
   float alpha;
+  const float* div;          // null, or one float in device memory: the image holds (alpha * w) / *div
   uint32_t block0;
   int32_t taps_contiguous;   // the kh * kw taps of a (co, ci) pair are consecutive floats: 1, or 4 when also 16-byte aligned in fours
 };
@@ -109,6 +110,10 @@ struct PackJob {
 __device__ __forceinline__ void pack_job(const PackJob& q, uint32_t blk, uint32_t nb) {
   const size_t total = (size_t)q.rows * q.pitch;
   const int taps = q.kh * q.kw;
+  // (a true division, as the tensor expression w / sigma rounds: the image equals the one packed from that tensor)
+  const bool divided = q.div != nullptr;
+  const float dv = divided ? *q.div : 1.f;
+  auto scaled = [&](float v) { v *= q.alpha; return divided ? v / dv : v; };
   auto put = [&](size_t e, float v) {
     const uint16_t hi = float_to_bf16_bits(v);
     q.dst[e] = hi;
@@ -129,10 +134,10 @@ __device__ __forceinline__ void pack_job(const PackJob& q, uint32_t blk, uint32_
         for (int tap = 0; tap < taps; tap += 4) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(src + tap);
 #pragma unroll
-          for (int i = 0; i < 4; i++) put(e0 + (size_t)(tap + i) * q.colp, q.alpha * v[i]);
+          for (int i = 0; i < 4; i++) put(e0 + (size_t)(tap + i) * q.colp, scaled(v[i]));
         }
       } else {
-        for (int tap = 0; tap < taps; tap++) put(e0 + (size_t)tap * q.colp, q.alpha * src[tap]);
+        for (int tap = 0; tap < taps; tap++) put(e0 + (size_t)tap * q.colp, scaled(src[tap]));
       }
     }
     const int tail0 = taps * q.colp, tail = q.pitch - tail0;       // zeros behind the last tap of every row
@@ -149,7 +154,7 @@ __device__ __forceinline__ void pack_job(const PackJob& q, uint32_t blk, uint32_
     float v = 0.f;
     if (col < q.cols && tap < taps) {
       const int co = q.transpose ? col : row, ci = q.transpose ? row : col;
-      v = q.alpha * q.w[co * q.s_co + ci * q.s_ci + (tap / q.kw) * q.s_r + (tap % q.kw) * q.s_s];
+      v = scaled(q.w[co * q.s_co + ci * q.s_ci + (tap / q.kw) * q.s_r + (tap % q.kw) * q.s_s]);
     }
     put(e, v);
   }
@@ -557,6 +562,7 @@ static size_t fill_pack_job(gc::PackJob& q, const gc_conv_desc* d, int pass, con
   q.colp = g.icp; q.pitch = g.row_pitch; q.kh = d->kh; q.kw = d->kw;
   q.planes = d->precision == GC_PREC_F32X3 ? 2 : 1;
   q.alpha = alpha;
+  q.div = nullptr;
   q.block0 = 0;
   const int taps = d->kh * d->kw;
   q.taps_contiguous = 0;
@@ -584,8 +590,8 @@ int gc_pack_weight(const gc_conv_desc* d, int pass, const float* w, const int64_
   return check_hip(hipGetLastError(), "pack_weight launch");
 }
 
-int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
-                    const float* alphas, void* const* packed, void* stream) {
+static int pack_weights_run(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
+                            const float* alphas, const float* const* divisors, void* const* packed, void* stream) {
   if (n < 0 || (n > 0 && (descs == nullptr || passes == nullptr || ws == nullptr || w_strides == nullptr || packed == nullptr))) {
     set_error("gc_pack_weights: null pointer"); return GC_BAD_ARGUMENT;
   }
@@ -606,6 +612,7 @@ int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes,
       PackJob& q = t.job[j];
       size_t nb = fill_pack_job(q, d, pass, ws[base + j], w_strides + 4 * (size_t)(base + j), alphas != nullptr ? alphas[base + j] : 1.f,
                                 packed[base + j]);
+      q.div = divisors != nullptr ? divisors[base + j] : nullptr;
       q.block0 = blocks;
       if (nb > 512) nb = 512;
       if (nb < 1) nb = 1;
@@ -617,6 +624,16 @@ int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes,
     if (check_hip(hipGetLastError(), "pack_weights launch")) return GC_HIP_ERROR;
   }
   return GC_OK;
+}
+
+int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
+                    const float* alphas, void* const* packed, void* stream) {
+  return pack_weights_run(n, descs, passes, ws, w_strides, alphas, nullptr, packed, stream);
+}
+
+int gc_pack_weights_div(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
+                        const float* alphas, const float* const* divisors, void* const* packed, void* stream) {
+  return pack_weights_run(n, descs, passes, ws, w_strides, alphas, divisors, packed, stream);
 }
 
 int gc_conv2d_fprop(const gc_conv_desc* d, const void* x, const void* packed_w, void* y, const gc_epilogue* ep, void* stream) {

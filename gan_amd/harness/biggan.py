@@ -23,6 +23,7 @@ weights.  Phases: hinge loss of BasicGANs/loss_functions.py:79-99, step order an
 BigGAN/train.py:115-127, 187-226.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn.functional as TF
@@ -35,7 +36,8 @@ from .. import ops
 GENERATOR_PLAN = ((16, 16), (16, 8), (8, 4), (4, 2), "attention", (2, 1))                  # BigGAN/model.py:147-154
 CRITIC_PLAN = ((None, 1, True), "attention", (1, 2, True), (2, 4, True), (4, 8, True), (8, 16, True), (16, 16, False))   # :212-220
 
-_opt = {"dtype": None, "fused_attention": False, "fused_norm": True, "defer": True}
+_opt = {"dtype": None, "fused_attention": False, "fused_norm": True, "defer": True,
+        "divided_pack": os.environ.get("GC_NO_DIVIDED_PACK") is None}
 
 
 def set_activation_dtype(dtype):
@@ -52,6 +54,12 @@ def set_deferred_activations(on):
     _opt["defer"] = bool(on)
 
 
+def set_divided_pack(on):
+    """Whether the convolutions' packed weight images are divided by sigma when they are packed, all layers of a network in
+    one launch per forward pass (default), or every forward call forms the tensor weight / sigma and packs it."""
+    _opt["divided_pack"] = bool(on)
+
+
 def set_fused_norm(on):
     """Training-mode (conditional) BatchNorm + ReLU on the fused normalisation kernels (default) or on torch ops."""
     _opt["fused_norm"] = bool(on)
@@ -64,6 +72,7 @@ def _sigma(layer):
     ahead = layer.__dict__.pop("_sigma_ahead", None)      # computed for the whole network in front of this forward pass
     if ahead is not None and ahead[1] == layer.weight._version:      # (a sigma left over from a pass that skipped this layer,
         return ahead[0]                                               #  or from before the weights moved, is not used)
+    layer.__dict__.pop("_divided", None)                  # (its packed images hold another sigma than the one made below)
     if layer.weight.is_cuda and layer.norm == 2 and layer.weight.dtype == torch.float32:
         return ops.spectral_sigma_(layer.weight, layer.U_vector, layer.n_iterations)       # four launches per iteration
     with torch.no_grad():
@@ -76,7 +85,7 @@ def _sigma(layer):
     return s
 
 
-def _sigmas_ahead(net):
+def _sigmas_ahead(net, need_backward=True):
     """One power iteration per spectrally normalised layer of `net`, all layers in one set of launches; each layer's next
     forward call takes its sigma from here instead of iterating itself (same values: the weights do not move inside a
     forward pass).  Layers that cannot take part (CPU, another norm) keep iterating in their own forward call."""
@@ -95,6 +104,39 @@ def _sigmas_ahead(net):
     sig = st.refresh()
     for i, m in enumerate(layers):
         m.__dict__["_sigma_ahead"] = (sig[i], m.weight._version)
+    if _opt["divided_pack"]:
+        # the packed images of the convolutions' weights, divided by the new sigmas, in one launch; each convolution is then
+        # called with its weight itself (_OverSigma).  Not for the up-sampling convolutions: their image is packed from the
+        # folded 4 x 4 filter, a tensor of its own per call.
+        idx = [i for i, m in enumerate(layers) if isinstance(m, Conv2d) and not m.__dict__.get("_upsampling")]
+        if idx:
+            convs = [layers[i] for i in idx]
+            epoch = ops.repack_divided([m._wkey_for(m.weight) for m in convs], [m.weight for m in convs], sig, idx,
+                                       forward_only=not need_backward)
+            for m in convs:
+                m.__dict__["_divided"] = epoch
+
+
+class _OverSigma(torch.autograd.Function):
+    """The weight itself, standing for weight / sigma in a convolution whose packed images were divided by sigma when they
+    were packed (ops.repack_divided); the gradient that comes back is the one with respect to weight / sigma and is divided
+    here (sigma is a constant of the backward pass, BigGAN/model.py:27-35).  The images of a layer are those of its LATEST
+    forward pass: a backward pass through an earlier one would have read the wrong sigma and is refused."""
+
+    @staticmethod
+    def forward(ctx, weight, sigma, key, epoch):
+        ctx.save_for_backward(sigma)
+        ctx.key, ctx.epoch = key, epoch
+        return weight.view_as(weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ops.divisor_epoch(ctx.key) != ctx.epoch:
+            raise RuntimeError("ganconv: backward pass through a spectrally normalised convolution that has run another forward pass "
+                               "since (its packed weights follow the latest sigma); run each backward pass before the layer's next "
+                               "forward pass, or biggan.set_divided_pack(False)")
+        (sigma,) = ctx.saved_tensors
+        return g / sigma, None, None, None
 
 
 class Conv2d(gnn.Conv2d):
@@ -112,9 +154,17 @@ class Conv2d(gnn.Conv2d):
         the ReLU's derivative is applied by the data-gradient kernel of the one convolution that reads the activated tensor
         (functional.conv2d's defer_activation_grad / input_activation_slope)."""
         out_dtype = out_dtype if out_dtype is not None else _opt["dtype"]
+        sigma = _sigma(self)
+        epoch = self.__dict__.pop("_divided", None)
         if upsample:
-            return GF.upsample2x_conv3x3(x, self.weight / _sigma(self), self.bias, activation=activation, out_dtype=out_dtype)
-        return GF.conv2d(x, self.weight / _sigma(self), self.bias, self.stride, self.padding, self.dilation, self.groups,
+            self.__dict__["_upsampling"] = True
+            return GF.upsample2x_conv3x3(x, self.weight / sigma, self.bias, activation=activation, out_dtype=out_dtype)
+        key = self._wkey_for(self.weight) if epoch is not None else 0
+        if key and ops.divisor_epoch(key) == epoch:
+            weight = _OverSigma.apply(self.weight, sigma, key, epoch)
+        else:
+            weight, key = self.weight / sigma, 0
+        return GF.conv2d(x, weight, self.bias, self.stride, self.padding, self.dilation, self.groups, _wkey=key,
                          activation=activation, out_dtype=out_dtype, defer_activation_grad=defer, input_activation_slope=in_slope)
 
 
@@ -245,7 +295,7 @@ class Generator(torch.nn.Module):
         self.to_RGB_layer = Conv2d(ch, 3, 1)
 
     def forward(self, latent_vector, y):
-        _sigmas_ahead(self)
+        _sigmas_ahead(self, torch.is_grad_enabled() and (latent_vector.requires_grad or self.to_RGB_layer.weight.requires_grad))
         chunks = latent_vector.split(20, dim=1)            # the first feeds the 4x4 seed, one more per residual block
         klass = self.linear_y(y)
         h = self.linear_z(chunks[0]).reshape(latent_vector.shape[0], -1, 4, 4)
@@ -276,7 +326,7 @@ class Discriminator(torch.nn.Module):
         self.projection_layer = Linear(16 * ch, 1)
 
     def forward(self, x, y):
-        _sigmas_ahead(self)
+        _sigmas_ahead(self, torch.is_grad_enabled() and (x.requires_grad or self.projection_layer.weight.requires_grad))
         h = x
         for block in self.main_sequence:
             h = block(h)

@@ -16,6 +16,8 @@ options of the harnesses are on: bf16 activation storage, fused normalisation.  
 
 Every step keeps the loss terms of its phases in `step.losses` (a device tensor; bench.py checks that they are finite).
 """
+import os
+
 import torch
 
 from .. import ops, optim
@@ -188,6 +190,9 @@ def biggan_128(device, batch=256, ch=64, n_classes=10, reducer_factory=None, dat
                      f"BigGAN {128}x{128} (ch {ch}, {n_classes} classes), batch {batch}: discriminator update + generator update (hinge loss, "
                      "orthogonal regularisation) with Adam, moving average of the generator", 3, device, reducer_factory, after)
     step.averaged_G = averaged_G
+    # every packed image this step caches belongs to a spectrally normalised convolution and is refreshed in front of each
+    # forward pass (ops.repack_divided): a recording may keep the images of the warm-up
+    step.weight_images_refreshed_in_step = bool(biggan._opt["divided_pack"]) and os.environ.get("GC_BIGGAN_CLEAR_IMAGES") is None
     return step
 
 

@@ -48,6 +48,8 @@ def get_precision():
 # (backward formulas run there): every compound look-up / insert holds _lock.
 _lock = threading.RLock()
 _wcache = {}          # module key -> {(pass, precision, image bytes): _Image}
+_divisors = {}        # module key -> (weight data_ptr, tensor holding the divisors, index into it, epoch): repack_divided
+_div_epoch = [0]
 _next_key = [1]
 
 
@@ -61,6 +63,7 @@ def new_weight_key():
 def drop_weight_key(key):
     with _lock:
         _wcache.pop(key, None)
+        _divisors.pop(key, None)
 
 
 def _dtype_code(t):
@@ -484,15 +487,17 @@ def _dma_ok(t, ic, oc, precision):
 
 class _Image:
     """A cached packed weight image and what it was made from / on."""
-    __slots__ = ("ptr", "version", "shape", "buf", "desc", "wref", "stream", "event", "alpha", "recorded", "done")
+    __slots__ = ("ptr", "version", "shape", "buf", "desc", "wref", "stream", "event", "alpha", "recorded", "done", "div_epoch")
 
-    def mark_packed(self, w):
-        """Called right after a pack launch on the current stream."""
+    def mark_packed(self, w, event=None):
+        """Called right after a pack launch on the current stream (event: one recorded behind a launch that packed several)."""
         self.ptr, self.version, self.shape = w.data_ptr(), w._version, tuple(w.shape)
         st = torch.cuda.current_stream(w.device)
         self.stream = st.cuda_stream
-        self.event = torch.cuda.Event()
-        self.event.record(st)
+        if event is None:
+            event = torch.cuda.Event()
+            event.record(st)
+        self.event = event
         self.recorded = torch.cuda.is_current_stream_capturing()      # the event is a node of a graph being recorded
         self.done = False
 
@@ -518,28 +523,96 @@ def _packed(desc, w, pass_, wkey, alpha=1.0):
     ik = (pass_, int(desc.precision), int(nbytes))
     alpha = float(alpha)
     with _lock:
+        # a key registered by repack_divided: the image of this weight holds (alpha * w) / divisor, current as of `epoch`
+        dv = _divisors.get(wkey) if wkey else None
+        if dv is not None and (dv[0] != w.data_ptr() or w.dtype != torch.float32):
+            dv = None
+        epoch = dv[3] if dv is not None else 0
+
+        def pack(w32, dst):
+            if dv is None:
+                _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w32.data_ptr()), _lib.strides4(w32), alpha,
+                                            ctypes.c_void_p(dst.data_ptr()), _stream()), "gc_pack_weight")
+            else:
+                _pack_divided([(desc, pass_, w32, alpha, dv[1].data_ptr() + 4 * dv[2], dst)])
+
         if wkey:
             ent = _wcache.get(wkey, {}).get(ik)
             if ent is not None and ent.ptr == w.data_ptr() and ent.shape == tuple(w.shape):
-                if ent.version == w._version and ent.alpha == alpha:
+                if ent.version == w._version and ent.alpha == alpha and ent.div_epoch == epoch:
                     return ent.ready(w)
                 if w.dtype == torch.float32:
                     # same storage, new values: refresh the image in place (keeps repack() able to find it)
-                    _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w.data_ptr()), _lib.strides4(w), alpha,
-                                                ctypes.c_void_p(ent.buf.data_ptr()), _stream()), "gc_pack_weight")
-                    ent.alpha = alpha
+                    pack(w, ent.buf)
+                    ent.alpha, ent.div_epoch = alpha, epoch
                     ent.mark_packed(w)
                     return ent.buf
         w32 = w if w.dtype == torch.float32 else w.float()
         buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        _lib.check(L.gc_pack_weight(ctypes.byref(desc), pass_, ctypes.c_void_p(w32.data_ptr()), _lib.strides4(w32), alpha,
-                                    ctypes.c_void_p(buf.data_ptr()), _stream()), "gc_pack_weight")
+        pack(w32, buf)
         if wkey:
             ent = _Image()
-            ent.buf, ent.desc, ent.wref, ent.alpha = buf, ConvDesc.from_buffer_copy(desc), weakref.ref(w), alpha
+            ent.buf, ent.desc, ent.wref, ent.alpha, ent.div_epoch = buf, ConvDesc.from_buffer_copy(desc), weakref.ref(w), alpha, epoch
             ent.mark_packed(w)
             _wcache.setdefault(wkey, {})[ik] = ent
         return buf
+
+
+def _pack_divided(jobs):
+    """One gc_pack_weights_div launch (per 24 images) for jobs of (descriptor, pass, fp32 weight, alpha, device address of the
+    divisor, destination)."""
+    n = len(jobs)
+    descs = (ConvDesc * n)(*[j[0] for j in jobs])
+    passes = (ctypes.c_int32 * n)(*[j[1] for j in jobs])
+    ws = (ctypes.c_void_p * n)(*[j[2].data_ptr() for j in jobs])
+    strides = (ctypes.c_int64 * (4 * n))(*[s_ for j in jobs for s_ in j[2].stride()])
+    alphas = (ctypes.c_float * n)(*[j[3] for j in jobs])
+    divs = (ctypes.c_void_p * n)(*[j[4] for j in jobs])
+    packed = (ctypes.c_void_p * n)(*[j[5].data_ptr() for j in jobs])
+    _lib.check(_lib.lib().gc_pack_weights_div(n, descs, passes, ws, strides, alphas, divs, packed, _stream()), "gc_pack_weights_div")
+
+
+def repack_divided(wkeys, weights, divisors, index=None, forward_only=False):
+    """Registers divisors[index[i]] (index None: divisors[i]; an element of one fp32 device tensor: the sigma of a spectral norm)
+    as the divisor of the packed images of weights[i] (module key wkeys[i]) and refreshes, in ONE launch, every image those keys have cached: the
+    convolutions that follow are called with the WEIGHT ITSELF (a view of it, see divisor_epoch) and find images of
+    weight / divisor without the tensor weight / divisor and without a pack launch of their own.  An image that does not
+    exist yet is packed with the divisor at its first use, and so is a data-gradient image left out here (forward_only: a
+    pass that no backward pass will follow).  Returns the epoch of this registration: the images are those of
+    THIS call's divisors until the next call for the same keys."""
+    with _lock:
+        _div_epoch[0] += 1
+        epoch = _div_epoch[0]
+        jobs, ents = [], []
+        if divisors.dtype != torch.float32 or not divisors.is_contiguous() or not divisors.is_cuda:
+            raise RuntimeError("ganconv: repack_divided takes the divisors as one contiguous fp32 device tensor")
+        for j, (key, w) in enumerate(zip(wkeys, weights)):
+            i = j if index is None else int(index[j])
+            if not key:
+                continue
+            _divisors[key] = (w.data_ptr(), divisors, i, epoch)
+            for ik, ent in _wcache.get(key, {}).items():
+                if w.dtype != torch.float32 or w.data_ptr() != ent.ptr or tuple(w.shape) != ent.shape:
+                    continue
+                if forward_only and ik[0] != _lib.GC_PASS_FPROP:
+                    continue          # (stays at its old epoch: refreshed at its next use, should there be one)
+                jobs.append((ent.desc, ik[0], w, ent.alpha, divisors.data_ptr() + 4 * i, ent.buf))
+                ents.append((ent, w))
+        if jobs:
+            _pack_divided(jobs)
+            st = torch.cuda.current_stream(jobs[0][2].device)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            for ent, w in ents:
+                ent.div_epoch = epoch
+                ent.mark_packed(w, ev)
+        return epoch
+
+
+def divisor_epoch(wkey):
+    """Epoch of the divisor the images of `wkey` hold now (0: none registered)."""
+    dv = _divisors.get(wkey)
+    return dv[3] if dv is not None else 0
 
 
 def weight_images_settled():
@@ -559,6 +632,8 @@ def repack(wkeys):
     with _lock:
         jobs = []
         for key in wkeys:
+            if key in _divisors:          # (refreshed per forward pass by repack_divided)
+                continue
             for ik, ent in _wcache.get(key, {}).items():
                 w = ent.wref()
                 if (w is None or w.dtype != torch.float32 or w.data_ptr() != ent.ptr or tuple(w.shape) != ent.shape

@@ -134,6 +134,13 @@ int gc_pack_weight(const gc_conv_desc* desc, int pass, const float* w, const int
 int gc_pack_weights(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
                     const float* alphas, void* const* packed, void* stream);
 
+/* gc_pack_weights with a divisor per entry that lives in DEVICE memory: divisors[i] is NULL or points to one float, and
+ * image i holds (alphas[i] * w) / *divisors[i], rounded as the tensor expression w / sigma rounds.  For the spectral norm
+ * (BigGAN/model.py:20-35: the weight of every forward call is W / sigma(W), sigma a device scalar that the power iteration
+ * has just advanced): all images of a network in one launch per forward pass, without the tensors W / sigma. */
+int gc_pack_weights_div(int32_t n, const gc_conv_desc* descs, const int32_t* passes, const float* const* ws, const int64_t* w_strides,
+                        const float* alphas, const float* const* divisors, void* const* packed, void* stream);
+
 /* y = conv2d(x, w) [+ bias, activation, statistics].  Replaces aten::convolution (forward) behind
  *   torch.nn.Conv2d        BasicGANs/models.py:77; Pix2Pix/models.py:17,83,225-232; StyleGAN/model.py:72
  *   F.conv2d               BigGAN/model.py:56-58

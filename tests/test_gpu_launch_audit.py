@@ -57,8 +57,12 @@ class Audit:
             t = t.to(torch.bfloat16)
         return t.double().cpu()
 
-    def _weight(self, w, alpha, precision):
+    def _weight(self, w, alpha, precision, wkey=0):
+        ptr = w.data_ptr()
         w = w.detach().float() * float(alpha)          # the pack kernel's product, in fp32
+        dv = self.ops._divisors.get(wkey) if wkey else None
+        if dv is not None and dv[0] == ptr:            # a spectrally normalised layer: the image holds weight / sigma
+            w = w / dv[1][dv[2]]
         if precision == self.L.GC_PREC_BF16:
             w = w.to(torch.bfloat16)
         return w.double().cpu()
@@ -94,30 +98,30 @@ class Audit:
                     x_act_slope=-1.0):
         y = self.saved["conv_fprop"](x, w, bias, stride, padding, precision, wkey, act, slope, out_dtype, alpha, defer_act_grad, x_act_slope)
         idx = self._sample(x.shape[0], 2.0 * y[0].numel() * w[0].numel())
-        xr, wr = self._operand(x[idx], precision), self._weight(w, alpha, precision)
+        xr, wr = self._operand(x[idx], precision), self._weight(w, alpha, precision, wkey)
         ref = torch.nn.functional.conv2d(xr, wr, None if bias is None else bias.detach().double().cpu(), stride, padding)
         self._judge("conv_fprop", y[idx], self._act(ref, act, slope), precision, f"x {tuple(x.shape)} w {tuple(w.shape)} s{stride} p{padding} act {act}")
         return y
 
-    def _dgrad_ref(self, gy, w, bias, H, W, stride, padding, precision, alpha, idx):
+    def _dgrad_ref(self, gy, w, bias, H, W, stride, padding, precision, alpha, idx, wkey=0):
         kh = w.shape[2]
         op_h = H - ((gy.shape[2] - 1) * stride - 2 * padding + kh)
         op_w = W - ((gy.shape[3] - 1) * stride - 2 * padding + w.shape[3])
-        gr, wr = self._operand(gy[idx], precision), self._weight(w, alpha, precision)
+        gr, wr = self._operand(gy[idx], precision), self._weight(w, alpha, precision, wkey)
         return torch.nn.functional.conv_transpose2d(gr, wr, None if bias is None else bias.detach().double().cpu(), stride, padding,
                                                     output_padding=(op_h, op_w))
 
     def _conv_dgrad(self, gy, w, bias, H, W, stride, padding, precision, wkey, act=0, slope=0.0, out_dtype=-1, alpha=1.0):
         gx = self.saved["conv_dgrad"](gy, w, bias, H, W, stride, padding, precision, wkey, act, slope, out_dtype, alpha)
         idx = self._sample(gy.shape[0], 2.0 * gy[0].numel() * w[0].numel())
-        ref = self._act(self._dgrad_ref(gy, w, bias, H, W, stride, padding, precision, alpha, idx), act, slope)
+        ref = self._act(self._dgrad_ref(gy, w, bias, H, W, stride, padding, precision, alpha, idx, wkey), act, slope)
         self._judge("conv_dgrad", gx[idx], ref, precision, f"gy {tuple(gy.shape)} w {tuple(w.shape)} s{stride} p{padding} act {act}")
         return gx
 
     def _conv_dgrad_masked(self, gy, w, x, x_act_slope, stride, padding, precision, wkey, out_dtype=-1, alpha=1.0):
         gx = self.saved["conv_dgrad_masked"](gy, w, x, x_act_slope, stride, padding, precision, wkey, out_dtype, alpha)
         idx = self._sample(gy.shape[0], 2.0 * gy[0].numel() * w[0].numel())
-        ref = self._dgrad_ref(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, alpha, idx)
+        ref = self._dgrad_ref(gy, w, None, x.shape[2], x.shape[3], stride, padding, precision, alpha, idx, wkey)
         ref = ref * torch.where(x[idx].detach().double().cpu() > 0, 1.0, float(x_act_slope))
         self._judge("conv_dgrad_masked", gx[idx], ref, precision, f"gy {tuple(gy.shape)} w {tuple(w.shape)} s{stride} p{padding}")
         return gx
