@@ -75,3 +75,32 @@ def test_biggan_critic_with_and_without_divided_images(gan):
             first.sum().backward()
     finally:
         biggan.set_divided_pack(True)
+
+
+def test_recorded_biggan_step_matches_eager_steps(gan):
+    """A reduced-width BigGAN training step recorded as one HIP graph (the recording keeps the packed images of the warm-up,
+    every forward pass refreshes them with its sigmas in one launch) against the same steps run eagerly: the loss terms of
+    the third and fourth step."""
+    from gan_amd.harness import steps as S
+    try:
+        eager = S.biggan_128("cuda:0", batch=4, ch=8, n_classes=4)
+        want = []
+        for _ in range(4):                       # (the eager twin runs first and alone)
+            eager()
+            want.append(eager.losses.clone())
+        torch.cuda.synchronize()
+        del eager
+        gan.ops.clear_weight_cache()
+        step = S.biggan_128("cuda:0", batch=4, ch=8, n_classes=4)
+        assert step.weight_images_refreshed_in_step
+        g = gan.GraphedStep(step, warmup=2)      # steps one and two
+        got = []
+        for _ in range(2):
+            g()
+            got.append(step.losses.clone())
+        torch.cuda.synchronize()
+        for a, b in zip(got, want[2:]):
+            assert bool(torch.isfinite(a).all())
+            assert torch.allclose(a, b, rtol=2e-3, atol=1e-5), (a, b)
+    finally:
+        S.reset_options()
