@@ -163,9 +163,13 @@ def biggan_128(device, batch=256, ch=64, n_classes=10, reducer_factory=None, dat
     torch.manual_seed(5000)
     biggan.set_activation_dtype(torch.bfloat16)
     biggan.set_fused_attention(True)
-    G, D = biggan.Generator(n_classes=n_classes, ch=ch).to(device), biggan.Discriminator(n_classes=n_classes, ch=ch).to(device)
+    # (GC_BIGGAN_INIT_ON_CPU: the QR factorisations of the orthogonal initialisation on the host, for a profiler whose counter
+    #  passes do not survive the solver library's kernels; other values than the device's QR, the same distribution)
+    init_device = "cpu" if os.environ.get("GC_BIGGAN_INIT_ON_CPU") else device
+    G, D = biggan.Generator(n_classes=n_classes, ch=ch).to(init_device), biggan.Discriminator(n_classes=n_classes, ch=ch).to(init_device)
     biggan.orthogonal_init(G)
     biggan.orthogonal_init(D)
+    G, D = G.to(device), D.to(device)
     averaged_G = biggan.Generator(n_classes=n_classes, ch=ch).to(device)
     averaged_G.load_state_dict(G.state_dict())
     averaged_G.train(False)
