@@ -15,7 +15,17 @@ namespace gc {
 namespace {
 
 constexpr int kTH = 4, kTW = 32;                 // output rectangle of a workgroup (a multiple of 4 rows: one or more per wave)
-constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
+
+// S = 2: the 4 x 4 / stride 2 / padding 1 layer above.  S = 1: a 3 x 3 / stride 1 / padding 1 layer on an image (BigGAN's
+// first discriminator block, BigGAN/model.py:181-200 on [B, 3, 128, 128]) with the same machinery: the filter rows are
+// padded to four taps (the fourth and a fourth row hold zeros), so a reduction step is still two filter rows of 4 taps x 4
+// channels, and the patch gets two columns and one row of zeros beyond what the taps with real weights read.
+template <int S>
+struct ImageGeom {
+  static constexpr int K = S == 2 ? 4 : 3;
+  static constexpr int VH = S * kTH + K - S, VW = S * kTW + K - S;      // the part of the patch that holds image data
+  static constexpr int PH = S == 2 ? VH : VH + 1, PW = S == 2 ? VW : VW + 2;
+};
 
 // LEAN: the epilogue's activation is none / ReLU / LeakyReLU with a slope in [0, 1], i.e. max(v, s v) with s = 1 / 0 / slope
 //
@@ -26,9 +36,11 @@ constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 // ICP: channels of a patch pixel (4, or 8 for 5 to 8 input channels -- the PatchGAN's image pair: a filter row per MFMA)
 // MASK: the stored value is multiplied by the derivative of the ReLU / LeakyReLU whose output is p.mask (gc_epilogue.grad_mask:
 // the second-order pass of the critic's first layer, whose result the next layer's masked data gradient would otherwise sweep)
-template <typename TOut, bool LEAN, int NB, int ICP, bool MASK = false>
+template <typename TOut, bool LEAN, int NB, int ICP, bool MASK = false, int S = 2>
 __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams p, int units, int units_per_wg) {
+  static_assert(S == 2 || (S == 1 && ICP == 4 && !MASK), "the stride-1 form: 4-channel patch pixels, no mask");
   constexpr int NKS = ICP / 2;        // reduction steps of 32: 16 taps x ICP channels
+  constexpr int kPH = ImageGeom<S>::PH, kPW = ImageGeom<S>::PW;
   __shared__ __attribute__((aligned(16))) uint16_t patch[2][kPH * kPW * ICP];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c16 = lane & 15;
   const int tiles_w = p.OW / kTW, tiles = tiles_w * (p.OH / kTH);
@@ -50,7 +62,21 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
     for (int ks = 0; ks < NKS; ks++) {
       const u32x4 z = {0u, 0u, 0u, 0u};
       u32x4 v = z;
-      if (ob < nb) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)channel_of(ob, c16) * p.row_pitch + ks * 32 + g * 8);
+      if (S == 2) {
+        if (ob < nb) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)channel_of(ob, c16) * p.row_pitch + ks * 32 + g * 8);
+      } else if (ob < nb) {
+        // the packed row holds [3 x 3 taps][4 channels]; lane group g takes filter row 2 ks + g / 2, taps 2 (g % 2) and + 1
+        const uint16_t* wrow = p.wp + (size_t)channel_of(ob, c16) * p.row_pitch;
+        const int r = 2 * ks + (g >> 1), s0 = 2 * (g & 1);
+        if (r < 3) {
+          const u32x2 a = *reinterpret_cast<const u32x2*>(wrow + (r * 3 + s0) * 4);
+          v[0] = a[0]; v[1] = a[1];
+          if (s0 + 1 < 3) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(wrow + (r * 3 + s0 + 1) * 4);
+            v[2] = b[0]; v[3] = b[1];
+          }
+        }
+      }
       wa[ob][ks] = __builtin_bit_cast(bf16x8, v);
     }
   f32x4 bias_v[NB];
@@ -73,14 +99,15 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
   f32x4 raw[NP][ICP / 4];
   auto load_unit = [&](int u) {
     const int n = u / tiles, r = u - n * tiles, th = r / tiles_w, tw = r - th * tiles_w;
-    const int ih0 = 2 * kTH * th - 1, iw0 = 2 * kTW * tw - 1;       // input coordinates of patch element (0, 0)
+    const int ih0 = S * kTH * th - 1, iw0 = S * kTW * tw - 1;       // input coordinates of patch element (0, 0)
     const float* img = reinterpret_cast<const float*>(p.in) + (size_t)n * p.IH * p.IW * p.IC;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int ih = ih0 + ppr[i], iw = iw0 + ppc[i];
 #pragma unroll
       for (int h = 0; h < ICP / 4; h++) raw[i][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t + i * kThreads < kPH * kPW && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+      if (t + i * kThreads < kPH * kPW && ppr[i] < ImageGeom<S>::VH && ppc[i] < ImageGeom<S>::VW && (unsigned)ih < (unsigned)p.IH &&
+          (unsigned)iw < (unsigned)p.IW) {
         const float* src = img + (uint32_t)((ih * p.IW + iw) * p.IC);
         raw[i][0][0] = src[0];
 #pragma unroll
@@ -118,8 +145,15 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 #pragma unroll
       for (int ks = 0; ks < NKS; ks++) {
         // the 8 reduction elements of lane group g: two pixels of 4 channels (two filter rows per step), or one pixel of 8
-        const int pr = ICP == 4 ? 2 * oh_l + 2 * ks + (g >> 1) : 2 * oh_l + ks, pc = ICP == 4 ? 2 * ow_l + 2 * (g & 1) : 2 * ow_l + g;
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(patch[buf] + (pr * kPW + pc) * ICP);
+        const int pr = ICP == 4 ? S * oh_l + 2 * ks + (g >> 1) : 2 * oh_l + ks, pc = ICP == 4 ? S * ow_l + 2 * (g & 1) : 2 * ow_l + g;
+        bf16x8 b;
+        if (S == 2) {
+          b = *reinterpret_cast<const bf16x8*>(patch[buf] + (pr * kPW + pc) * ICP);
+        } else {          // (two neighbouring pixels, 8-byte aligned: the pixel column is not even)
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(patch[buf] + (pr * kPW + pc) * ICP);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(patch[buf] + (pr * kPW + pc + 1) * ICP);
+          b = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+        }
 #pragma unroll
         for (int ob = 0; ob < NB; ob++)
           if (ob < nb) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob][ks], b, acc[ob], 0, 0, 0);
@@ -187,14 +221,25 @@ __global__ __launch_bounds__(kThreads) void conv_image_kernel(const GatherParams
 
 }  // namespace
 
-// Applies to: fp32 input of at most 4 dense channels (up to 8 with at most 64 output channels), the 4x4 / stride 2 / padding 1 forward pass, up to 128 output
+static bool image_stride1(const GatherParams& p) { return p.T == 9 && p.a == 1; }
+
+// Applies to: fp32 input of at most 4 dense channels (up to 8 with at most 64 output channels), the 4x4 / stride 2 / padding 1 forward pass
+// (or, with at most 4 input and 64 output channels, 3x3 / stride 1 / padding 1), up to 128 output
 // channels in multiples of 16 (more than 64: the data gradient of a generator's image-producing transposed convolution), output extents that tile by 4 x 32, plain epilogue (bias, activation).
 bool plan_image(const GatherParams& p, const GatherLaunch& l) {
   if (l.in_bf16 || l.x3 || l.mode != kThinInput || (p.ICp != 4 && p.ICp != 8) || p.IC > p.ICp || p.in_cstride != p.IC || p.in_coff != 0) return false;
   if (p.ICp == 8 && p.OC > 64) return false;
-  if (p.T != 16 || p.tt.n_classes != 1 || p.a != 2 || p.row_pitch != 16 * p.ICp || p.IH != 2 * p.OH || p.IW != 2 * p.OW) return false;
-  for (int e = 0; e < 16; e++)
-    if (p.tt.dh[e] != e / 4 - 1 || p.tt.dw[e] != e % 4 - 1 || p.tt.wtap[e] != e) return false;
+  if (p.tt.n_classes != 1) return false;
+  if (image_stride1(p)) {
+    static const bool off = getenv("GC_NO_IMAGE_3X3") != nullptr;
+    if (off || p.ICp != 4 || p.OC > 64 || p.row_pitch != 64 || p.IH != p.OH || p.IW != p.OW || p.mask != nullptr) return false;
+    for (int e = 0; e < 9; e++)
+      if (p.tt.dh[e] != e / 3 - 1 || p.tt.dw[e] != e % 3 - 1 || p.tt.wtap[e] != e) return false;
+  } else {
+    if (p.T != 16 || p.a != 2 || p.row_pitch != 16 * p.ICp || p.IH != 2 * p.OH || p.IW != 2 * p.OW) return false;
+    for (int e = 0; e < 16; e++)
+      if (p.tt.dh[e] != e / 4 - 1 || p.tt.dw[e] != e % 4 - 1 || p.tt.wtap[e] != e) return false;
+  }
   if (p.OC % 16 != 0 || p.OC > 128 || p.OH % kTH != 0 || p.OW % kTW != 0 || !p.out_vec) return false;
   // 16-byte stores of 8 channels
   if ((reinterpret_cast<uintptr_t>(p.out) & 15u) != 0 || p.out_cstride % 8 != 0 || p.out_coff % 8 != 0) return false;
@@ -210,7 +255,7 @@ bool plan_image(const GatherParams& p, const GatherLaunch& l) {
 // Whether launch_image applies p.mask itself (the caller then clears it): 4-channel patch pixels, up to 64 output channels,
 // a 16-byte aligned mask (it shares the output's layout).
 bool image_applies_mask(const GatherParams& p) {
-  return p.mask != nullptr && p.ICp == 4 && p.OC <= 64 && p.act == GC_ACT_NONE && (reinterpret_cast<uintptr_t>(p.mask) & 15u) == 0;
+  return p.mask != nullptr && !image_stride1(p) && p.ICp == 4 && p.OC <= 64 && p.act == GC_ACT_NONE && (reinterpret_cast<uintptr_t>(p.mask) & 15u) == 0;
 }
 
 int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hipStream_t stream) {
@@ -227,7 +272,15 @@ int launch_image(const GatherParams& p, const GatherLaunch& l, bool out_f32, hip
   const dim3 grid(blocks);
 #define GC_IMAGE_LAUNCH8(T_, L_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, 4, 8>), grid, dim3(kThreads), 0, stream, p, units, per)
 #define GC_IMAGE_LAUNCH(T_, L_, NB_) hipLaunchKernelGGL((conv_image_kernel<T_, L_, NB_, 4>), grid, dim3(kThreads), 0, stream, p, units, per)
-  if (image_applies_mask(p)) {
+  if (image_stride1(p)) {
+    if (out_f32) {
+      if (lean) hipLaunchKernelGGL((conv_image_kernel<float, true, 4, 4, false, 1>), grid, dim3(kThreads), 0, stream, p, units, per);
+      else hipLaunchKernelGGL((conv_image_kernel<float, false, 4, 4, false, 1>), grid, dim3(kThreads), 0, stream, p, units, per);
+    } else {
+      if (lean) hipLaunchKernelGGL((conv_image_kernel<uint16_t, true, 4, 4, false, 1>), grid, dim3(kThreads), 0, stream, p, units, per);
+      else hipLaunchKernelGGL((conv_image_kernel<uint16_t, false, 4, 4, false, 1>), grid, dim3(kThreads), 0, stream, p, units, per);
+    }
+  } else if (image_applies_mask(p)) {
     if (out_f32) hipLaunchKernelGGL((conv_image_kernel<float, true, 4, 4, true>), grid, dim3(kThreads), 0, stream, p, units, per);
     else hipLaunchKernelGGL((conv_image_kernel<uint16_t, true, 4, 4, true>), grid, dim3(kThreads), 0, stream, p, units, per);
   } else if (p.ICp == 8) {

@@ -14,15 +14,22 @@
 // live across the whole split.  Loads of rectangle i + 1 are in flight while rectangle i is multiplied (two LDS
 // buffers).  At the end the four waves' tiles are added through LDS and leave as one partial tile in the layout of the
 // thin-input kernel ([split][Cout][tap][4 channels]); the common split reduction follows.
+#include <stdlib.h>
+
 #include "conv_wgrad.h"
 
 namespace gc {
 namespace {
 
 constexpr int kTH = 4, kTW = 32, kUnit = kTH * kTW;      // output rectangle = 128 consecutive values of the reduction index
-constexpr int kPH = 2 * kTH + 2, kPW = 2 * kTW + 2;
 constexpr int kGyBytes = kUnit * 128;
-constexpr int patch_bytes(int icp) { return kPH * kPW * 2 * icp; }
+// S = 2: the 4 x 4 / stride 2 / padding 1 layer.  S = 1: a 3 x 3 / stride 1 / padding 1 layer on an image (BigGAN's first
+// discriminator block, BigGAN/model.py:181-200), with the same reads: a filter row is still 4 taps x 4 channels = one block
+// of 16 columns per output pixel (the pixels k .. k + 3 of the patch row), the fourth tap's columns and a fourth filter row
+// are simply not kept; the patch carries two more columns than the three real taps read.
+constexpr int patch_h(int s) { return s == 2 ? 2 * kTH + 2 : kTH + 2; }
+constexpr int patch_w(int s) { return s == 2 ? 2 * kTW + 2 : kTW + 4; }
+constexpr int patch_bytes(int icp, int s) { return patch_h(s) * patch_w(s) * 2 * icp; }
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -39,9 +46,11 @@ __device__ __forceinline__ bf16x8 read_tr(const char* a0, int second_offset) {
 // TX: storage type of the image (uint16_t = bf16, float: rounded to bf16 on the way into the patch)
 // ICP: channels of a patch pixel (4, or 8 for 5 to 8 input channels -- the PatchGAN's image pair, Pix2Pix/models.py:225-232: the
 // 4 taps x 8 channels of a filter row are then two blocks of 16 columns, twice the MFMAs and accumulators)
-template <typename TX, int ICP>
+template <typename TX, int ICP, int S = 2>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradParams p) {
-  constexpr int kPatchBytes = patch_bytes(ICP);
+  static_assert(S == 2 || (S == 1 && ICP == 4), "the stride-1 form: 4-channel patch pixels");
+  constexpr int kPH = patch_h(S), kPW = patch_w(S), NR = S == 2 ? 4 : 3;      // NR: filter rows
+  constexpr int kPatchBytes = patch_bytes(ICP, S);
   constexpr int NH = ICP / 4;                          // 16-column blocks per filter row
   __shared__ __attribute__((aligned(16))) char smem[2 * (kPatchBytes + kGyBytes)];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
         yreg[i] = *reinterpret_cast<const u32x4*>(gy + (k0 + (size_t)(row >> 5) * p.Wo + (row & 31)) * p.y_cstride + p.y_coff + ch * 8);
     }
     const TX* img = x + (size_t)n * p.H * p.W * p.Cin;
-    const int ih0 = 2 * kTH * th - 1, iw0 = 2 * kTW * tw - 1;
+    const int ih0 = S * kTH * th - 1, iw0 = S * kTW * tw - 1;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int ih = ih0 + ppr[i], iw = iw0 + ppc[i];
@@ -141,15 +150,16 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
     for (int i = 0; i < 4; i++)
       if (i < co_blocks) a[i] = read_tr(yb + yrow * 128 + ((i ^ gy_swz(k0)) << 5) + pp8, 4 * 128);
     // output pixel k of the row meets the patch pixels 2k .. 2k + 3 of filter row r: 4 taps x ICP channels, contiguous
+    // (stride 1: the patch pixels k .. k + 3, the fourth being the unused tap)
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < NR; r++)
 #pragma unroll
-      for (int h = 0; h < NH; h++) b[r][h] = read_tr(pb + ((2 * wave + r) * kPW + 2 * k0) * (2 * ICP) + 32 * h + pp8, 4 * 4 * ICP);
+      for (int h = 0; h < NH; h++) b[r][h] = read_tr(pb + ((S * wave + r) * kPW + S * k0) * (2 * ICP) + 32 * h + pp8, 4 * S * 2 * ICP);
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (i < co_blocks)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < NR; r++)
 #pragma unroll
           for (int h = 0; h < NH; h++) acc[i][r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[r][h], acc[i][r][h], 0, 0, 0);
     if (more) store_unit(buf ^ 1);
@@ -181,17 +191,19 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
   }
   if (wave != 0) return;
   // [split][Cout][tap][ICP]: column (lane & 15) of block h of filter row r is tap 4 r + (16 h + column) / ICP, channel column % ICP
-  float* part = p.part + (size_t)split * p.Cout * (16 * ICP);
+  // (stride 1: [split][Cout][3 x 3 taps][4]; column (lane & 15) is tap column (lane & 15) / 4, the fourth is dropped)
+  constexpr int kRow = S == 2 ? 16 * ICP : 9 * ICP, kTapsPerRow = S == 2 ? 4 : 3;
+  float* part = p.part + (size_t)split * p.Cout * kRow;
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < NR; r++)
 #pragma unroll
       for (int h = 0; h < NH; h++)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int co = i * 16 + (lane >> 4) * 4 + e;
-          if (co < p.Cout) part[(size_t)co * (16 * ICP) + r * (4 * ICP) + h * 16 + (lane & 15)] = acc[i][r][h][e];
+          if (co < p.Cout && (S == 2 || (lane & 15) < 12)) part[(size_t)co * kRow + r * (kTapsPerRow * ICP) + h * 16 + (lane & 15)] = acc[i][r][h][e];
         }
 }
 
@@ -204,7 +216,15 @@ bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l) {
   return p.k_per_split % kUnit == 0 && p.y_cstride % 8 == 0 && p.y_coff % 8 == 0;
 }
 
+static bool wgrad_image_stride1(const WgradParams& p) {
+  static const bool off = getenv("GC_NO_IMAGE_3X3") != nullptr;
+  return !off && p.thin && p.Cin <= 4 && p.kh == 3 && p.kw == 3 && p.sh == 1 && p.sw == 1 && p.ph == 1 && p.pw == 1 && p.Wo % kTW == 0 &&
+         p.Ho % kTH == 0 && p.H == p.Ho && p.W == p.Wo && p.Cout % 16 == 0 && p.Cout <= 64 && p.x_cstride == p.Cin && p.x_coff == 0 &&
+         (long)p.H * p.W * p.Cin < (1l << 31);
+}
+
 bool wgrad_image_geometry(const WgradParams& p) {
+  if (wgrad_image_stride1(p)) return true;
   return p.thin && p.Cin <= 8 && p.kh == 4 && p.kw == 4 && p.sh == 2 && p.sw == 2 && p.ph == 1 && p.pw == 1 && p.Wo % kTW == 0 &&
          p.Ho % kTH == 0 && p.H == 2 * p.Ho && p.W == 2 * p.Wo && p.Cout % 16 == 0 && p.Cout <= 64 && p.x_cstride == p.Cin &&
          p.x_coff == 0 && (long)p.H * p.W * p.Cin < (1l << 31);
@@ -214,7 +234,10 @@ int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t s
   if (p.K <= 0 || p.splits <= 0) return GC_OK;
   ProfScope ps("gc::conv_wgrad_image_kernel", l.flops, stream);
   const dim3 grid((unsigned)p.splits), block(kThreads);
-  if (p.ICp == 8) {
+  if (wgrad_image_stride1(p)) {
+    if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 4, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 4, 1>), grid, block, 0, stream, p);
+  } else if (p.ICp == 8) {
     if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 8>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 8>), grid, block, 0, stream, p);
   } else {

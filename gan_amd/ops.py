@@ -879,6 +879,9 @@ def _(x, w, mask, mask_slope, stride, padding, precision, wkey, out_dtype=-1, al
     return x.new_empty(mask.shape, dtype=_out_dtype(x, out_dtype))
 
 
+_IMAGE_3X3 = os.environ.get("GC_NO_IMAGE_3X3") is None
+
+
 def _image_layer(x, gy, geom, precision):
     """fp32 image, bf16 gradient, in the geometry of the image layer's weight-gradient kernel (conv_wgrad_image.hip),
     which rounds the image to bf16 in registers: no bf16 copy of the image is needed."""
@@ -886,8 +889,11 @@ def _image_layer(x, gy, geom, precision):
         return False
     kh, kw, stride, padding = geom
     (_, Cin, H, W), (_, Cout, Ho, Wo) = x.shape, gy.shape
-    return (Cin <= 8 and kh == 4 and kw == 4 and stride == 2 and padding == 1 and Wo % 32 == 0 and Ho % 4 == 0 and H == 2 * Ho and W == 2 * Wo
-            and Cout % 16 == 0 and Cout <= 64)
+    if Wo % 32 or Ho % 4 or Cout % 16 or Cout > 64:
+        return False
+    if kh == 3 and kw == 3 and stride == 1 and padding == 1:          # (BigGAN's first discriminator block: 3 x 3 on the image)
+        return Cin <= 4 and H == Ho and W == Wo and _IMAGE_3X3
+    return Cin <= 8 and kh == 4 and kw == 4 and stride == 2 and padding == 1 and H == 2 * Ho and W == 2 * Wo
 
 
 def _wgrad_operands(x, gy, precision, geom=None):

@@ -134,3 +134,50 @@ def test_image_pair_data_gradient_on_the_few_channel_kernel(gan, cimg, cmid, hw,
     (gx,), names = _names(gan, lambda: torch.autograd.grad(y, (xg,), gy.cuda().to(dt)))
     assert any("conv_scatter_kernel" in n for n in names), sorted(names)
     assert torch.equal(gx.double().cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,N,act,odt", [(3, 64, 128, 128, 3, "relu", torch.bfloat16), (3, 32, 8, 64, 2, None, torch.float32),
+                                                   (4, 48, 12, 32, 5, "leaky_relu", torch.bfloat16), (1, 16, 4, 32, 1, "tanh", torch.float32)])
+def test_image_layer_3x3(gan, cin, cout, H, W, N, act, odt):
+    """A 3 x 3 / stride 1 / padding 1 convolution on an fp32 image of at most 4 channels (BigGAN's first discriminator block,
+    BigGAN/model.py:181-200) on the image-layer kernel.  Small integers: every sum is exact, so the pre-activation values
+    equal torch's CPU result bit for bit."""
+    g = torch.Generator().manual_seed(71 + cout)
+    x = torch.randint(-3, 4, (N, cin, H, W), generator=g).float()
+    w = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    want = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    if act == "relu":
+        want = torch.relu(want)
+    elif act == "leaky_relu":
+        want = torch.nn.functional.leaky_relu(want, 0.25)
+    elif act == "tanh":
+        want = torch.tanh(want)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last)
+    y, names = _names(gan, lambda: gan.functional.conv2d(xg, w.cuda(), b.cuda(), 1, 1, activation=act, negative_slope=0.25, out_dtype=odt))
+    assert "gc::conv_image_kernel" in names, sorted(names)
+    assert y.dtype == odt
+    if act == "tanh":
+        assert torch.allclose(y.double().cpu(), want, atol=2e-6)
+    else:
+        assert torch.equal(y.double().cpu(), want)          # (multiples of 1/4 of small integers: exact in bf16 too)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,N,xdt", [(3, 64, 128, 128, 5, torch.float32), (3, 32, 8, 64, 3, torch.float32), (4, 48, 12, 32, 7, torch.bfloat16),
+                                                (1, 16, 4, 32, 2, torch.float32)])
+def test_image_layer_3x3_weight_gradient(gan, cin, cout, H, W, N, xdt):
+    """Weight and bias gradient of the 3 x 3 / stride 1 / padding 1 image layer (BigGAN/model.py:181-200) on the image-layer
+    weight-gradient kernel; small integers, bit for bit torch's CPU gradient."""
+    g = torch.Generator().manual_seed(75 + cout)
+    x = torch.randint(-3, 4, (N, cin, H, W), generator=g).float()
+    w = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).float()
+    b = torch.zeros(cout)
+    gy = torch.randint(-2, 3, (N, cout, H, W), generator=g).float()
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), wr, br, 1, 1).backward(gy.double())
+    xg = x.cuda().to(xdt).contiguous(memory_format=torch.channels_last)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = gan.functional.conv2d(xg, wg, bg, 1, 1, out_dtype=torch.bfloat16)
+    (gw, gb), names = _names(gan, lambda: torch.autograd.grad(y, (wg, bg), gy.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)))
+    assert "gc::conv_wgrad_image_kernel" in names and not any("copy" in n for n in names), sorted(names)
+    assert torch.equal(gw.double().cpu(), wr.grad) and torch.equal(gb.double().cpu(), br.grad)
