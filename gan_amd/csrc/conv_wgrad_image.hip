@@ -27,9 +27,11 @@ constexpr int kGyBytes = kUnit * 128;
 // discriminator block, BigGAN/model.py:181-200), with the same reads: a filter row is still 4 taps x 4 channels = one block
 // of 16 columns per output pixel (the pixels k .. k + 3 of the patch row), the fourth tap's columns and a fourth filter row
 // are simply not kept; the patch carries two more columns than the three real taps read.
-constexpr int patch_h(int s) { return s == 2 ? 2 * kTH + 2 : kTH + 2; }
+// KS: filter size -- 4 (S = 2), or with S = 1: 3 (padding 1) or 1 (padding 0: a from-RGB layer, StyleGAN/model.py:453-514; one
+// filter row, of whose four columns of taps only the first is kept).
+constexpr int patch_h(int s, int ks) { return s == 2 ? 2 * kTH + 2 : kTH + ks - 1; }
 constexpr int patch_w(int s) { return s == 2 ? 2 * kTW + 2 : kTW + 4; }
-constexpr int patch_bytes(int icp, int s) { return patch_h(s) * patch_w(s) * 2 * icp; }
+constexpr int patch_bytes(int icp, int s, int ks) { return patch_h(s, ks) * patch_w(s) * 2 * icp; }
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -46,11 +48,11 @@ __device__ __forceinline__ bf16x8 read_tr(const char* a0, int second_offset) {
 // TX: storage type of the image (uint16_t = bf16, float: rounded to bf16 on the way into the patch)
 // ICP: channels of a patch pixel (4, or 8 for 5 to 8 input channels -- the PatchGAN's image pair, Pix2Pix/models.py:225-232: the
 // 4 taps x 8 channels of a filter row are then two blocks of 16 columns, twice the MFMAs and accumulators)
-template <typename TX, int ICP, int S = 2>
+template <typename TX, int ICP, int S = 2, int KS = 4>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradParams p) {
-  static_assert(S == 2 || (S == 1 && ICP == 4), "the stride-1 form: 4-channel patch pixels");
-  constexpr int kPH = patch_h(S), kPW = patch_w(S), NR = S == 2 ? 4 : 3;      // NR: filter rows
-  constexpr int kPatchBytes = patch_bytes(ICP, S);
+  static_assert((S == 2 && KS == 4) || (S == 1 && ICP == 4 && (KS == 3 || KS == 1)), "the stride-1 forms: 4-channel patch pixels, 3 x 3 or 1 x 1");
+  constexpr int kPH = patch_h(S, KS), kPW = patch_w(S), NR = KS, kPad = KS == 1 ? 0 : 1;      // NR: filter rows
+  constexpr int kPatchBytes = patch_bytes(ICP, S, KS);
   constexpr int NH = ICP / 4;                          // 16-column blocks per filter row
   __shared__ __attribute__((aligned(16))) char smem[2 * (kPatchBytes + kGyBytes)];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
         yreg[i] = *reinterpret_cast<const u32x4*>(gy + (k0 + (size_t)(row >> 5) * p.Wo + (row & 31)) * p.y_cstride + p.y_coff + ch * 8);
     }
     const TX* img = x + (size_t)n * p.H * p.W * p.Cin;
-    const int ih0 = S * kTH * th - 1, iw0 = S * kTW * tw - 1;
+    const int ih0 = S * kTH * th - kPad, iw0 = S * kTW * tw - kPad;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int ih = ih0 + ppr[i], iw = iw0 + ppc[i];
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
   if (wave != 0) return;
   // [split][Cout][tap][ICP]: column (lane & 15) of block h of filter row r is tap 4 r + (16 h + column) / ICP, channel column % ICP
   // (stride 1: [split][Cout][3 x 3 taps][4]; column (lane & 15) is tap column (lane & 15) / 4, the fourth is dropped)
-  constexpr int kRow = S == 2 ? 16 * ICP : 9 * ICP, kTapsPerRow = S == 2 ? 4 : 3;
+  constexpr int kRow = KS * KS * ICP, kTapsPerRow = KS;
   float* part = p.part + (size_t)split * p.Cout * kRow;
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_image_kernel(const WgradP
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int co = i * 16 + (lane >> 4) * 4 + e;
-          if (co < p.Cout && (S == 2 || (lane & 15) < 12)) part[(size_t)co * kRow + r * (kTapsPerRow * ICP) + h * 16 + (lane & 15)] = acc[i][r][h][e];
+          if (co < p.Cout && (S == 2 || (lane & 15) < 4 * KS)) part[(size_t)co * kRow + r * (kTapsPerRow * ICP) + h * 16 + (lane & 15)] = acc[i][r][h][e];
         }
 }
 
@@ -218,7 +220,8 @@ bool wgrad_image_applies(const WgradParams& p, const WgradLaunch& l) {
 
 static bool wgrad_image_stride1(const WgradParams& p) {
   static const bool off = getenv("GC_NO_IMAGE_3X3") != nullptr;
-  return !off && p.thin && p.Cin <= 4 && p.kh == 3 && p.kw == 3 && p.sh == 1 && p.sw == 1 && p.ph == 1 && p.pw == 1 && p.Wo % kTW == 0 &&
+  const bool k3 = p.kh == 3 && p.kw == 3 && p.ph == 1 && p.pw == 1, k1 = p.kh == 1 && p.kw == 1 && p.ph == 0 && p.pw == 0;
+  return !off && p.thin && p.Cin <= 4 && (k3 || k1) && p.sh == 1 && p.sw == 1 && p.Wo % kTW == 0 &&
          p.Ho % kTH == 0 && p.H == p.Ho && p.W == p.Wo && p.Cout % 16 == 0 && p.Cout <= 64 && p.x_cstride == p.Cin && p.x_coff == 0 &&
          (long)p.H * p.W * p.Cin < (1l << 31);
 }
@@ -235,8 +238,13 @@ int launch_wgrad_image(const WgradParams& p, const WgradLaunch& l, hipStream_t s
   ProfScope ps("gc::conv_wgrad_image_kernel", l.flops, stream);
   const dim3 grid((unsigned)p.splits), block(kThreads);
   if (wgrad_image_stride1(p)) {
-    if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 4, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 4, 1>), grid, block, 0, stream, p);
+    if (p.kh == 3) {
+      if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 4, 1, 3>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 4, 1, 3>), grid, block, 0, stream, p);
+    } else {
+      if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 4, 1, 1>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 4, 1, 1>), grid, block, 0, stream, p);
+    }
   } else if (p.ICp == 8) {
     if (p.x_f32) hipLaunchKernelGGL((conv_wgrad_image_kernel<float, 8>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_image_kernel<uint16_t, 8>), grid, block, 0, stream, p);

@@ -891,7 +891,8 @@ def _image_layer(x, gy, geom, precision):
     (_, Cin, H, W), (_, Cout, Ho, Wo) = x.shape, gy.shape
     if Wo % 32 or Ho % 4 or Cout % 16 or Cout > 64:
         return False
-    if kh == 3 and kw == 3 and stride == 1 and padding == 1:          # (BigGAN's first discriminator block: 3 x 3 on the image)
+    if stride == 1 and ((kh == 3 and kw == 3 and padding == 1) or (kh == 1 and kw == 1 and padding == 0)):
+        # (BigGAN's first discriminator block: 3 x 3 on the image; StyleGAN's from-RGB layers: 1 x 1)
         return Cin <= 4 and H == Ho and W == Wo and _IMAGE_3X3
     return Cin <= 8 and kh == 4 and kw == 4 and stride == 2 and padding == 1 and H == 2 * Ho and W == 2 * Wo
 

@@ -163,21 +163,23 @@ def test_image_layer_3x3(gan, cin, cout, H, W, N, act, odt):
         assert torch.equal(y.double().cpu(), want)          # (multiples of 1/4 of small integers: exact in bf16 too)
 
 
+@pytest.mark.parametrize("k", [3, 1])
 @pytest.mark.parametrize("cin,cout,H,W,N,xdt", [(3, 64, 128, 128, 5, torch.float32), (3, 32, 8, 64, 3, torch.float32), (4, 48, 12, 32, 7, torch.bfloat16),
                                                 (1, 16, 4, 32, 2, torch.float32)])
-def test_image_layer_3x3_weight_gradient(gan, cin, cout, H, W, N, xdt):
-    """Weight and bias gradient of the 3 x 3 / stride 1 / padding 1 image layer (BigGAN/model.py:181-200) on the image-layer
-    weight-gradient kernel; small integers, bit for bit torch's CPU gradient."""
-    g = torch.Generator().manual_seed(75 + cout)
+def test_image_layer_weight_gradient_stride_1(gan, cin, cout, H, W, N, xdt, k):
+    """Weight and bias gradient of a 3 x 3 / padding 1 (BigGAN/model.py:181-200) or 1 x 1 (a from-RGB layer,
+    StyleGAN/model.py:453-514) stride-1 layer on an image, on the image-layer weight-gradient kernel; small integers, bit for
+    bit torch's CPU gradient."""
+    g = torch.Generator().manual_seed(75 + cout + k)
     x = torch.randint(-3, 4, (N, cin, H, W), generator=g).float()
-    w = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).float()
+    w = torch.randint(-2, 3, (cout, cin, k, k), generator=g).float()
     b = torch.zeros(cout)
     gy = torch.randint(-2, 3, (N, cout, H, W), generator=g).float()
     wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
-    torch.nn.functional.conv2d(x.double(), wr, br, 1, 1).backward(gy.double())
+    torch.nn.functional.conv2d(x.double(), wr, br, 1, k // 2).backward(gy.double())
     xg = x.cuda().to(xdt).contiguous(memory_format=torch.channels_last)
     wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    y = gan.functional.conv2d(xg, wg, bg, 1, 1, out_dtype=torch.bfloat16)
+    y = gan.functional.conv2d(xg, wg, bg, 1, k // 2, out_dtype=torch.bfloat16)
     (gw, gb), names = _names(gan, lambda: torch.autograd.grad(y, (wg, bg), gy.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)))
     assert "gc::conv_wgrad_image_kernel" in names and not any("copy" in n for n in names), sorted(names)
     assert torch.equal(gw.double().cpu(), wr.grad) and torch.equal(gb.double().cpu(), br.grad)
