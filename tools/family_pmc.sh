@@ -4,6 +4,8 @@
 # Writes gpurun_out/<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of eager steps), traffic.{json,txt}
 # (FETCH_SIZE / WRITE_SIZE passes, per kernel and launch) and sq.txt (matrix-core, wait and LDS counters per kernel).
 # Every counter pass is a run of its own; counters never share a run with a trace.
+# BigGAN: run with GC_BIGGAN_INIT_ON_CPU=1 (the counter passes do not survive the solver library's QR kernels of the
+# orthogonal initialisation; with it the factorisations run on the host).
 set -e -o pipefail
 tag=$1; fam=$2
 out=gpurun_out/$tag
