@@ -159,8 +159,18 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
   if (MODE == 2 || MODE == 3) {      // (sum, sum of squares) per slice of the rows the convolution in front wrote: plain sums in double
     __shared__ double sh_s[kThreads], sh_q[kThreads];      // MODE 3: straight from the fp32 rows themselves (few rows: no slice pass)
     double ds = 0.0, dq = 0.0;
-    if (cok)
-      for (int s = lane; s < p.slabs; s += kFinLanes) {
+    if (cok) {
+      int s = lane;
+      if (MODE == 3)      // four rows in flight per step (the loads of a row wait for nothing but each other; same fixed order every run)
+        for (; s + 3 * kFinLanes < p.slabs; s += 4 * kFinLanes) {
+          const float2 v0 = *reinterpret_cast<const float2*>(p.part + ((size_t)s * p.C + c) * 2);
+          const float2 v1 = *reinterpret_cast<const float2*>(p.part + ((size_t)(s + kFinLanes) * p.C + c) * 2);
+          const float2 v2 = *reinterpret_cast<const float2*>(p.part + ((size_t)(s + 2 * kFinLanes) * p.C + c) * 2);
+          const float2 v3 = *reinterpret_cast<const float2*>(p.part + ((size_t)(s + 3 * kFinLanes) * p.C + c) * 2);
+          ds += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+          dq += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+        }
+      for (; s < p.slabs; s += kFinLanes) {
         if (MODE == 3) {
           const float2 v = *reinterpret_cast<const float2*>(p.part + ((size_t)s * p.C + c) * 2);
           ds += (double)v.x;
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const BnParams p)
           dq += v[1];
         }
       }
+    }
     sh_s[t] = ds; sh_q[t] = dq;
     __syncthreads();
     if (lane != 0 || !cok) return;
